@@ -1,0 +1,88 @@
+"""ctypes binding of libbge_world.so (include/bge_world.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libbge_world.so")
+
+
+class BgeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bge error {code}: {msg}")
+        self.code = code
+
+
+class WorldDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
+                ("pair_capacity", C.c_uint64)]
+
+
+class WorldInfo(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_entities", "n_transforms", "n_slots", "n_tiles", "n_passes", "n_roots",
+                                          "n_limbo", "n_bodies", "max_depth")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+# name -> (restype, argtypes); every symbol include/bge_world.h declares
+_vp, _u64, _u32, _f = C.c_void_p, C.c_uint64, C.c_uint32, C.c_float
+SYMBOLS = {
+    "bge_last_error": (C.c_char_p, []),
+    "bge_version": (_u32, []),
+    "bge_world_create": (C.c_int, [C.POINTER(WorldDesc), C.POINTER(_vp)]),
+    "bge_world_destroy": (None, [_vp]),
+    "bge_world_set_topology": (C.c_int, [_vp, _u64, _vp, _vp]),
+    "bge_world_upload_trs": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp]),
+    "bge_world_mark_dirty": (C.c_int, [_vp, _u64, _u64]),
+    "bge_world_upload_bodies": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bge_world_set_velocities": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
+    "bge_world_tick": (C.c_int, [_vp, _f, _vp, _u32]),
+    "bge_world_tick_many": (C.c_int, [_vp, _u32, _f, _vp, _u32]),
+    "bge_world_sync": (C.c_int, [_vp]),
+    "bge_world_download_world": (C.c_int, [_vp, _u64, _u64, _vp]),
+    "bge_world_download_pose": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
+    "bge_world_download_bodies": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "bge_world_download_dirty": (C.c_int, [_vp, _u64, _u64, _vp]),
+    "bge_world_dirty_count": (C.c_int, [_vp, C.POINTER(_u64)]),
+    "bge_world_pairs": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "bge_world_pack_roots": (C.c_int, [_vp, _vp]),
+    "bge_world_device_array": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
+    "bge_world_get_info": (C.c_int, [_vp, C.POINTER(WorldInfo)]),
+    "bge_flatten_topology": (C.c_int, [_u64, _vp, _vp, _vp, _vp, _vp, C.POINTER(WorldInfo)]),
+    "bge_partition_subtrees": (C.c_int, [_u64, _vp, _vp, _u32, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB
+
+
+def lib():
+    """Load libbge_world.so.  torch is imported first so that the HIP runtime torch bundles
+    (same SONAME libamdhip64.so.7) is the single runtime of the process."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError(f"{_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing, the library also loads against /opt/rocm
+            pass
+        l = C.CDLL(_LIB)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BgeError(rc, lib().bge_last_error().decode("utf-8", "replace"))

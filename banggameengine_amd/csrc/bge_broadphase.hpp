@@ -1,0 +1,43 @@
+// bge_broadphase.hpp — AABB broadphase on the device (see bge_broadphase.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+
+#include "bge_kernels.hpp"
+
+namespace bge {
+
+class Broadphase {
+public:
+    // n_slots: upper bound of bodies; pair_capacity: pairs kept per tick
+    int configure(uint64_t n_slots, uint64_t pair_capacity);
+    // Collect the overlapping pairs of the AABBs the tick kernel just wrote.
+    int run(hipStream_t stream, const WorldView& w, uint64_t n_slots_ticked, const uint32_t* entity_of_slot);
+    int download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uint64_t* total);
+    void release();
+    const char* error() const { return error_.c_str(); }
+    void* pairs_device() const { return pairs_; }
+    uint64_t capacity() const { return capacity_; }
+
+private:
+    int fail(int code, const char* what, hipError_t e);
+    std::string error_;
+    uint64_t n_slots_ = 0;
+    uint64_t capacity_ = 0;
+    uint32_t table_size_ = 0;
+    void* pairs_ = nullptr;      // uint32[capacity][2]
+    void* counters_ = nullptr;   // device scalars (pair count, bounds, ...)
+    void* cell_count_ = nullptr; // uint32[table_size + 1]
+    void* cell_start_ = nullptr; // uint32[table_size + 1]
+    void* scan_tmp_ = nullptr;
+    void* sorted_slot_ = nullptr; // uint32[n_slots]
+    void* sorted_aabb_ = nullptr; // float[n_slots][8] (min xyz, cell key, max xyz, filter word)
+    void* body_cell_ = nullptr;   // int32[n_slots][4]
+    void* large_list_ = nullptr;  // uint32[n_slots]
+    bool ran_ = false;
+};
+
+} // namespace bge

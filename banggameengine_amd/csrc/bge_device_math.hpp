@@ -1,0 +1,258 @@
+// bge_device_math.hpp — gfx950 device arithmetic of the world tick.
+//
+// Everything here is IEEE-754 binary32 with one rounding per operation (the translation unit is
+// compiled with -ffp-contract=off; divide and sqrt are HIP's correctly-rounded defaults), so the
+// results are the ones the reference's scalar-SSE /fp:precise build produces for the same inputs:
+//   bx_*      bx::floor / cos / sin / mtxSRT / mtxMul as called from src/ecs/Transform.cpp:18-36
+//             (constants and operation order: SURVEY.md §8 a-3 / a-4)
+//   bt_*      the Bullet pieces behind src/physics/PhysicsSystem.cpp:40-64, 863, 937-947
+//             (setEulerZYX, setRotation, getEulerZYX, integrateTransform, btTransformAabb);
+//             libm calls go through include/bge_detmath.h so host and device agree bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/bge_detmath.h"
+
+namespace bge {
+namespace dev {
+
+struct F3 {
+    float x, y, z;
+};
+struct Q4 {
+    float x, y, z, w;
+};
+
+__device__ __forceinline__ F3 ld3(const float* __restrict__ base, uint32_t slot)
+{
+    const float* p = base + 3ull * slot;
+    return F3{p[0], p[1], p[2]};
+}
+__device__ __forceinline__ void st3(float* __restrict__ base, uint32_t slot, const F3& v)
+{
+    float* p = base + 3ull * slot;
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+}
+__device__ __forceinline__ Q4 ld4(const float* __restrict__ base, uint32_t slot)
+{
+    const float4 v = reinterpret_cast<const float4*>(base)[slot];
+    return Q4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float* __restrict__ base, uint32_t slot, const Q4& q)
+{
+    reinterpret_cast<float4*>(base)[slot] = make_float4(q.x, q.y, q.z, q.w);
+}
+
+// ------------------------------------------------------------------ bx
+__device__ __forceinline__ float bx_floor(float a)
+{
+    if (a < 0.0f) {
+        const float na = -a;
+        const float fr = na - static_cast<float>(static_cast<int>(na));
+        const float result = na - fr;
+        return -(0.0f != fr ? result + 1.0f : result);
+    }
+    return a - (a - static_cast<float>(static_cast<int>(a)));
+}
+
+__device__ __forceinline__ float bx_cos(float a)
+{
+    const float kPiHalf = 1.5707963267948966f;
+    const float kInvPi = 0.31830988618379067f;
+    const float scaled = (a * 2.0f) * kInvPi;
+    const float real = bx_floor(scaled);
+    const float xx = a - real * kPiHalf;
+    const int quadrant = static_cast<int>(real) & 3;
+    const bool even = (quadrant & 1) == 0;
+
+    const float c0 = even ? 1.0f : xx;
+    const float c2 = even ? -0.5f : __uint_as_float(0xbe2aaaabu);
+    const float c4 = __uint_as_float(even ? 0x3d2aaaa4u : 0x3c088898u);
+    const float c6 = __uint_as_float(even ? 0xbab60981u : 0xb9501096u);
+    const float c8 = __uint_as_float(even ? 0x37cfab9cu : 0x363938a8u);
+    const float c10 = __uint_as_float(even ? 0xb48b634du : 0xb2d70013u);
+
+    const float xsq = xx * xx;
+    float acc = c10 * xsq + c8;
+    acc = acc * xsq + c6;
+    acc = acc * xsq + c4;
+    acc = acc * xsq + c2;
+    acc = acc * xsq + 1.0f;
+    const float result = acc * c0;
+    return (quadrant == 1 || quadrant == 2) ? -result : result;
+}
+
+__device__ __forceinline__ float bx_sin(float a) { return bx_cos(a - 1.5707963267948966f); }
+
+// local = S * R(euler) * T, row-major (bx::mtxSRT)
+__device__ __forceinline__ void bx_mtx_srt(float (&m)[16], const F3& s, const F3& r, const F3& t)
+{
+    const float sx = bx_sin(r.x);
+    const float cx = bx_cos(r.x);
+    const float sy = bx_sin(r.y);
+    const float cy = bx_cos(r.y);
+    const float sz = bx_sin(r.z);
+    const float cz = bx_cos(r.z);
+    const float sxsz = sx * sz;
+    const float cycz = cy * cz;
+
+    m[0] = s.x * (cycz - sxsz * sy);
+    m[1] = (s.x * -cx) * sz;
+    m[2] = s.x * (sxsz * cy + cz * sy);
+    m[3] = 0.0f;
+    m[4] = s.y * ((cz * sx) * sy + sz * cy);
+    m[5] = (s.y * cx) * cz;
+    m[6] = s.y * (sz * sy - cycz * sx);
+    m[7] = 0.0f;
+    m[8] = (s.z * -cx) * sy;
+    m[9] = s.z * sx;
+    m[10] = (s.z * cx) * cy;
+    m[11] = 0.0f;
+    m[12] = t.x;
+    m[13] = t.y;
+    m[14] = t.z;
+    m[15] = 1.0f;
+}
+
+// out = a * b, each element ((a0*b[j] + a1*b[4+j]) + a2*b[8+j]) + a3*b[12+j]   (bx::vec4MulMtx)
+__device__ __forceinline__ void bx_mtx_mul(float (&o)[16], const float (&a)[16], const float (&b)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[4 * i + j] = ((a[4 * i + 0] * b[j] + a[4 * i + 1] * b[4 + j]) + a[4 * i + 2] * b[8 + j])
+                           + a[4 * i + 3] * b[12 + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Bullet pieces
+constexpr float kBtEpsilon = 1.1920928955078125e-07f;
+constexpr float kBtPi = 3.1415926535897932384626433832795029f;
+constexpr float kBtAngularMotionThreshold = 0.5f * (kBtPi * 0.5f);
+constexpr float kBtContactBreakingThreshold = 0.02f;
+
+struct M3 {
+    float m[3][3];
+};
+
+// ToBtQuaternion(euler) = setEulerZYX(yaw = e.y, pitch = e.x, roll = e.z)
+__device__ __forceinline__ Q4 bt_quat_from_transform_euler(const F3& e)
+{
+    const float halfYaw = e.y * 0.5f;
+    const float halfPitch = e.x * 0.5f;
+    const float halfRoll = e.z * 0.5f;
+    const float cosYaw = bge_det_cosf(halfYaw);
+    const float sinYaw = bge_det_sinf(halfYaw);
+    const float cosPitch = bge_det_cosf(halfPitch);
+    const float sinPitch = bge_det_sinf(halfPitch);
+    const float cosRoll = bge_det_cosf(halfRoll);
+    const float sinRoll = bge_det_sinf(halfRoll);
+    Q4 q;
+    q.x = cosYaw * cosPitch * sinRoll - sinYaw * sinPitch * cosRoll;
+    q.y = cosYaw * sinPitch * cosRoll + sinYaw * cosPitch * sinRoll;
+    q.z = sinYaw * cosPitch * cosRoll - cosYaw * sinPitch * sinRoll;
+    q.w = cosYaw * cosPitch * cosRoll + sinYaw * sinPitch * sinRoll;
+    return q;
+}
+
+__device__ __forceinline__ float bt_quat_length2(const Q4& q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+
+__device__ __forceinline__ M3 bt_mat_from_quat(const Q4& q)
+{
+    const float d = bt_quat_length2(q);
+    const float s = 2.0f / d;
+    const float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    const float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+    const float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    M3 r;
+    r.m[0][0] = 1.0f - (yy + zz);
+    r.m[0][1] = xy - wz;
+    r.m[0][2] = xz + wy;
+    r.m[1][0] = xy + wz;
+    r.m[1][1] = 1.0f - (xx + zz);
+    r.m[1][2] = yz - wx;
+    r.m[2][0] = xz - wy;
+    r.m[2][1] = yz + wx;
+    r.m[2][2] = 1.0f - (xx + yy);
+    return r;
+}
+
+// Transform::rotationEuler written by SyncRigidBodiesFromPhysics: {pitch, yaw, roll} of getEulerZYX
+__device__ __forceinline__ F3 bt_transform_euler_from_mat(const M3& a)
+{
+    float yaw, pitch, roll;
+    if (__builtin_fabsf(a.m[2][0]) >= 1.0f) {
+        yaw = 0.0f;
+        const float delta = bge_det_atan2f(a.m[0][0], a.m[0][2]);
+        if (a.m[2][0] > 0.0f) {
+            pitch = kBtPi / 2.0f;
+            roll = pitch + delta;
+        } else {
+            pitch = -kBtPi / 2.0f;
+            roll = -pitch + delta;
+        }
+    } else {
+        float sp = a.m[2][0];
+        sp = sp < -1.0f ? -1.0f : sp;
+        sp = sp > 1.0f ? 1.0f : sp;
+        pitch = -bge_det_asinf(sp);
+        const float c = bge_det_cosf(pitch);
+        roll = bge_det_atan2f(a.m[2][1] / c, a.m[2][2] / c);
+        yaw = bge_det_atan2f(a.m[1][0] / c, a.m[0][0] / c);
+    }
+    return F3{pitch, yaw, roll};
+}
+
+// rotation part of btTransformUtil::integrateTransform
+__device__ __forceinline__ Q4 bt_integrate_orientation(const Q4& orn0, const F3& w, float dt)
+{
+    const float fAngle2 = w.x * w.x + w.y * w.y + w.z * w.z;
+    float fAngle = 0.0f;
+    if (fAngle2 > kBtEpsilon) fAngle = __builtin_sqrtf(fAngle2);
+    if (fAngle * dt > kBtAngularMotionThreshold) fAngle = kBtAngularMotionThreshold / dt;
+    float k;
+    if (fAngle < 0.001f) {
+        k = 0.5f * dt - (dt * dt * dt) * 0.020833333333f * fAngle * fAngle;
+    } else {
+        k = bge_det_sinf(0.5f * fAngle * dt) / fAngle;
+    }
+    const Q4 a{w.x * k, w.y * k, w.z * k, bge_det_cosf(fAngle * dt * 0.5f)};
+    const Q4& b = orn0;
+    Q4 r;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    const float l2 = bt_quat_length2(r);
+    if (l2 > kBtEpsilon) {
+        const float s = 1.0f / __builtin_sqrtf(l2);
+        r.x *= s;
+        r.y *= s;
+        r.z *= s;
+        r.w *= s;
+    }
+    return bt_quat_length2(r) > kBtEpsilon ? r : orn0;
+}
+
+// btTransformAabb + updateSingleAabb's contact threshold
+__device__ __forceinline__ void bt_aabb_of_pose(const F3& o, const M3& r, const F3& he, float (&mn)[3], float (&mx)[3])
+{
+    const float ex = __builtin_fabsf(r.m[0][0]) * he.x + __builtin_fabsf(r.m[0][1]) * he.y + __builtin_fabsf(r.m[0][2]) * he.z;
+    const float ey = __builtin_fabsf(r.m[1][0]) * he.x + __builtin_fabsf(r.m[1][1]) * he.y + __builtin_fabsf(r.m[1][2]) * he.z;
+    const float ez = __builtin_fabsf(r.m[2][0]) * he.x + __builtin_fabsf(r.m[2][1]) * he.y + __builtin_fabsf(r.m[2][2]) * he.z;
+    mn[0] = (o.x - ex) - kBtContactBreakingThreshold;
+    mn[1] = (o.y - ey) - kBtContactBreakingThreshold;
+    mn[2] = (o.z - ez) - kBtContactBreakingThreshold;
+    mx[0] = (o.x + ex) + kBtContactBreakingThreshold;
+    mx[1] = (o.y + ey) + kBtContactBreakingThreshold;
+    mx[2] = (o.z + ez) + kBtContactBreakingThreshold;
+}
+
+} // namespace dev
+} // namespace bge

@@ -1,0 +1,440 @@
+// bge_kernels.hip — hand-written gfx950 kernels of the world tick.
+//
+// k_tick<PHYS, XFORM, AABB>: one workgroup (4 wave64) per 256-slot tile.
+//   PHYS   rigid-body slice of PhysicsSystem::Update for free bodies
+//          (src/physics/PhysicsSystem.cpp:952-989 re-pose rule, :863 one Bullet sub-step,
+//           :916-950 write-back + mark dirty)
+//   XFORM  TransformSystem::Update (src/ecs/TransformSystem.cpp:10-46): local = mtxSRT, then
+//          world = parentWorld * local level by level inside the tile, the parents' world matrices
+//          staged in LDS (16 KiB per workgroup), one workgroup barrier per level
+//   AABB   the per-body AABB Bullet feeds its broadphase (current pose U predicted pose, +0.02)
+//
+// Memory plan (all streams indexed by slot, 256 consecutive slots per workgroup):
+//   reads   flags 4 B, pos/euler/scale 12 B each, vel 12 B + inv_mass 4 B (Dynamic bodies only),
+//           parent 4 B (only in tiles that have a hierarchy)
+//   writes  pos 12 B + vel 12 B (Dynamic only), world 64 B; flags only when a bit changed
+//   The world matrices leave through LDS so that every wave-level store instruction writes 1 KiB of
+//   contiguous memory (16 B per lane), whatever the per-node compute layout was.
+//   The kernel is HBM-bound (~250 flop against >= 113 B per entity): no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "bge_device_math.hpp"
+#include "bge_flatten.hpp"
+#include "bge_kernels.hpp"
+
+namespace bge {
+
+using namespace dev;
+
+namespace {
+
+// LDS image of the tile's world matrices: node n, row r lives at float4 index n*4 + (r ^ ((n>>2)&3)).
+// The XOR spreads the four 64-B rows of consecutive nodes over all 64 banks for ds_read_b128
+// (lanes n, n+4, n+8, n+12 of a 16-lane group would otherwise share a bank).
+__device__ __forceinline__ uint32_t lds_row(uint32_t n, uint32_t r) { return n * 4u + (r ^ ((n >> 2) & 3u)); }
+
+__device__ __forceinline__ void lds_put(float4* lds, uint32_t n, const float (&m)[16])
+{
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) lds[lds_row(n, r)] = make_float4(m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]);
+}
+
+__device__ __forceinline__ void lds_get(const float4* lds, uint32_t n, float (&m)[16])
+{
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        const float4 v = lds[lds_row(n, r)];
+        m[4 * r] = v.x;
+        m[4 * r + 1] = v.y;
+        m[4 * r + 2] = v.z;
+        m[4 * r + 3] = v.w;
+    }
+}
+
+template <bool PHYS, bool XFORM, bool AABB>
+__global__ void __launch_bounds__(kTile) k_tick(WorldView w, TickParams p)
+{
+    __shared__ float4 lds[kTile * 4];
+
+    const uint32_t tile = p.tile_begin + blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slot = tile * kTile + tid;
+    const uint32_t hdr = w.tile_hdr[tile];
+    const uint32_t count = (hdr >> kHdrCountShift) & kHdrCountMask;
+    const uint32_t max_level = hdr & kHdrLevelMask;
+
+    const uint32_t f0 = w.flags[slot];
+    uint32_t f = f0;
+    const bool valid = (f & kValid) != 0;
+
+    F3 pos{0.0f, 0.0f, 0.0f}, eul{0.0f, 0.0f, 0.0f}, scl{1.0f, 1.0f, 1.0f};
+    if (valid) {
+        pos = ld3(w.pos, slot);
+        eul = ld3(w.euler, slot);
+        if (XFORM) scl = ld3(w.scale, slot);
+    }
+
+    if (PHYS) {
+        const uint32_t type = f & kTypeMask;
+        if (valid && type != 0) {
+            const bool dynamic = type == 2u;
+            const bool repose = (f & (kTDirty | kBDirty)) != 0;
+            bool spin = (f & kSpin) != 0;
+            Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
+            F3 v{0.0f, 0.0f, 0.0f};
+            F3 av{0.0f, 0.0f, 0.0f};
+            if (repose) {
+                // SyncKinematicBodiesToPhysics / EnsureRigidBody: pose from the LOCAL Transform, zero velocities
+                q = bt_quat_from_transform_euler(eul);
+                st4(w.quat, slot, q);
+                if (dynamic && spin) {
+                    st3(w.angvel, slot, av);
+                    spin = false;
+                    f &= ~kSpin;
+                }
+            } else {
+                if (dynamic) v = ld3(w.vel, slot);
+                if (spin) av = ld3(w.angvel, slot);
+                if (spin || AABB) q = ld4(w.quat, slot);
+            }
+
+            if (AABB) {
+                const F3 he = ld3(w.half_extent, slot);
+                const M3 r = bt_mat_from_quat(q);
+                float mn[3], mx[3];
+                bt_aabb_of_pose(pos, r, he, mn, mx);
+                if (dynamic) {
+                    // interpolation transform of predictUnconstraintMotion: velocity before the gravity impulse
+                    const F3 pp{pos.x + v.x * p.dt, pos.y + v.y * p.dt, pos.z + v.z * p.dt};
+                    float mn2[3], mx2[3];
+                    if (spin) {
+                        const M3 r2 = bt_mat_from_quat(bt_integrate_orientation(q, av, p.dt));
+                        bt_aabb_of_pose(pp, r2, he, mn2, mx2);
+                    } else {
+                        bt_aabb_of_pose(pp, r, he, mn2, mx2);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        mn[a] = mn2[a] < mn[a] ? mn2[a] : mn[a];
+                        mx[a] = mx2[a] > mx[a] ? mx2[a] : mx[a];
+                    }
+                }
+                float* bb = w.aabb + 6ull * slot;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    bb[a] = mn[a];
+                    bb[3 + a] = mx[a];
+                }
+            }
+
+            if (dynamic) {
+                const float inv_mass = w.inv_mass[slot];
+                if (inv_mass != 0.0f) {
+                    // applyGravity (F = g * (1/invMass)) + solver write-back of the external force impulse
+                    const float mass = 1.0f / inv_mass;
+                    v.x = v.x + ((p.gx * mass) * inv_mass) * p.dt;
+                    v.y = v.y + ((p.gy * mass) * inv_mass) * p.dt;
+                    v.z = v.z + ((p.gz * mass) * inv_mass) * p.dt;
+                    // integrateTransforms
+                    pos.x = pos.x + v.x * p.dt;
+                    pos.y = pos.y + v.y * p.dt;
+                    pos.z = pos.z + v.z * p.dt;
+                    if (spin) {
+                        q = bt_integrate_orientation(q, av, p.dt);
+                        st4(w.quat, slot, q);
+                    }
+                    st3(w.vel, slot, v);
+                    st3(w.pos, slot, pos);
+                } else if (repose) {
+                    st3(w.vel, slot, v);
+                }
+                // SyncRigidBodiesFromPhysics: rotationEuler <- getEulerZYX(basis) whenever the orientation was
+                // (re)posed or advanced; a non-spinning body keeps its euler triple bit for bit
+                if (repose || spin) {
+                    eul = bt_transform_euler_from_mat(bt_mat_from_quat(q));
+                    st3(w.euler, slot, eul);
+                }
+                f |= kTDirty; // transform->MarkDirty()
+            }
+            f &= ~kBDirty;
+        }
+    }
+
+    if (XFORM) {
+        float local[16];
+        bx_mtx_srt(local, scl, eul, pos);
+
+        if (max_level == 0 && (hdr & kHdrExt) == 0) {
+            // flat tile: every node is a root, world = local (Transform.cpp:32-35)
+            if (valid) lds_put(lds, tid, local);
+        } else {
+            const uint32_t level = (f & kLevelMask) >> kLevelShift;
+            const uint32_t parent = (f & kHasParent) ? w.parent[slot] : kNone;
+            float world[16];
+            if (valid && level == 0) {
+                if (f & kExtParent) {
+                    // parent resolved by an earlier launch: read its world matrix from memory
+                    float pw[16];
+                    const float4* src = reinterpret_cast<const float4*>(w.world) + 4ull * parent;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float4 t = src[r];
+                        pw[4 * r] = t.x;
+                        pw[4 * r + 1] = t.y;
+                        pw[4 * r + 2] = t.z;
+                        pw[4 * r + 3] = t.w;
+                    }
+                    bx_mtx_mul(world, pw, local);
+                    lds_put(lds, tid, world);
+                } else {
+                    lds_put(lds, tid, local);
+                }
+            }
+            for (uint32_t d = 1; d <= max_level; ++d) {
+                __syncthreads();
+                if (valid && level == d) {
+                    float pw[16];
+                    lds_get(lds, parent, pw);
+                    bx_mtx_mul(world, pw, local); // parent * local — the reference's order
+                    lds_put(lds, tid, world);
+                }
+            }
+        }
+        __syncthreads();
+        // coalesced write-out: lane t stores float4 #(t + 256k) of the tile's 16 KiB image
+        float4* dst = reinterpret_cast<float4*>(w.world) + 4ull * kTile * tile;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t qi = tid + kTile * k;
+            const uint32_t n = qi >> 2;
+            const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
+            if (n < count) dst[n * 4u + r] = lds[qi];
+        }
+        f &= ~kTDirty; // transform->dirty = false
+    }
+
+    if (f != f0) w.flags[slot] = f;
+}
+
+// ------------------------------------------------------------------ component scatter / gather (entity order <-> slots)
+// stage holds `count` rows of `width` 32-bit words for entities [first, first+count).
+__global__ void k_scatter_rows(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+                               uint32_t width, const uint32_t* __restrict__ stage, uint32_t* __restrict__ dst,
+                               uint32_t* __restrict__ flags, uint32_t or_bits)
+{
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t slot = slot_of_entity[first + i];
+    if (slot == kNone) return;
+    if (dst) {
+        for (uint32_t k = 0; k < width; ++k) dst[static_cast<uint64_t>(slot) * width + k] = stage[i * width + k];
+    }
+    if (flags && or_bits) flags[slot] |= or_bits;
+}
+
+__global__ void k_gather_rows(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+                              uint32_t width, const uint32_t* __restrict__ src, uint32_t* __restrict__ stage)
+{
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t slot = slot_of_entity[first + i];
+    for (uint32_t k = 0; k < width; ++k) {
+        stage[i * width + k] = slot == kNone ? 0u : src[static_cast<uint64_t>(slot) * width + k];
+    }
+}
+
+// Body upload: type/shape bits + dirty, inverse mass, AABB half extents, group/mask.
+__global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+                                 const uint32_t* __restrict__ type_bits, const float* __restrict__ inv_mass,
+                                 const float* __restrict__ half_extent3, const uint32_t* __restrict__ group,
+                                 const uint32_t* __restrict__ mask, WorldView w)
+{
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t slot = slot_of_entity[first + i];
+    if (slot == kNone) return;
+    uint32_t f = w.flags[slot];
+    f &= ~(kTypeMask | kBDirty | kSpin | kCapsule);
+    f |= type_bits[i];
+    w.flags[slot] = f;
+    w.inv_mass[slot] = inv_mass[i];
+    w.half_extent[3ull * slot + 0] = half_extent3[3 * i + 0];
+    w.half_extent[3ull * slot + 1] = half_extent3[3 * i + 1];
+    w.half_extent[3ull * slot + 2] = half_extent3[3 * i + 2];
+    w.group[slot] = group[i];
+    w.mask[slot] = mask[i];
+    if ((f & kTypeMask) == 0) {
+        // body removed: forget its state
+        w.vel[3ull * slot] = w.vel[3ull * slot + 1] = w.vel[3ull * slot + 2] = 0.0f;
+        w.angvel[3ull * slot] = w.angvel[3ull * slot + 1] = w.angvel[3ull * slot + 2] = 0.0f;
+    }
+}
+
+__global__ void k_scatter_velocities(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+                                     const float* __restrict__ lin, const float* __restrict__ ang, WorldView w)
+{
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t slot = slot_of_entity[first + i];
+    if (slot == kNone) return;
+    uint32_t f = w.flags[slot];
+    if ((f & kTypeMask) != 2u) return; // only Dynamic bodies carry velocity
+    if (lin) {
+        w.vel[3ull * slot + 0] = lin[3 * i + 0];
+        w.vel[3ull * slot + 1] = lin[3 * i + 1];
+        w.vel[3ull * slot + 2] = lin[3 * i + 2];
+    }
+    if (ang) {
+        const float ax = ang[3 * i + 0], ay = ang[3 * i + 1], az = ang[3 * i + 2];
+        w.angvel[3ull * slot + 0] = ax;
+        w.angvel[3ull * slot + 1] = ay;
+        w.angvel[3ull * slot + 2] = az;
+        const uint32_t nf = (ax != 0.0f || ay != 0.0f || az != 0.0f) ? (f | kSpin) : (f & ~kSpin);
+        if (nf != f) w.flags[slot] = nf;
+    }
+}
+
+__global__ void k_init_slots(uint64_t n_slots, const uint32_t* __restrict__ structural_flags, WorldView w)
+{
+    const uint64_t s = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (s >= n_slots) return;
+    const uint32_t sf = structural_flags[s];
+    w.flags[s] = (sf & kValid) ? (sf | kTDirty) : sf; // Transform::Transform(): dirty = true
+    w.pos[3 * s] = w.pos[3 * s + 1] = w.pos[3 * s + 2] = 0.0f;
+    w.euler[3 * s] = w.euler[3 * s + 1] = w.euler[3 * s + 2] = 0.0f;
+    w.scale[3 * s] = w.scale[3 * s + 1] = w.scale[3 * s + 2] = 1.0f;
+    w.vel[3 * s] = w.vel[3 * s + 1] = w.vel[3 * s + 2] = 0.0f;
+    w.angvel[3 * s] = w.angvel[3 * s + 1] = w.angvel[3 * s + 2] = 0.0f;
+    w.quat[4 * s] = w.quat[4 * s + 1] = w.quat[4 * s + 2] = 0.0f;
+    w.quat[4 * s + 3] = 1.0f;
+    w.inv_mass[s] = 0.0f;
+    w.half_extent[3 * s] = w.half_extent[3 * s + 1] = w.half_extent[3 * s + 2] = 0.5f;
+    w.group[s] = 1u;
+    w.mask[s] = 0xffffffffu;
+    // mtxIdentity(local), mtxIdentity(world)
+    for (int k = 0; k < 16; ++k) w.world[16 * s + k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    for (int k = 0; k < 6; ++k) w.aabb[6 * s + k] = 0.0f;
+}
+
+// Scene::CountDirtyTransforms: per-lane predicate -> wave ballot popcount -> one atomic per wave.
+__global__ void k_count_dirty(uint64_t n_slots, const uint32_t* __restrict__ flags, unsigned long long* __restrict__ out)
+{
+    uint64_t s = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long local = 0;
+    for (; s < n_slots; s += stride) {
+        const uint32_t f = flags[s];
+        local += ((f & kValid) && (f & kTDirty)) ? 1ull : 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63u) == 0 && local) atomicAdd(out, local);
+}
+
+__global__ void k_dirty_bytes(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+                              const uint32_t* __restrict__ flags, uint8_t* __restrict__ out)
+{
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t slot = slot_of_entity[first + i];
+    out[i] = (slot != kNone && (flags[slot] & kTDirty)) ? 1 : 0;
+}
+
+// Root table for the per-frame all-gather: 4 lanes per root, 16 B each.
+__global__ void k_pack_roots(uint64_t n_roots, const uint32_t* __restrict__ root_slots, const float4* __restrict__ world,
+                             float4* __restrict__ dst)
+{
+    const uint64_t t = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t r = t >> 2;
+    if (r >= n_roots) return;
+    dst[t] = world[4ull * root_slots[r] + (t & 3u)];
+}
+
+inline dim3 grid_for(uint64_t n, uint32_t block) { return dim3(static_cast<uint32_t>((n + block - 1) / block)); }
+
+} // namespace
+
+// ------------------------------------------------------------------ launch wrappers
+hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams& p, uint32_t n_tiles, uint32_t flags)
+{
+    if (n_tiles == 0) return hipSuccess;
+    const bool phys = (flags & 1u) != 0, xform = (flags & 2u) != 0, aabb = (flags & 4u) != 0;
+    const dim3 grid(n_tiles), block(kTile);
+    if (phys && xform && aabb) hipLaunchKernelGGL((k_tick<true, true, true>), grid, block, 0, stream, w, p);
+    else if (phys && xform) hipLaunchKernelGGL((k_tick<true, true, false>), grid, block, 0, stream, w, p);
+    else if (phys && aabb) hipLaunchKernelGGL((k_tick<true, false, true>), grid, block, 0, stream, w, p);
+    else if (phys) hipLaunchKernelGGL((k_tick<true, false, false>), grid, block, 0, stream, w, p);
+    else if (xform) hipLaunchKernelGGL((k_tick<false, true, false>), grid, block, 0, stream, w, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                               uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_rows, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count, width,
+                       static_cast<const uint32_t*>(stage), static_cast<uint32_t*>(dst), flags, or_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                              uint32_t width, const void* src, void* stage)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_rows, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count, width,
+                       static_cast<const uint32_t*>(src), static_cast<uint32_t*>(stage));
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                                 const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
+                                 const uint32_t* group, const uint32_t* mask, const WorldView& w)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_bodies, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count,
+                       type_bits, inv_mass, half_extent3, group, mask, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_velocities(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                                     const float* lin, const float* ang, const WorldView& w)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_velocities, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count,
+                       lin, ang, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_slots(hipStream_t stream, uint64_t n_slots, const uint32_t* structural_flags, const WorldView& w)
+{
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_init_slots, grid_for(n_slots, 256), dim3(256), 0, stream, n_slots, structural_flags, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_dirty(hipStream_t stream, uint64_t n_slots, const uint32_t* flags, unsigned long long* out)
+{
+    if (n_slots == 0) return hipSuccess;
+    const uint64_t blocks = (n_slots + 255) / 256;
+    hipLaunchKernelGGL(k_count_dirty, dim3(static_cast<uint32_t>(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream,
+                       n_slots, flags, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_dirty_bytes(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                              const uint32_t* flags, uint8_t* out)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dirty_bytes, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count, flags, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst)
+{
+    if (n_roots == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_roots, grid_for(n_roots * 4, 256), dim3(256), 0, stream, n_roots, root_slots,
+                       reinterpret_cast<const float4*>(world), reinterpret_cast<float4*>(dst));
+    return hipGetLastError();
+}
+
+} // namespace bge

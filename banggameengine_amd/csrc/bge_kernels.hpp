@@ -1,0 +1,57 @@
+// bge_kernels.hpp — device data layout and kernel launch entry points (see bge_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace bge {
+
+// Structure-of-arrays image of the Scene's components in HBM.  Every array is indexed by SLOT
+// (bge_flatten.hpp); 256 consecutive slots form the tile one workgroup ticks.
+struct WorldView {
+    uint32_t* flags;          // [slots] body type, dirty bits, level, ...
+    const uint32_t* parent;   // [slots] in-tile index / global slot of the parent
+    const uint32_t* tile_hdr; // [tiles]
+    // Transform (src/ecs/Transform.h:14-16)
+    float* pos;               // [slots][3]  Transform::position == rigid body origin
+    float* euler;             // [slots][3]  Transform::rotationEuler
+    float* scale;             // [slots][3]
+    // world matrices (Transform::world); `local` is never materialised
+    float* world;             // [slots][16]
+    // rigid body state (Bullet's btRigidBody) and parameters
+    float* vel;               // [slots][3]
+    float* angvel;            // [slots][3]
+    float* quat;              // [slots][4]
+    float* inv_mass;          // [slots]
+    float* half_extent;       // [slots][3]  AABB half extents of the collider in its own frame
+    uint32_t* group;          // [slots]     collision filter group (layer)
+    uint32_t* mask;           // [slots]
+    float* aabb;              // [slots][6]  min xyz, max xyz fed to the broadphase
+};
+
+struct TickParams {
+    float dt;
+    float gx, gy, gz;
+    uint32_t tile_begin;
+};
+
+// flags: bit0 physics, bit1 transforms, bit2 aabb (bge_tick_flags)
+hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams& p, uint32_t n_tiles, uint32_t flags);
+
+hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                               uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits);
+hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                              uint32_t width, const void* src, void* stage);
+hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                                 const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
+                                 const uint32_t* group, const uint32_t* mask, const WorldView& w);
+hipError_t launch_scatter_velocities(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                                     const float* lin, const float* ang, const WorldView& w);
+hipError_t launch_init_slots(hipStream_t stream, uint64_t n_slots, const uint32_t* structural_flags, const WorldView& w);
+hipError_t launch_count_dirty(hipStream_t stream, uint64_t n_slots, const uint32_t* flags, unsigned long long* out);
+hipError_t launch_dirty_bytes(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
+                              const uint32_t* flags, uint8_t* out);
+hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst);
+
+} // namespace bge

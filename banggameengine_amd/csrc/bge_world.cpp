@@ -1,0 +1,737 @@
+// bge_world.cpp — implementation of the C ABI declared in include/bge_world.h.
+//
+// Host-side plumbing only: device allocation, the entity-index <-> slot maps, staging of uploads and
+// downloads, and kernel launches on the world's stream.  All arithmetic of the hot path is in
+// bge_kernels.hip; there is no CPU fallback — every entry point that needs the GPU fails with
+// BGE_ERR_HIP when no device is usable.
+#include "../../include/bge_world.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bge_broadphase.hpp"
+#include "bge_flatten.hpp"
+#include "bge_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        const hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? BGE_ERR_OOM : BGE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+        }                                                                                                  \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        const hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// Collider size -> AABB half extents in the collider's frame.
+// Box: btBoxShape ctor (implicit = he - 0.04), setSafeMargin (margin = min(0.04, 0.1*min he) through
+// btBoxShape::setMargin), btTransformAabb adds the margin back.  Capsule (up axis Y): (r, r+h/2, r).
+// Reference clamps: src/physics/PhysicsSystem.cpp:692-703.
+void collider_half_extents(uint8_t shape, const float* size, float* out)
+{
+    if (shape == BGE_SHAPE_CAPSULE) {
+        const float radius = std::max(size[0], 0.01f);
+        const float half_height = std::max(size[1], 0.0f);
+        const float h = 0.5f * (half_height * 2.0f);
+        out[0] = radius;
+        out[1] = radius + h;
+        out[2] = radius;
+        return;
+    }
+    const float hx = std::max(size[0], 0.01f), hy = std::max(size[1], 0.01f), hz = std::max(size[2], 0.01f);
+    const float m0 = 0.04f;
+    float ix = hx - m0, iy = hy - m0, iz = hz - m0;
+    const float min_dim = std::min(hx, std::min(hy, hz));
+    const float safe = 0.1f * min_dim;
+    float margin = m0;
+    if (safe < margin) {
+        ix = (ix + m0) - safe;
+        iy = (iy + m0) - safe;
+        iz = (iz + m0) - safe;
+        margin = safe;
+    }
+    out[0] = ix + margin;
+    out[1] = iy + margin;
+    out[2] = iz + margin;
+}
+
+} // namespace
+
+struct bge_world {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t pair_capacity_req = 0;
+
+    bge::Flattened flat;
+    std::vector<uint32_t> parent_entity; // effective topology input of the last set_topology
+    std::vector<uint8_t> has_tf;
+    bool has_topology = false;
+    bool maybe_dirty = true;
+    uint64_t n_bodies_hint = 0;
+
+    // device arrays
+    DevBuf flags, parent, tile_hdr, slot_of_entity, root_slots;
+    DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
+    DevBuf root_worlds, counter, stage, stage2;
+    bge::Broadphase broadphase;
+    bge::WorldView view{};
+
+    void rebuild_view()
+    {
+        view.flags = flags.as<uint32_t>();
+        view.parent = parent.as<uint32_t>();
+        view.tile_hdr = tile_hdr.as<uint32_t>();
+        view.pos = pos.as<float>();
+        view.euler = euler.as<float>();
+        view.scale = scale.as<float>();
+        view.world = world.as<float>();
+        view.vel = vel.as<float>();
+        view.angvel = angvel.as<float>();
+        view.quat = quat.as<float>();
+        view.inv_mass = inv_mass.as<float>();
+        view.half_extent = half_extent.as<float>();
+        view.group = group.as<uint32_t>();
+        view.mask = mask.as<uint32_t>();
+        view.aabb = aabb.as<float>();
+    }
+    void release_all()
+    {
+        for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &root_slots, &pos, &euler, &scale, &world, &vel,
+                          &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
+                          &stage2}) {
+            b->release();
+        }
+        broadphase.release();
+    }
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int check_range(const bge_world* w, uint64_t first, uint64_t count)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    if (first > w->flat.n_entities || count > w->flat.n_entities - first) {
+        return fail(BGE_ERR_INVALID, "entity range [%llu, +%llu) outside [0, %llu)", (unsigned long long)first,
+                    (unsigned long long)count, (unsigned long long)w->flat.n_entities);
+    }
+    return BGE_OK;
+}
+
+// upload one host array of `count` rows x `width` words into a per-slot device array
+int upload_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, const void* host, void* dst,
+                uint32_t or_bits)
+{
+    const size_t bytes = static_cast<size_t>(count) * width * 4;
+    HIP_TRY(w->stage.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(w->stage.p, host, bytes, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(bge::launch_scatter_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, width, w->stage.p, dst,
+                                     w->flags.as<uint32_t>(), or_bits));
+    // the staging buffer is reused by the next call
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return BGE_OK;
+}
+
+int download_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, const void* src, void* host)
+{
+    const size_t bytes = static_cast<size_t>(count) * width * 4;
+    HIP_TRY(w->stage.ensure(bytes));
+    HIP_TRY(bge::launch_gather_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, width, src, w->stage.p));
+    HIP_TRY(hipMemcpyAsync(host, w->stage.p, bytes, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return BGE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* bge_last_error(void) { return g_last_error.c_str(); }
+uint32_t bge_version(void) { return 0x00010000u; }
+
+int bge_world_create(const bge_world_desc* desc, bge_world** out)
+{
+    if (!out) return fail(BGE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (desc && desc->struct_size != 0 && desc->struct_size < sizeof(bge_world_desc)) {
+        return fail(BGE_ERR_INVALID, "bge_world_desc.struct_size %u < %zu", desc->struct_size, sizeof(bge_world_desc));
+    }
+    int ndev = 0;
+    {
+        const hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) {
+            return fail(BGE_ERR_HIP, "no usable HIP device (hipGetDeviceCount: %s, count %d) — this library has no CPU path",
+                        hipGetErrorString(e), ndev);
+        }
+    }
+    int device = desc ? desc->device : -1;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(BGE_ERR_INVALID, "device %d out of range (count %d)", device, ndev);
+
+    bge_world* w = new (std::nothrow) bge_world();
+    if (!w) return fail(BGE_ERR_OOM, "host allocation failed");
+    w->device = device;
+    DeviceGuard guard(device);
+    if (desc && desc->stream) {
+        w->stream = static_cast<hipStream_t>(desc->stream);
+    } else {
+        const hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete w;
+            return fail(BGE_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+        }
+        w->own_stream = true;
+    }
+    w->pair_capacity_req = desc ? desc->pair_capacity : 0;
+    *out = w;
+    return BGE_OK;
+}
+
+void bge_world_destroy(bge_world* w)
+{
+    if (!w) return;
+    DeviceGuard guard(w->device);
+    (void)hipStreamSynchronize(w->stream);
+    w->release_all();
+    if (w->own_stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+}
+
+int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, const uint8_t* has_transform)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (n >= 0xfffffff0ull) return fail(BGE_ERR_INVALID, "too many entities (%llu)", (unsigned long long)n);
+    DeviceGuard guard(w->device);
+
+    bge::Flattened nf;
+    try {
+        bge::flatten_topology(n, parent, has_transform, nf);
+    } catch (const std::bad_alloc&) {
+        return fail(BGE_ERR_OOM, "host allocation failed while flattening %llu entities", (unsigned long long)n);
+    }
+
+    // ---- carry component state of surviving entity indices over to the new layout
+    const bool carry = w->has_topology && w->flat.n_slots > 0;
+    const uint64_t n_keep = carry ? std::min<uint64_t>(n, w->flat.n_entities) : 0;
+    struct Carry {
+        DevBuf* buf;
+        uint32_t width;
+        DevBuf tmp;
+    };
+    std::vector<Carry> carries;
+    DevBuf old_flags_tmp;
+    if (n_keep) {
+        for (auto [buf, width] : std::initializer_list<std::pair<DevBuf*, uint32_t>>{
+                 {&w->pos, 3}, {&w->euler, 3}, {&w->scale, 3}, {&w->world, 16}, {&w->vel, 3}, {&w->angvel, 3},
+                 {&w->quat, 4}, {&w->inv_mass, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6}}) {
+            carries.push_back(Carry{buf, width, DevBuf{}});
+        }
+        for (Carry& c : carries) {
+            HIP_TRY(c.tmp.ensure(n_keep * c.width * 4));
+            HIP_TRY(bge::launch_gather_rows(w->stream, w->slot_of_entity.as<uint32_t>(), 0, n_keep, c.width, c.buf->p, c.tmp.p));
+        }
+        HIP_TRY(old_flags_tmp.ensure(n_keep * 4));
+        HIP_TRY(bge::launch_gather_rows(w->stream, w->slot_of_entity.as<uint32_t>(), 0, n_keep, 1, w->flags.p, old_flags_tmp.p));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+
+    // ---- which surviving transforms changed parent (Scene::SetParent marks the subtree dirty, Scene.cpp:392)
+    std::vector<uint8_t> keep_mask(n_keep, 0); // 1 = carried over, 2 = carried over but hierarchy-dirty
+    if (n_keep) {
+        std::vector<uint32_t> eff_new(n, bge::kNone);
+        for (uint64_t i = 0; i < n; ++i) {
+            const bool tf = !has_transform || has_transform[i];
+            const uint32_t p = parent ? parent[i] : bge::kNone;
+            if (tf && p != bge::kNone && p < n && (!has_transform || has_transform[p])) eff_new[i] = p;
+        }
+        std::vector<uint32_t> order; // BFS over the new forest so that dirtiness flows parent -> child
+        order.reserve(n);
+        std::vector<uint32_t> child_begin(n + 1, 0), child_list;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (eff_new[i] != bge::kNone) child_begin[eff_new[i] + 1]++;
+        }
+        for (uint64_t i = 0; i < n; ++i) child_begin[i + 1] += child_begin[i];
+        child_list.resize(child_begin[n]);
+        {
+            std::vector<uint32_t> cur(child_begin.begin(), child_begin.end() - 1);
+            for (uint64_t i = 0; i < n; ++i) {
+                if (eff_new[i] != bge::kNone) child_list[cur[eff_new[i]]++] = static_cast<uint32_t>(i);
+            }
+        }
+        std::vector<uint8_t> hdirty(n, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (nf.slot_of_entity[i] != bge::kNone && eff_new[i] == bge::kNone) order.push_back(static_cast<uint32_t>(i));
+        }
+        for (size_t h = 0; h < order.size(); ++h) {
+            const uint32_t u = order[h];
+            const bool survived = u < n_keep && w->flat.slot_of_entity[u] != bge::kNone;
+            const uint32_t old_parent = (u < w->parent_entity.size()) ? w->parent_entity[u] : bge::kNone;
+            bool d = !survived || old_parent != eff_new[u];
+            if (eff_new[u] != bge::kNone && hdirty[eff_new[u]]) d = true;
+            hdirty[u] = d ? 1 : 0;
+            for (uint32_t c = child_begin[u]; c < child_begin[u + 1]; ++c) order.push_back(child_list[c]);
+        }
+        for (uint64_t i = 0; i < n_keep; ++i) {
+            if (nf.slot_of_entity[i] == bge::kNone || w->flat.slot_of_entity[i] == bge::kNone) continue;
+            keep_mask[i] = hdirty[i] ? 2 : 1;
+        }
+        w->parent_entity.swap(eff_new);
+    } else {
+        w->parent_entity.assign(n, bge::kNone);
+        for (uint64_t i = 0; i < n; ++i) {
+            const bool tf = !has_transform || has_transform[i];
+            const uint32_t p = parent ? parent[i] : bge::kNone;
+            if (tf && p != bge::kNone && p < n && (!has_transform || has_transform[p])) w->parent_entity[i] = p;
+        }
+    }
+
+    // ---- (re)allocate for the new layout
+    const uint64_t S = std::max<uint64_t>(nf.n_slots, bge::kTile);
+    const uint64_t T = std::max<uint32_t>(nf.n_tiles_total, 1);
+    HIP_TRY(w->flags.ensure(S * 4));
+    HIP_TRY(w->parent.ensure(S * 4));
+    HIP_TRY(w->tile_hdr.ensure(T * 4));
+    HIP_TRY(w->slot_of_entity.ensure(std::max<uint64_t>(n, 1) * 4));
+    HIP_TRY(w->root_slots.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 4));
+    HIP_TRY(w->pos.ensure(S * 12));
+    HIP_TRY(w->euler.ensure(S * 12));
+    HIP_TRY(w->scale.ensure(S * 12));
+    HIP_TRY(w->world.ensure(S * 64));
+    HIP_TRY(w->vel.ensure(S * 12));
+    HIP_TRY(w->angvel.ensure(S * 12));
+    HIP_TRY(w->quat.ensure(S * 16));
+    HIP_TRY(w->inv_mass.ensure(S * 4));
+    HIP_TRY(w->half_extent.ensure(S * 12));
+    HIP_TRY(w->group.ensure(S * 4));
+    HIP_TRY(w->mask.ensure(S * 4));
+    HIP_TRY(w->aabb.ensure(S * 24));
+    HIP_TRY(w->root_worlds.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 64));
+    HIP_TRY(w->counter.ensure(64));
+    w->rebuild_view();
+
+    if (nf.n_slots) {
+        HIP_TRY(hipMemcpyAsync(w->parent.p, nf.parent_field.data(), nf.n_slots * 4, hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(hipMemcpyAsync(w->tile_hdr.p, nf.tile_hdr.data(), static_cast<size_t>(nf.n_tiles_total) * 4,
+                               hipMemcpyHostToDevice, w->stream));
+        // structural flags travel through the staging buffer, k_init_slots merges them
+        HIP_TRY(w->stage.ensure(nf.n_slots * 4));
+        HIP_TRY(hipMemcpyAsync(w->stage.p, nf.flags.data(), nf.n_slots * 4, hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(bge::launch_init_slots(w->stream, nf.n_slots, w->stage.as<uint32_t>(), w->view));
+    }
+    if (n) HIP_TRY(hipMemcpyAsync(w->slot_of_entity.p, nf.slot_of_entity.data(), n * 4, hipMemcpyHostToDevice, w->stream));
+    if (!nf.root_slots.empty()) {
+        HIP_TRY(hipMemcpyAsync(w->root_slots.p, nf.root_slots.data(), nf.root_slots.size() * 4, hipMemcpyHostToDevice, w->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(w->stream));
+
+    if (n_keep) {
+        // entities that lost or gained their Transform restart from defaults: route them to "no slot"
+        std::vector<uint32_t> carry_map(n_keep, bge::kNone);
+        for (uint64_t i = 0; i < n_keep; ++i) {
+            if (keep_mask[i]) carry_map[i] = nf.slot_of_entity[i];
+        }
+        DevBuf map_dev;
+        HIP_TRY(map_dev.ensure(n_keep * 4));
+        HIP_TRY(hipMemcpyAsync(map_dev.p, carry_map.data(), n_keep * 4, hipMemcpyHostToDevice, w->stream));
+        for (Carry& c : carries) {
+            HIP_TRY(bge::launch_scatter_rows(w->stream, map_dev.as<uint32_t>(), 0, n_keep, c.width, c.tmp.p, c.buf->p, nullptr, 0));
+        }
+        // flags: keep body type / dirty / spin / shape bits of the old word, structure from the new one
+        std::vector<uint32_t> old_flags(n_keep);
+        HIP_TRY(hipMemcpy(old_flags.data(), old_flags_tmp.p, n_keep * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> merged(nf.flags);
+        const uint32_t keep_bits = bge::kTypeMask | bge::kTDirty | bge::kBDirty | bge::kSpin | bge::kCapsule;
+        for (uint64_t s = 0; s < nf.n_slots; ++s) {
+            if (merged[s] & bge::kValid) merged[s] |= bge::kTDirty;
+        }
+        for (uint64_t i = 0; i < n_keep; ++i) {
+            if (!keep_mask[i]) continue;
+            const uint32_t s = nf.slot_of_entity[i];
+            uint32_t f = (nf.flags[s] & ~keep_bits) | (old_flags[i] & keep_bits);
+            if (keep_mask[i] == 2) f |= bge::kTDirty;
+            merged[s] = f;
+        }
+        HIP_TRY(hipMemcpyAsync(w->flags.p, merged.data(), nf.n_slots * 4, hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        for (Carry& c : carries) c.tmp.release();
+        old_flags_tmp.release();
+        map_dev.release();
+    }
+
+    uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(4 * n, 1024);
+    {
+        const int rc = w->broadphase.configure(S, cap);
+        if (rc != BGE_OK) return fail(rc, "broadphase allocation failed");
+    }
+
+    w->flat = std::move(nf);
+    w->has_tf.assign(n, 1);
+    if (has_transform) std::copy(has_transform, has_transform + n, w->has_tf.begin());
+    w->has_topology = true;
+    w->maybe_dirty = true;
+    return BGE_OK;
+}
+
+int bge_world_upload_trs(bge_world* w, uint64_t first, uint64_t count, const float* pos3, const float* euler3,
+                         const float* scale3)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    if (pos3) {
+        if (int rc = upload_rows(w, first, count, 3, pos3, w->pos.p, 0)) return rc;
+    }
+    if (euler3) {
+        if (int rc = upload_rows(w, first, count, 3, euler3, w->euler.p, 0)) return rc;
+    }
+    if (scale3) {
+        if (int rc = upload_rows(w, first, count, 3, scale3, w->scale.p, 0)) return rc;
+    }
+    return bge_world_mark_dirty(w, first, count);
+}
+
+int bge_world_mark_dirty(bge_world* w, uint64_t first, uint64_t count)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    HIP_TRY(bge::launch_scatter_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, 0, nullptr, nullptr,
+                                     w->flags.as<uint32_t>(), bge::kTDirty));
+    w->maybe_dirty = true;
+    return BGE_OK;
+}
+
+int bge_world_upload_bodies(bge_world* w, uint64_t first, uint64_t count, const uint8_t* type, const float* mass,
+                            const uint8_t* shape, const float* size3, const uint32_t* layer, const uint32_t* mask)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (!type) return fail(BGE_ERR_INVALID, "type is NULL");
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+
+    // host: component values -> device parameters (PhysicsSystem.cpp:398-477, 686-707)
+    std::vector<uint32_t> words(count * 7);
+    uint32_t* type_bits = words.data();
+    float* inv_mass = reinterpret_cast<float*>(words.data() + count);
+    float* he = reinterpret_cast<float*>(words.data() + 2 * count);
+    uint32_t* group = words.data() + 5 * count;
+    uint32_t* msk = words.data() + 6 * count;
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint8_t t = type[i];
+        if (t != BGE_BODY_NONE && t > BGE_BODY_KINEMATIC) return fail(BGE_ERR_INVALID, "type[%llu] = %u", (unsigned long long)i, t);
+        const uint8_t sh = shape ? shape[i] : BGE_SHAPE_BOX;
+        const float default_size[3] = {0.5f, 0.5f, 0.5f};
+        const float* sz = size3 ? size3 + 3 * i : default_size;
+        if (t == BGE_BODY_NONE) {
+            type_bits[i] = 0;
+            inv_mass[i] = 0.0f;
+        } else {
+            type_bits[i] = (static_cast<uint32_t>(t) + 1u) | bge::kBDirty | (sh == BGE_SHAPE_CAPSULE ? bge::kCapsule : 0u);
+            float m = 0.0f;
+            if (t == BGE_BODY_DYNAMIC) m = std::max(mass ? mass[i] : 1.0f, 0.01f);
+            inv_mass[i] = m != 0.0f ? 1.0f / m : 0.0f;
+        }
+        collider_half_extents(sh, sz, he + 3 * i);
+        const uint32_t l = layer ? layer[i] : 1u;
+        group[i] = l ? l : 1u;
+        msk[i] = mask ? mask[i] : 0xffffffffu;
+    }
+    const size_t bytes = words.size() * 4;
+    HIP_TRY(w->stage.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(w->stage.p, words.data(), bytes, hipMemcpyHostToDevice, w->stream));
+    const uint32_t* d = w->stage.as<uint32_t>();
+    HIP_TRY(bge::launch_scatter_bodies(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, d,
+                                       reinterpret_cast<const float*>(d + count), reinterpret_cast<const float*>(d + 2 * count),
+                                       d + 5 * count, d + 6 * count, w->view));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->maybe_dirty = true;
+    return BGE_OK;
+}
+
+int bge_world_set_velocities(bge_world* w, uint64_t first, uint64_t count, const float* linvel3, const float* angvel3)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0 || (!linvel3 && !angvel3)) return BGE_OK;
+    DeviceGuard guard(w->device);
+    const size_t rows = static_cast<size_t>(count) * 12;
+    HIP_TRY(w->stage.ensure(rows * 2));
+    float* dl = w->stage.as<float>();
+    float* da = reinterpret_cast<float*>(static_cast<char*>(w->stage.p) + rows);
+    if (linvel3) HIP_TRY(hipMemcpyAsync(dl, linvel3, rows, hipMemcpyHostToDevice, w->stream));
+    if (angvel3) HIP_TRY(hipMemcpyAsync(da, angvel3, rows, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(bge::launch_scatter_velocities(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, linvel3 ? dl : nullptr,
+                                           angvel3 ? da : nullptr, w->view));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return BGE_OK;
+}
+
+int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float gravity[3], uint32_t flags)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    if ((flags & (BGE_TICK_PHYSICS | BGE_TICK_TRANSFORMS)) == 0) return fail(BGE_ERR_INVALID, "tick flags select nothing");
+    if ((flags & BGE_TICK_BROADPHASE) && !(flags & BGE_TICK_PHYSICS)) {
+        return fail(BGE_ERR_INVALID, "BGE_TICK_BROADPHASE needs BGE_TICK_PHYSICS (the AABBs come from the physics step)");
+    }
+    if ((flags & BGE_TICK_PHYSICS) && !gravity) return fail(BGE_ERR_INVALID, "gravity is NULL");
+    DeviceGuard guard(w->device);
+    const bool phys = (flags & BGE_TICK_PHYSICS) != 0;
+    const bool xform = (flags & BGE_TICK_TRANSFORMS) != 0;
+    for (uint32_t t = 0; t < ticks; ++t) {
+        if (!phys && !w->maybe_dirty) continue; // TransformSystem::Update with nothing dirty: a no-op scan
+        bge::TickParams p{};
+        p.dt = dt;
+        p.gx = gravity ? gravity[0] : 0.0f;
+        p.gy = gravity ? gravity[1] : 0.0f;
+        p.gz = gravity ? gravity[2] : 0.0f;
+        const size_t n_passes = w->flat.pass_tile_begin.size() - 1;
+        for (size_t pass = 0; pass < n_passes; ++pass) {
+            p.tile_begin = w->flat.pass_tile_begin[pass];
+            const uint32_t n_tiles = w->flat.pass_tile_begin[pass + 1] - p.tile_begin;
+            HIP_TRY(bge::launch_tick(w->stream, w->view, p, n_tiles, flags));
+        }
+        if (flags & BGE_TICK_BROADPHASE) {
+            const int rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
+                                             w->slot_of_entity.as<uint32_t>());
+            if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
+        }
+        w->maybe_dirty = phys && !xform;
+    }
+    return BGE_OK;
+}
+
+int bge_world_tick(bge_world* w, float dt, const float gravity[3], uint32_t flags)
+{
+    return bge_world_tick_many(w, 1, dt, gravity, flags);
+}
+
+int bge_world_sync(bge_world* w)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return BGE_OK;
+}
+
+int bge_world_download_world(bge_world* w, uint64_t first, uint64_t count, float* out16)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (!out16) return fail(BGE_ERR_INVALID, "out16 is NULL");
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    return download_rows(w, first, count, 16, w->world.p, out16);
+}
+
+int bge_world_download_pose(bge_world* w, uint64_t first, uint64_t count, float* pos3, float* euler3)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    if (pos3) {
+        if (int rc = download_rows(w, first, count, 3, w->pos.p, pos3)) return rc;
+    }
+    if (euler3) {
+        if (int rc = download_rows(w, first, count, 3, w->euler.p, euler3)) return rc;
+    }
+    return BGE_OK;
+}
+
+int bge_world_download_bodies(bge_world* w, uint64_t first, uint64_t count, float* linvel3, float* angvel3, float* quat4,
+                              float* aabb6)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    if (linvel3) {
+        if (int rc = download_rows(w, first, count, 3, w->vel.p, linvel3)) return rc;
+    }
+    if (angvel3) {
+        if (int rc = download_rows(w, first, count, 3, w->angvel.p, angvel3)) return rc;
+    }
+    if (quat4) {
+        if (int rc = download_rows(w, first, count, 4, w->quat.p, quat4)) return rc;
+    }
+    if (aabb6) {
+        if (int rc = download_rows(w, first, count, 6, w->aabb.p, aabb6)) return rc;
+    }
+    return BGE_OK;
+}
+
+int bge_world_download_dirty(bge_world* w, uint64_t first, uint64_t count, uint8_t* dirty)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (!dirty) return fail(BGE_ERR_INVALID, "dirty is NULL");
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    HIP_TRY(w->stage.ensure(count));
+    HIP_TRY(bge::launch_dirty_bytes(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, w->flags.as<uint32_t>(),
+                                    w->stage.as<uint8_t>()));
+    HIP_TRY(hipMemcpyAsync(dirty, w->stage.p, count, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return BGE_OK;
+}
+
+int bge_world_dirty_count(bge_world* w, uint64_t* out)
+{
+    if (!w || !out) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    DeviceGuard guard(w->device);
+    HIP_TRY(hipMemsetAsync(w->counter.p, 0, 8, w->stream));
+    HIP_TRY(bge::launch_count_dirty(w->stream, w->flat.n_slots, w->flags.as<uint32_t>(), w->counter.as<unsigned long long>()));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, w->counter.p, 8, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    *out = v;
+    return BGE_OK;
+}
+
+int bge_world_pairs(bge_world* w, uint32_t* pairs2, uint64_t cap, uint64_t* total)
+{
+    if (!w || !total) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    DeviceGuard guard(w->device);
+    const int rc = w->broadphase.download(w->stream, pairs2, cap, total);
+    if (rc != BGE_OK) return fail(rc, "pair download failed: %s", w->broadphase.error());
+    return BGE_OK;
+}
+
+int bge_world_pack_roots(bge_world* w, void* dst_device)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    DeviceGuard guard(w->device);
+    float* dst = dst_device ? static_cast<float*>(dst_device) : w->root_worlds.as<float>();
+    HIP_TRY(bge::launch_pack_roots(w->stream, w->flat.root_slots.size(), w->root_slots.as<uint32_t>(), w->world.as<float>(), dst));
+    return BGE_OK;
+}
+
+int bge_world_device_array(bge_world* w, int which, void** device_ptr, uint64_t* elements)
+{
+    if (!w || !device_ptr) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    uint64_t n = 0;
+    void* p = nullptr;
+    switch (which) {
+    case BGE_ARRAY_WORLD: p = w->world.p; n = w->flat.n_slots; break;
+    case BGE_ARRAY_ROOT_WORLDS: p = w->root_worlds.p; n = w->flat.root_slots.size(); break;
+    case BGE_ARRAY_SLOT_OF_ENTITY: p = w->slot_of_entity.p; n = w->flat.n_entities; break;
+    case BGE_ARRAY_POSITION: p = w->pos.p; n = w->flat.n_slots; break;
+    case BGE_ARRAY_PAIRS: p = w->broadphase.pairs_device(); n = w->broadphase.capacity(); break;
+    default: return fail(BGE_ERR_INVALID, "unknown device array %d", which);
+    }
+    *device_ptr = p;
+    if (elements) *elements = n;
+    return BGE_OK;
+}
+
+static void fill_info(const bge::Flattened& f, bge_world_info* info)
+{
+    info->n_entities = f.n_entities;
+    info->n_transforms = f.n_transforms;
+    info->n_slots = f.n_slots;
+    info->n_tiles = f.n_tiles_ticked;
+    info->n_passes = f.pass_tile_begin.size() - 1;
+    info->n_roots = f.root_slots.size();
+    info->n_limbo = f.n_limbo;
+    info->n_bodies = 0;
+    info->max_depth = f.max_depth;
+}
+
+int bge_world_get_info(bge_world* w, bge_world_info* info)
+{
+    if (!w || !info) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    fill_info(w->flat, info);
+    return BGE_OK;
+}
+
+int bge_flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, uint32_t* slot_of_entity,
+                         uint8_t* level_of_entity, uint32_t* pass_of_entity, bge_world_info* info)
+{
+    if (n >= 0xfffffff0ull) return fail(BGE_ERR_INVALID, "too many entities");
+    bge::Flattened f;
+    try {
+        bge::flatten_topology(n, parent, has_transform, f);
+    } catch (const std::bad_alloc&) {
+        return fail(BGE_ERR_OOM, "host allocation failed");
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t s = f.slot_of_entity[i];
+        if (slot_of_entity) slot_of_entity[i] = s;
+        if (level_of_entity) level_of_entity[i] = s == bge::kNone ? 0 : static_cast<uint8_t>((f.flags[s] & bge::kLevelMask) >> bge::kLevelShift);
+        if (pass_of_entity) pass_of_entity[i] = f.pass_of_entity[i];
+    }
+    if (info) fill_info(f, info);
+    return BGE_OK;
+}
+
+int bge_partition_subtrees(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, uint32_t nranks,
+                           uint32_t* rank_of_entity, uint64_t* nodes_per_rank)
+{
+    if (!rank_of_entity || nranks == 0) return fail(BGE_ERR_INVALID, "bad arguments");
+    try {
+        bge::partition_subtrees(n, parent, has_transform, nranks, rank_of_entity, nodes_per_rank);
+    } catch (const std::bad_alloc&) {
+        return fail(BGE_ERR_OOM, "host allocation failed");
+    }
+    return BGE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,187 @@
+"""Thin numpy face of the C ABI (include/bge_world.h).  One method per entry point; no logic of its own."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import WorldDesc, WorldInfo, check, lib
+
+NO_PARENT = 0xFFFFFFFF
+BODY_STATIC, BODY_DYNAMIC, BODY_KINEMATIC, BODY_NONE = 0, 1, 2, 255
+SHAPE_BOX, SHAPE_CAPSULE = 0, 1
+TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL = 1, 2, 4, 3
+ARRAY_WORLD, ARRAY_ROOT_WORLDS, ARRAY_SLOT_OF_ENTITY, ARRAY_POSITION, ARRAY_PAIRS = 0, 1, 2, 3, 4
+
+# fixed step and gravity of the reference (assets/config/physics.json:2-3)
+FIXED_DT = float(np.float32(0.0083333333))
+GRAVITY = (0.0, -9.81, 0.0)
+
+
+def _arr(a, dtype, shape_tail=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape_tail is not None and a.ndim == 2 and a.shape[1] != shape_tail:
+        raise ValueError(f"expected (*, {shape_tail}) array, got {a.shape}")
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class World:
+    """A device-resident mirror of one reference ``Scene`` (see include/bge_world.h)."""
+
+    def __init__(self, device: int = -1, stream: int | None = None, pair_capacity: int = 0):
+        self._h = C.c_void_p()
+        desc = WorldDesc(C.sizeof(WorldDesc), device, C.c_void_p(stream) if stream else None, pair_capacity)
+        check(lib().bge_world_create(C.byref(desc), C.byref(self._h)))
+        self.n = 0
+
+    def close(self):
+        if self._h:
+            lib().bge_world_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- topology and components
+    def set_topology(self, parent, has_transform=None):
+        parent = _arr(parent, np.uint32)
+        ht = _arr(has_transform, np.uint8)
+        self.n = len(parent)
+        check(lib().bge_world_set_topology(self._h, self.n, _p(parent), _p(ht)))
+        return self
+
+    def upload_trs(self, pos=None, euler=None, scale=None, first=0):
+        pos, euler, scale = (_arr(a, np.float32, 3) for a in (pos, euler, scale))
+        count = next(len(a) for a in (pos, euler, scale) if a is not None)
+        check(lib().bge_world_upload_trs(self._h, first, count, _p(pos), _p(euler), _p(scale)))
+
+    def mark_dirty(self, first=0, count=None):
+        check(lib().bge_world_mark_dirty(self._h, first, self.n - first if count is None else count))
+
+    def upload_bodies(self, body_type, mass=None, shape=None, size=None, layer=None, mask=None, first=0):
+        t = _arr(body_type, np.uint8)
+        check(lib().bge_world_upload_bodies(self._h, first, len(t), _p(t), _p(_arr(mass, np.float32)),
+                                            _p(_arr(shape, np.uint8)), _p(_arr(size, np.float32, 3)),
+                                            _p(_arr(layer, np.uint32)), _p(_arr(mask, np.uint32))))
+
+    def set_velocities(self, linvel=None, angvel=None, first=0):
+        l, a = _arr(linvel, np.float32, 3), _arr(angvel, np.float32, 3)
+        count = len(l) if l is not None else len(a)
+        check(lib().bge_world_set_velocities(self._h, first, count, _p(l), _p(a)))
+
+    # -- tick
+    def tick(self, dt=FIXED_DT, gravity=GRAVITY, flags=TICK_ALL, ticks=1):
+        g = (C.c_float * 3)(*gravity)
+        check(lib().bge_world_tick_many(self._h, ticks, dt, g, flags))
+
+    def sync(self):
+        check(lib().bge_world_sync(self._h))
+
+    # -- results
+    def download_world(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((count, 16), np.float32)
+        check(lib().bge_world_download_world(self._h, first, count, _p(out)))
+        return out
+
+    def download_pose(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        pos, euler = np.empty((count, 3), np.float32), np.empty((count, 3), np.float32)
+        check(lib().bge_world_download_pose(self._h, first, count, _p(pos), _p(euler)))
+        return pos, euler
+
+    def download_bodies(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        v, w, q, bb = (np.empty((count, k), np.float32) for k in (3, 3, 4, 6))
+        check(lib().bge_world_download_bodies(self._h, first, count, _p(v), _p(w), _p(q), _p(bb)))
+        return dict(linvel=v, angvel=w, quat=q, aabb=bb)
+
+    def download_dirty(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        d = np.empty(count, np.uint8)
+        check(lib().bge_world_download_dirty(self._h, first, count, _p(d)))
+        return d.astype(bool)
+
+    def dirty_count(self) -> int:
+        v = C.c_uint64(0)
+        check(lib().bge_world_dirty_count(self._h, C.byref(v)))
+        return int(v.value)
+
+    def pairs(self, cap=None):
+        """Sorted (a, b) entity-index pairs of the last BROADPHASE tick."""
+        total = C.c_uint64(0)
+        cap = int(cap or max(1024, 8 * self.n))
+        buf = np.empty((cap, 2), np.uint32)
+        check(lib().bge_world_pairs(self._h, _p(buf), cap, C.byref(total)))
+        if total.value > cap:
+            raise _capi.BgeError(-1, f"pair buffer too small: {total.value} > {cap}")
+        out = buf[: total.value]
+        order = np.lexsort((out[:, 1], out[:, 0]))
+        return out[order].copy()
+
+    def pair_count(self) -> int:
+        total = C.c_uint64(0)
+        check(lib().bge_world_pairs(self._h, None, 0, C.byref(total)))
+        return int(total.value)
+
+    # -- multi-GPU support / device-resident consumers
+    def pack_roots(self, dst_device_ptr: int | None = None):
+        check(lib().bge_world_pack_roots(self._h, C.c_void_p(dst_device_ptr) if dst_device_ptr else None))
+
+    def device_array(self, which: int):
+        ptr, n = C.c_void_p(), C.c_uint64(0)
+        check(lib().bge_world_device_array(self._h, which, C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
+    def info(self) -> dict:
+        inf = WorldInfo()
+        check(lib().bge_world_get_info(self._h, C.byref(inf)))
+        return inf.as_dict()
+
+    # -- convenience used by tests and the bench: build a whole synthetic workload
+    def load(self, wl, with_bodies=True):
+        self.set_topology(wl.parent)
+        self.upload_trs(wl.pos, wl.euler, wl.scale)
+        if with_bodies:
+            self.upload_bodies(wl.body_type)
+        return self
+
+
+def flatten_topology(parent, has_transform=None):
+    """Host-only: the slot / level / pass the library would give each entity, plus layout info."""
+    parent = _arr(parent, np.uint32)
+    ht = _arr(has_transform, np.uint8)
+    n = len(parent)
+    slot = np.empty(n, np.uint32)
+    level = np.empty(n, np.uint8)
+    pas = np.empty(n, np.uint32)
+    inf = WorldInfo()
+    check(lib().bge_flatten_topology(n, _p(parent), _p(ht), _p(slot), _p(level), _p(pas), C.byref(inf)))
+    return slot, level, pas, inf.as_dict()
+
+
+def partition_subtrees(parent, nranks, has_transform=None):
+    """Host-only: rank of every entity (whole subtrees per rank) and the node count per rank."""
+    parent = _arr(parent, np.uint32)
+    ht = _arr(has_transform, np.uint8)
+    n = len(parent)
+    rank = np.empty(n, np.uint32)
+    load = np.empty(nranks, np.uint64)
+    check(lib().bge_partition_subtrees(n, _p(parent), _p(ht), nranks, _p(rank), _p(load)))
+    return rank, load

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — entity-updates/s of the ECS world tick (transform + physics) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-gather] [--no-cpu]
+
+A "step" is one fixed-step tick of the whole (sharded) world: the fused integrate + transform-hierarchy
+kernel over every tile, and for N > 1 the packing of this rank's root world matrices plus ONE RCCL
+all-gather of them (BASELINE.json configs[4]).  Inputs are synthetic and resident in
+HBM before the timed region.  Rank 0 prints one JSON line.
+
+Workloads (BASELINE.json `configs`):
+    N = 1 : "flat1m"    — configs[1]: 1,000,000 entities, flat, every entity a Dynamic body
+    N > 1 : "subtree64" — configs[4] (variant 5b): 2,000,000 entities PER GPU in 64-node subtrees whose
+            roots are Dynamic bodies; shards are whole subtrees; all-gather of 31,250 roots x 64 B per rank.
+            ("chains4_shard" = variant 5a, 500,000 roots per rank, is selectable with --workload.)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=None, help="flat1m | chains4 | subtree64 | chains4_shard | cube4m | flat10k")
+    ap.add_argument("--entities", type=int, default=None, help="entities per GPU (default: the configuration's size)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-frame all-gather of roots")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(wl, target_seconds):
+    """Time the reference-faithful CPU path (oracle port, 1 thread) on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    n = wl.n
+    roots_only = int(wl.bodies_on_roots_only)
+    # probe one tick to size the sample, then time `ticks` ticks after one warm tick
+    sec, _ = po.bench_tick(wl.shape, wl.pos_box, roots_only, 0, n, wl.seed, 0, 1)
+    ticks = int(max(2, min(120, target_seconds / max(sec, 1e-9))))
+    sec, upd = po.bench_tick(wl.shape, wl.pos_box, roots_only, 0, n, wl.seed, 1, ticks)
+    return {
+        "value": upd * ticks / sec,
+        "unit": "entity-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n} entities x {ticks} ticks of the same workload ({wl.name}); hash-map AoS restatement of "
+                  "PhysicsSystem::Update (free bodies) + TransformSystem::Update, 1 thread; the reference itself "
+                  "does not build here (bx/bgfx/Bullet absent)",
+    }
+
+
+def load_traffic(workload_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get(workload_name, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size and world_size == 1 and args.gpus > 1:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
+              f"(--nproc-per-node {args.gpus}); running 1 rank", file=sys.stderr)
+    n_gpus = world_size
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import banggameengine_amd as B
+    from banggameengine_amd import synth
+    from banggameengine_amd.world import FIXED_DT, GRAVITY
+
+    name = args.workload or ("flat1m" if n_gpus == 1 else "subtree64")
+    base = synth.config(name)
+    per_gpu = args.entities or base.n
+    if base.shape == synth.SUBTREE64:
+        per_gpu -= per_gpu % 64
+    elif base.shape == synth.CHAINS4:
+        per_gpu -= per_gpu % 4
+    wl = synth.config(name, n=per_gpu, first=rank * per_gpu)  # global entity numbering: shard r = [r*per_gpu, (r+1)*per_gpu)
+    flags = B.TICK_ALL | (B.TICK_BROADPHASE if name == "cube4m" else 0)
+
+    stream = torch.cuda.current_stream()
+    world = B.World(device=local_rank, stream=stream.cuda_stream)
+    world.load(wl)
+    world.tick(dt=FIXED_DT, flags=B.TICK_ALL)  # first tick creates the bodies (zero velocity), as in the reference
+    world.set_velocities(wl.vel)            # synthetic initial velocities
+    info = world.info()
+
+    gather = n_gpus > 1 and not args.no_gather
+    n_roots = info["n_roots"]
+    if gather:
+        mine = torch.empty((n_roots, 16), dtype=torch.float32, device="cuda")
+        table = torch.empty((n_gpus * n_roots, 16), dtype=torch.float32, device="cuda")
+
+    def step():
+        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags)
+        if gather:
+            world.pack_roots(mine.data_ptr())
+            dist.all_gather_into_tensor(table, mine)
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    kernel_ms = 0.0
+    t0 = time.perf_counter()
+    if not gather:
+        # the step IS the tick kernel(s): one event pair around the K launches, on the launch stream
+        ev[0].record(stream)
+        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags, ticks=args.steps)
+        ev[1].record(stream)
+    else:
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in pairs:
+            a.record(stream)
+            world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags)
+            b.record(stream)
+            world.pack_roots(mine.data_ptr())
+            dist.all_gather_into_tensor(table, mine)
+    barrier()
+    t1 = time.perf_counter()
+    if not gather:
+        kernel_ms = ev[0].elapsed_time(ev[1]) / args.steps
+    else:
+        kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if world_size > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed_s = float(elapsed.item())
+    total_entities = per_gpu * n_gpus
+    value = total_entities * args.steps / elapsed_s
+
+    if rank == 0:
+        alg_bytes = wl.bytes_per_update * per_gpu  # per launch of the tick kernel on one GPU
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "entity-updates/sec (transform+physics tick)",
+            "value": value,
+            "unit": "entity-updates/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_s / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{name}: {per_gpu} entities/GPU x {n_gpus} GPU, "
+                            + {"flat1m": "flat hierarchy, every entity a Dynamic body (BASELINE configs[1])",
+                               "subtree64": "64-node subtrees (1+3+12+48), roots Dynamic, sharded by subtree "
+                                            "(BASELINE configs[4], variant 5b)",
+                               "chains4_shard": "depth-4 chains, roots Dynamic, sharded by subtree (configs[4], 5a)",
+                               "chains4": "depth-4 chains, roots Dynamic (configs[2])",
+                               "cube4m": "flat + AABB broadphase (configs[3])",
+                               "flat10k": "flat 10k (configs[0])"}[name],
+                "entities_per_gpu": per_gpu,
+                "tiles": info["n_tiles"], "passes": info["n_passes"], "roots_per_gpu": n_roots,
+                "collective": (f"all_gather_into_tensor of {n_roots} x 64 B root world matrices per rank per step "
+                               "(RCCL)") if gather else "none",
+                "dt": FIXED_DT, "gravity": list(GRAVITY),
+                "bytes_per_update_algorithmic": wl.bytes_per_update,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_tick<physics,transforms>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": load_traffic(name),
+                "kernel_ms_per_launch": kernel_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        if n_gpus == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    world.close()
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

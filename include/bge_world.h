@@ -1,0 +1,187 @@
+/*
+ * bge_world.h — C ABI of the MI355X-native ECS world tick (libbge_world.so).
+ *
+ * The reference (Skeletus/BangGameEngine) has no plugin/FFI layer: the per-frame world update is
+ * three C++ call sites inside Application::Update (src/core/Application.cpp:256, :283-285).  This
+ * header is the boundary a maintainer binds instead (INTEGRATION.md shows the C++ adapter that keeps
+ * the reference's call shapes on top of it).  Each entry point cites the reference code it replaces.
+ *
+ * Model
+ *   - A `bge_world` is a device-resident mirror of one reference `Scene` (src/ecs/Scene.h:97-105):
+ *     Transform / RigidBody / Collider components as structure-of-arrays in HBM, plus the parent→child
+ *     hierarchy flattened into 256-slot tiles ordered by depth.
+ *   - Entities are addressed by a dense ENTITY INDEX in [0, n) chosen by the caller (the adapter maps
+ *     the reference's sparse EntityId — src/ecs/Entity.h:4-5 — onto it).
+ *   - Matrices are 16 floats, row-major, row-vector convention, translation in elements 12..14, exactly
+ *     as `Transform::world` (src/ecs/Transform.h:18-19).
+ *   - Not thread-safe: one host thread per world (the reference is single-threaded).
+ *   - Every function returns BGE_OK (0) or a negative error code and never throws; the message of the
+ *     last failure on the calling thread is available from bge_last_error().
+ *   - All work is enqueued on the world's HIP stream (bge_world_desc.stream, or a private stream);
+ *     download functions synchronise that stream before returning.
+ */
+#ifndef BGE_WORLD_H
+#define BGE_WORLD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGE_API __attribute__((visibility("default")))
+
+#define BGE_NO_PARENT 0xffffffffu
+
+enum bge_status {
+    BGE_OK = 0,
+    BGE_ERR_INVALID = -1,     /* bad argument */
+    BGE_ERR_HIP = -2,         /* a HIP runtime call failed */
+    BGE_ERR_OOM = -3,         /* host or device allocation failed */
+    BGE_ERR_STATE = -4,       /* call order (e.g. upload before set_topology) */
+    BGE_ERR_UNSUPPORTED = -5  /* feature not built */
+};
+
+/* RigidBodyType (src/ecs/PhysicsComponents.h:20-25) + "entity has no rigid body" */
+enum bge_body_type { BGE_BODY_STATIC = 0, BGE_BODY_DYNAMIC = 1, BGE_BODY_KINEMATIC = 2, BGE_BODY_NONE = 255 };
+/* ColliderShape (src/ecs/PhysicsComponents.h:7-11) */
+enum bge_shape { BGE_SHAPE_BOX = 0, BGE_SHAPE_CAPSULE = 1 };
+
+/* What one bge_world_tick does. */
+enum bge_tick_flags {
+    BGE_TICK_PHYSICS = 1u,    /* rigid-body slice of PhysicsSystem::Update (src/physics/PhysicsSystem.cpp:1208-1328) */
+    BGE_TICK_TRANSFORMS = 2u, /* TransformSystem::Update (src/ecs/TransformSystem.cpp:40-46) */
+    BGE_TICK_BROADPHASE = 4u, /* AABB update + overlapping pairs (Bullet updateAabbs/calculateOverlappingPairs) */
+    BGE_TICK_ALL = 3u         /* Application::Update's physics + transform steps (src/core/Application.cpp:256,284) */
+};
+
+enum bge_device_array {
+    BGE_ARRAY_WORLD = 0,          /* float[n_slots][16], slot order */
+    BGE_ARRAY_ROOT_WORLDS = 1,    /* float[n_roots][16], filled by bge_world_pack_roots */
+    BGE_ARRAY_SLOT_OF_ENTITY = 2, /* uint32[n_entities], BGE_NO_PARENT where the entity has no Transform */
+    BGE_ARRAY_POSITION = 3,       /* float[n_slots][3] */
+    BGE_ARRAY_PAIRS = 4           /* uint32[pair_capacity][2], entity indices */
+};
+
+typedef struct bge_world bge_world;
+
+typedef struct bge_world_desc {
+    uint32_t struct_size; /* sizeof(bge_world_desc) */
+    int32_t device;       /* HIP device ordinal, or -1 for the current device */
+    void* stream;         /* hipStream_t to enqueue on, or NULL for a private non-blocking stream */
+    uint64_t pair_capacity; /* max overlapping pairs kept per tick (0 = 4 x entities, set at topology time) */
+} bge_world_desc;
+
+typedef struct bge_world_info {
+    uint64_t n_entities;
+    uint64_t n_transforms; /* entities that own a Transform */
+    uint64_t n_slots;      /* n_tiles * 256 */
+    uint64_t n_tiles;      /* tiles that are ticked */
+    uint64_t n_passes;     /* dependent launches per transform pass (1 unless a subtree exceeds a tile) */
+    uint64_t n_roots;
+    uint64_t n_limbo;      /* transforms inside a parent cycle: never updated, stay dirty */
+    uint64_t n_bodies;
+    uint64_t max_depth;
+} bge_world_info;
+
+BGE_API const char* bge_last_error(void);
+BGE_API uint32_t bge_version(void);
+
+/* Scene lifetime: `Application` owning a `Scene` + `PhysicsSystem` (src/core/Application.h:39-42). */
+BGE_API int bge_world_create(const bge_world_desc* desc, bge_world** out);
+BGE_API void bge_world_destroy(bge_world* world);
+
+/*
+ * Hierarchy: replaces Scene::m_parents / m_children and the root scan of
+ * Scene::ForEachRootTransform (src/ecs/Scene.cpp:354-393, 523-533).
+ *   parent[i]         entity index of i's parent, or BGE_NO_PARENT
+ *   has_transform[i]  0/1, NULL = all 1.  An entity whose parent has no Transform is a root
+ *                     (Scene.cpp:528); an entity without a Transform gets no slot.
+ * Entities in a parent cycle are never reached by the reference's DFS; they are kept, never updated,
+ * and stay dirty.  Calling this again re-flattens and keeps all component state of surviving indices.
+ * All Transforms start dirty with TRS = (0, 0, 1) as a default-constructed Transform (Transform.h:14-16).
+ */
+BGE_API int bge_world_set_topology(bge_world* world, uint64_t n, const uint32_t* parent, const uint8_t* has_transform);
+
+/*
+ * Transform components: position / rotationEuler (radians) / scale as packed xyz triples
+ * (src/ecs/Transform.h:14-16).  Any array may be NULL (left unchanged).  Marks the range dirty
+ * (Transform::MarkDirty, src/ecs/Transform.cpp:13-16).
+ */
+BGE_API int bge_world_upload_trs(bge_world* world, uint64_t first, uint64_t count, const float* pos3,
+                                 const float* euler3, const float* scale3);
+BGE_API int bge_world_mark_dirty(bge_world* world, uint64_t first, uint64_t count);
+
+/*
+ * RigidBody + Collider components (src/ecs/PhysicsComponents.h:13-37) for a range of entities.
+ *   type[i]   bge_body_type; BGE_BODY_NONE removes the body.  A body exists only where the entity also has
+ *             a Transform (PhysicsSystem.cpp:389-393).
+ *   mass      RigidBody::mass (Dynamic: max(mass, 0.01), else 0 — PhysicsSystem.cpp:426-429); NULL = 1
+ *   shape     bge_shape, NULL = box;   size3: Collider::size, NULL = (.5,.5,.5)
+ *   layer / mask   NULL = 1 / 0xffffffff; layer 0 is treated as 1 (PhysicsSystem.cpp:407)
+ * Marks RigidBody.dirty and Collider.dirty: on the next physics tick the body is (re)created from its
+ * Transform with zero velocity (PhysicsSystem.cpp:398-477).
+ */
+BGE_API int bge_world_upload_bodies(bge_world* world, uint64_t first, uint64_t count, const uint8_t* type,
+                                    const float* mass, const uint8_t* shape, const float* size3,
+                                    const uint32_t* layer, const uint32_t* mask);
+/*
+ * Extension (no reference API): overwrite linear / angular velocity without touching dirty flags.
+ * The reference's bodies only ever gain velocity from gravity and contacts; synthetic workloads seed it.
+ */
+BGE_API int bge_world_set_velocities(bge_world* world, uint64_t first, uint64_t count, const float* linvel3,
+                                     const float* angvel3);
+
+/*
+ * One fixed-step tick = Application::Update's data-parallel part (src/core/Application.cpp:256, 284):
+ *   BGE_TICK_PHYSICS     re-pose dirty bodies from their Transform (zeroing Dynamic velocities,
+ *                        PhysicsSystem.cpp:952-989), one Bullet sub-step for free bodies
+ *                        (v += g*dt; x += v*dt; exponential-map rotation), write position/rotationEuler back
+ *                        and mark Dynamic transforms dirty (PhysicsSystem.cpp:916-950)
+ *   BGE_TICK_TRANSFORMS  local = mtxSRT(S,R,T); world = parentWorld * local (root: world = local); clear dirty
+ *   BGE_TICK_BROADPHASE  (with PHYSICS) feed AABBs and collect overlapping pairs
+ * dt is seconds (the reference narrows its double once, PhysicsSystem.cpp:863); gravity is 3 floats
+ * (the reference uses (0, config.gravity, 0), PhysicsSystem.cpp:130).
+ */
+BGE_API int bge_world_tick(bge_world* world, float dt, const float gravity[3], uint32_t flags);
+/* Enqueue `ticks` identical ticks back to back (the catch-up loop of Application::Run, Application.cpp:96-101). */
+BGE_API int bge_world_tick_many(bge_world* world, uint32_t ticks, float dt, const float gravity[3], uint32_t flags);
+BGE_API int bge_world_sync(bge_world* world);
+
+/* Results.  `Transform::world` after TransformSystem::Update; position/rotationEuler after PhysicsSystem::Update. */
+BGE_API int bge_world_download_world(bge_world* world, uint64_t first, uint64_t count, float* out16);
+BGE_API int bge_world_download_pose(bge_world* world, uint64_t first, uint64_t count, float* pos3, float* euler3);
+BGE_API int bge_world_download_bodies(bge_world* world, uint64_t first, uint64_t count, float* linvel3,
+                                      float* angvel3, float* quat4, float* aabb6);
+BGE_API int bge_world_download_dirty(bge_world* world, uint64_t first, uint64_t count, uint8_t* dirty);
+/* Scene::CountDirtyTransforms (src/ecs/Scene.cpp:435-446): a device-side wave-reduced count. */
+BGE_API int bge_world_dirty_count(bge_world* world, uint64_t* out);
+/* Overlapping pairs of the last BROADPHASE tick as (a, b) entity indices, a < b, unordered list.
+ * *total receives the number found on the device (may exceed cap; at most cap are copied). */
+BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, uint64_t* total);
+
+/* Multi-GPU support: compact the world matrices of all roots (entity order) into one buffer that the
+ * caller all-gathers across ranks (one collective per frame).  dst = NULL packs into the world's own
+ * BGE_ARRAY_ROOT_WORLDS buffer; otherwise dst is a device pointer with room for n_roots*16 floats. */
+BGE_API int bge_world_pack_roots(bge_world* world, void* dst_device);
+BGE_API int bge_world_device_array(bge_world* world, int which, void** device_ptr, uint64_t* elements);
+BGE_API int bge_world_get_info(bge_world* world, bge_world_info* info);
+
+/*
+ * Host-side helpers (no GPU needed).
+ * bge_flatten_topology: the tile/pass layout bge_world_set_topology would build — for inspection and tests.
+ *   slot_of_entity[n], level_of_entity[n] (depth inside its tile), pass_of_entity[n]; any may be NULL.
+ * bge_partition_subtrees: assign every entity to one of `nranks` shards, whole subtrees only, balancing
+ *   node counts greedily (largest subtree first); rank_of_entity[n].  Entities in cycles go to rank 0.
+ */
+BGE_API int bge_flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform,
+                                 uint32_t* slot_of_entity, uint8_t* level_of_entity, uint32_t* pass_of_entity,
+                                 bge_world_info* info);
+BGE_API int bge_partition_subtrees(uint64_t n, const uint32_t* parent, const uint8_t* has_transform,
+                                   uint32_t nranks, uint32_t* rank_of_entity, uint64_t* nodes_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGE_WORLD_H */

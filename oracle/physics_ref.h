@@ -1,0 +1,257 @@
+// oracle/physics_ref.h — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the rigid-body slice of the reference's PhysicsSystem::Update
+// for FREE bodies (no contacts, no constraints, no ground plane, no sleeping — the
+// scope of SURVEY.md §8 a-10..a-13).  Structure follows the reference's per-tick
+// loops over a per-entity runtime hash map so that timing it is a fair "reference
+// CPU path" (it omits Bullet's own broadphase-tree / island / solver bookkeeping, so
+// it is FASTER than the real reference would be — a conservative baseline).
+//
+// Follows:
+//   src/physics/PhysicsSystem.cpp:1222-1246  prune runtimes whose entity/components vanished
+//   src/physics/PhysicsSystem.cpp:1248-1260  EnsureRigidBody for every RigidBody with a Collider
+//   src/physics/PhysicsSystem.cpp:382-499    EnsureRigidBody: (re)create on collider/body dirty,
+//                                            mass = max(mass,0.01) for Dynamic else 0,
+//                                            layer 0 -> 1, new body => zero velocity, pose from Transform
+//   src/physics/PhysicsSystem.cpp:686-707    CreateShape clamps
+//   src/physics/PhysicsSystem.cpp:952-989    SyncKinematicBodiesToPhysics (teleport rule)
+//   src/physics/PhysicsSystem.cpp:848-875    StepSimulation -> stepSimulation(dt, 4, fixedStep)
+//   src/physics/PhysicsSystem.cpp:916-950    SyncRigidBodiesFromPhysics (Dynamic only; marks dirty)
+// and, inside stepSimulation, Bullet's published per-step sequence for an active free body
+// (BulletDynamics/Dynamics/btDiscreteDynamicsWorld.cpp, btRigidBody.cpp,
+//  BulletDynamics/ConstraintSolver/btSequentialImpulseConstraintSolver.cpp):
+//   applyGravity:            totalForce += g * (1/invMass)
+//   predictUnconstraintMotion: damping factor pow(1-0, dt) == 1; predicted pose = integrate(x, v, w, dt)
+//   updateAabbs:             AABB(current pose) ∪ AABB(predicted pose), each grown by 0.02
+//   solver writeback:        v += (totalForce * invMass) * dt          (externalForceImpulse)
+//   integrateTransforms:     x += v * dt; orientation by exponential map
+//   clearForces
+// With dt == fixedStep (src/core/Application.cpp:326, PhysicsSystem.h:77) that is exactly one
+// sub-step per tick; the caller passes that dt.
+//
+// Orientation state.  Bullet keeps a 3x3 basis and converts basis -> quaternion -> basis every
+// step.  Three modes are implemented so the choice the GPU path makes can be quantified:
+//   kOrientIdeal   (default, what the GPU path implements): state is a quaternion; a body whose
+//                  angular velocity is exactly zero keeps its orientation and its Transform euler
+//                  bit for bit after the tick in which it was (re)posed.
+//   kOrientQuat    state is a quaternion, re-normalised and written back every tick.
+//   kOrientBasis   Bullet's own scheme: 3x3 basis state, getRotation/setRotation every tick.
+// tests/test_oracle_physics.py bounds the distance between the modes.
+//
+// PARITY STATUS: "parity unpinned" (Bullet absent and unpinned; spec-derived).
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+
+#include "bullet_math.h"
+#include "ecs_ref.h"
+
+namespace orc {
+
+enum OrientMode : int { kOrientIdeal = 0, kOrientQuat = 1, kOrientBasis = 2 };
+
+struct RefBodyRuntime {
+    bool hasShape = false;
+    bool hasBody = false;
+    RefBodyType type = RefBodyType::Static;
+    uint32_t layer = 1, mask = 0xffffffffu;
+    bt::Vec3 aabbHalfExtents{0.5f, 0.5f, 0.5f};
+    // "btRigidBody"
+    bt::Vec3 origin{0, 0, 0};
+    bt::Quat orn{0, 0, 0, 1};
+    bt::Mat3 basis{{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
+    bt::Vec3 linvel{0, 0, 0};
+    bt::Vec3 angvel{0, 0, 0};
+    float invMass = 0.0f;
+    bool freshPose = true; // orientation was (re)posed and not yet written back
+    float aabbMin[3] = {0, 0, 0};
+    float aabbMax[3] = {0, 0, 0};
+};
+
+class RefPhysicsSystem {
+public:
+    float gravityY = -9.81f; // assets/config/physics.json:2, PhysicsSystem.h:87
+    int orientMode = kOrientIdeal;
+    bool computeAabbs = false;
+
+    std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
+
+    // The rigid-body slice of PhysicsSystem::Update(scene, camera, input, dt).
+    void Update(RefScene& scene, double dt)
+    {
+        // :1222-1246 prune
+        std::vector<EntityId> gone;
+        for (const auto& kv : runtime_) {
+            if (!scene.IsAlive(kv.first) || !scene.GetRigidBody(kv.first) || !scene.GetCollider(kv.first)) {
+                gone.push_back(kv.first);
+            }
+        }
+        for (EntityId id : gone) runtime_.erase(id);
+
+        // :1248-1260 ensure
+        for (auto& kv : scene.GetRigidBodies()) {
+            if (!scene.IsAlive(kv.first)) continue;
+            RefCollider* collider = scene.GetCollider(kv.first);
+            if (!collider) continue;
+            EnsureRigidBody(scene, kv.first, *collider, kv.second);
+        }
+        SyncKinematicBodiesToPhysics(scene);
+        StepSimulation(static_cast<float>(dt));
+        SyncRigidBodiesFromPhysics(scene);
+    }
+
+    // Extension used by the synthetic workloads (the reference has no API to give a body an
+    // initial velocity; bodies only ever gain velocity from gravity/contacts).
+    void SetVelocity(EntityId id, const bt::Vec3& lin, const bt::Vec3& ang)
+    {
+        auto it = runtime_.find(id);
+        if (it != runtime_.end()) {
+            it->second.linvel = lin;
+            it->second.angvel = ang;
+        }
+    }
+
+private:
+    static void PoseFromTransform(RefBodyRuntime& rt, const RefTransform& t)
+    {
+        rt.origin = bt::Vec3{t.position.x, t.position.y, t.position.z};
+        rt.orn = bt::QuatFromTransformEuler(t.rotationEuler.x, t.rotationEuler.y, t.rotationEuler.z);
+        rt.basis = bt::MatFromQuat(rt.orn); // btTransform::setRotation
+        rt.freshPose = true;
+    }
+
+    void EnsureRigidBody(RefScene& scene, EntityId entity, RefCollider& collider, RefRigidBody& body)
+    {
+        RefTransform* transform = scene.GetTransform(entity);
+        if (!transform) return;
+        auto res = runtime_.try_emplace(entity);
+        bool inserted = res.second;
+        RefBodyRuntime& rt = res.first->second;
+
+        if (collider.dirty || !rt.hasShape) {
+            if (collider.shape == RefShape::Capsule) {
+                const float radius = std::max(collider.size.x, 0.01f);
+                const float halfHeight = std::max(collider.size.y, 0.0f);
+                // btCapsuleShape(radius, 2*halfHeight): m_implicitShapeDimensions.y = 0.5*height
+                rt.aabbHalfExtents = bt::CapsuleAabbHalfExtents(radius, 0.5f * (halfHeight * 2.0f));
+            } else {
+                rt.aabbHalfExtents = bt::BoxAabbHalfExtents(std::max(collider.size.x, 0.01f),
+                                                           std::max(collider.size.y, 0.01f),
+                                                           std::max(collider.size.z, 0.01f));
+            }
+            rt.hasShape = true;
+            collider.dirty = false;
+            inserted = true;
+        }
+
+        const uint32_t desiredLayer = body.layer ? body.layer : 1u;
+        if (inserted || !rt.hasBody || body.dirty) {
+            float mass = 0.0f;
+            if (body.type == RefBodyType::Dynamic) mass = std::max(body.mass, 0.01f);
+            rt.invMass = mass != 0.0f ? 1.0f / mass : 0.0f; // btRigidBody::setMassProps
+            PoseFromTransform(rt, *transform);
+            rt.linvel = bt::Vec3{0, 0, 0};
+            rt.angvel = bt::Vec3{0, 0, 0};
+            rt.hasBody = true;
+            body.dirty = false;
+        }
+        rt.type = body.type;
+        rt.layer = desiredLayer;
+        rt.mask = body.mask;
+    }
+
+    void SyncKinematicBodiesToPhysics(RefScene& scene)
+    {
+        for (auto& kv : runtime_) {
+            RefRigidBody* body = scene.GetRigidBody(kv.first);
+            RefTransform* transform = scene.GetTransform(kv.first);
+            RefBodyRuntime& rt = kv.second;
+            if (!body || !transform || !rt.hasBody) continue;
+            if (!transform->dirty && !body->dirty) continue; // both branches of :963-971
+            PoseFromTransform(rt, *transform);
+            if (body->type == RefBodyType::Dynamic) {
+                rt.linvel = bt::Vec3{0, 0, 0};
+                rt.angvel = bt::Vec3{0, 0, 0};
+            }
+            body->dirty = false;
+        }
+    }
+
+    void StepSimulation(float dt)
+    {
+        const bt::Vec3 g{0.0f, gravityY, 0.0f};
+        for (auto& kv : runtime_) {
+            RefBodyRuntime& rt = kv.second;
+            if (!rt.hasBody) continue;
+            const bool dynamic = rt.type == RefBodyType::Dynamic && rt.invMass != 0.0f;
+
+            const bool spinning = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
+            const bool rotate = orientMode != kOrientIdeal || spinning;
+
+            if (computeAabbs) {
+                bt::AabbOfPose(rt.origin, rt.basis, rt.aabbHalfExtents, rt.aabbMin, rt.aabbMax);
+                if (dynamic) {
+                    // predicted (interpolation) transform uses the velocity BEFORE the gravity impulse
+                    const bt::Vec3 p{rt.origin.x + rt.linvel.x * dt, rt.origin.y + rt.linvel.y * dt,
+                                     rt.origin.z + rt.linvel.z * dt};
+                    bt::Mat3 pb = rt.basis;
+                    if (rotate) pb = bt::MatFromQuat(bt::IntegrateOrientation(CurrentOrn(rt), rt.angvel, dt));
+                    float mn[3], mx[3];
+                    bt::AabbOfPose(p, pb, rt.aabbHalfExtents, mn, mx);
+                    for (int a = 0; a < 3; ++a) {
+                        rt.aabbMin[a] = std::min(rt.aabbMin[a], mn[a]);
+                        rt.aabbMax[a] = std::max(rt.aabbMax[a], mx[a]);
+                    }
+                }
+            }
+            if (!dynamic) continue;
+
+            // applyGravity + solver write-back of the external force impulse
+            const float massInv = 1.0f / rt.invMass;
+            const bt::Vec3 force{g.x * massInv, g.y * massInv, g.z * massInv};
+            rt.linvel.x = rt.linvel.x + (force.x * rt.invMass) * dt;
+            rt.linvel.y = rt.linvel.y + (force.y * rt.invMass) * dt;
+            rt.linvel.z = rt.linvel.z + (force.z * rt.invMass) * dt;
+            // integrateTransforms
+            rt.origin.x = rt.origin.x + rt.linvel.x * dt;
+            rt.origin.y = rt.origin.y + rt.linvel.y * dt;
+            rt.origin.z = rt.origin.z + rt.linvel.z * dt;
+            if (rotate) {
+                rt.orn = bt::IntegrateOrientation(CurrentOrn(rt), rt.angvel, dt);
+                rt.basis = bt::MatFromQuat(rt.orn);
+                rt.freshPose = true;
+            }
+        }
+    }
+
+    bt::Quat CurrentOrn(const RefBodyRuntime& rt) const
+    {
+        return orientMode == kOrientBasis ? bt::QuatFromMat(rt.basis) : rt.orn;
+    }
+
+    void SyncRigidBodiesFromPhysics(RefScene& scene)
+    {
+        for (auto& kv : runtime_) {
+            RefRigidBody* body = scene.GetRigidBody(kv.first);
+            RefBodyRuntime& rt = kv.second;
+            if (!body || !rt.hasBody) continue;
+            if (body->type != RefBodyType::Dynamic) continue;
+            RefTransform* transform = scene.GetTransform(kv.first);
+            if (!transform) continue;
+            transform->position = Float3{rt.origin.x, rt.origin.y, rt.origin.z};
+            if (orientMode != kOrientIdeal || rt.freshPose) {
+                const bt::Vec3 e = bt::TransformEulerFromMat(rt.basis);
+                transform->rotationEuler = Float3{e.x, e.y, e.z};
+                rt.freshPose = false;
+            }
+            transform->MarkDirty();
+        }
+    }
+
+    std::unordered_map<EntityId, RefBodyRuntime> runtime_;
+};
+
+} // namespace orc
