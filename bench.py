@@ -106,7 +106,9 @@ def main():
     wl = synth.config(name, n=per_gpu, first=rank * per_gpu)  # global entity numbering: shard r = [r*per_gpu, (r+1)*per_gpu)
     flags = B.TICK_ALL | (B.TICK_BROADPHASE if name == "cube4m" else 0)
 
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-null) torch stream carries the world's kernels, the events and the collective
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     world = B.World(device=local_rank, stream=stream.cuda_stream)
     world.load(wl)
     world.tick(dt=FIXED_DT, flags=B.TICK_ALL)  # first tick creates the bodies (zero velocity), as in the reference
