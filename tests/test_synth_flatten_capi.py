@@ -1,0 +1,139 @@
+"""Host logic that needs no GPU: synthetic inputs, topology flattening, partitioning, and the C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import banggameengine_amd as B
+from banggameengine_amd import _capi, synth
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NONE = 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("shape,box", [(synth.FLAT, synth.SLAB), (synth.CHAINS4, synth.SLAB), (synth.SUBTREE64, synth.CUBE)])
+def test_numpy_generator_matches_c(shape, box):
+    first, n, seed = 12345, 5000, 0xBA5E0002
+    parent, pos, euler, scale, vel = po.synth_fill(shape, box, seed, first, n)
+    p2, e2, s2 = synth.trs(seed, first, n, box)
+    assert np.array_equal(pos.view(np.uint32), p2.view(np.uint32))
+    assert np.array_equal(euler.view(np.uint32), e2.view(np.uint32))
+    assert np.array_equal(scale.view(np.uint32), s2.view(np.uint32))
+    assert np.array_equal(vel.view(np.uint32), synth.velocity(seed, first, n).view(np.uint32))
+    gp = synth.parents(shape, first, n)
+    assert np.array_equal(np.where(gp == NONE, -1, gp.astype(np.int64)), parent.astype(np.int64))
+
+
+def test_value_ranges():
+    pos, euler, scale = synth.trs(1, 0, 100000)
+    assert pos[:, 1].min() >= 1 and pos[:, 1].max() < 50 and abs(pos[:, 0]).max() <= 250
+    assert abs(euler[:, 0]).max() <= 1.5 and abs(euler[:, 1:]).max() <= 3.1
+    assert scale.min() >= 0.5 and scale.max() < 2.0
+
+
+def _check_layout(parent, has_tf=None):
+    n = len(parent)
+    slot, level, pas, info = B.flatten_topology(parent, has_tf)
+    ht = np.ones(n, bool) if has_tf is None else np.asarray(has_tf, bool)
+    assert ((slot != NONE) == ht).all()
+    used = slot[slot != NONE]
+    assert len(np.unique(used)) == len(used)
+    assert info["n_slots"] % 256 == 0 and used.max(initial=0) < max(info["n_slots"], 1)
+    for i in range(n):
+        if not ht[i]:
+            continue
+        p = parent[i]
+        is_root = p == NONE or not ht[p]
+        if pas[i] == NONE:      # limbo: must be unreachable from any root
+            continue
+        if is_root:
+            assert level[i] == 0 and pas[i] == 0
+        else:
+            assert pas[p] != NONE
+            same_tile = slot[p] // 256 == slot[i] // 256
+            if same_tile:
+                assert level[i] == level[p] + 1 and slot[p] < slot[i]
+            else:
+                assert pas[p] < pas[i] and level[i] == 0
+    return slot, level, pas, info
+
+
+def test_flatten_shapes():
+    for shape, n in ((synth.FLAT, 1000), (synth.CHAINS4, 4096), (synth.SUBTREE64, 64 * 37)):
+        _, _, _, info = _check_layout(synth.parents(shape, 0, n))
+        assert info["n_passes"] == 1 and info["n_limbo"] == 0 and info["n_transforms"] == n
+
+
+def test_flatten_random_forest_and_missing_transforms():
+    rng = np.random.default_rng(11)
+    n = 5000
+    parent = np.full(n, NONE, np.uint32)
+    for i in range(1, n):
+        if rng.random() < 0.9:
+            parent[i] = rng.integers(max(0, i - 30), i)
+    has_tf = (rng.random(n) > 0.05).astype(np.uint8)
+    _check_layout(parent, has_tf)
+
+
+def test_flatten_oversize_subtrees_use_passes():
+    # one root with 1000 children, and one chain of 600
+    parent = np.full(1601, NONE, np.uint32)
+    parent[1:1001] = 0
+    parent[1002:] = np.arange(1001, 1600)
+    _, _, pas, info = _check_layout(parent)
+    assert info["n_passes"] == 3 and info["max_depth"] == 599 and pas.max() == 2
+
+
+def test_flatten_cycles_go_to_limbo():
+    parent = np.array([NONE, 0, 3, 2, 1], np.uint32)
+    slot, level, pas, info = _check_layout(parent)
+    assert info["n_limbo"] == 2 and pas[2] == NONE and pas[3] == NONE and slot[2] >= 256
+
+
+def test_flat_layout_is_identity():
+    slot, _, _, _ = B.flatten_topology(np.full(1000, NONE, np.uint32))
+    assert np.array_equal(slot, np.arange(1000))
+
+
+def test_partition_keeps_subtrees_whole_and_balanced():
+    for shape, n in ((synth.SUBTREE64, 64 * 101), (synth.CHAINS4, 4 * 1001), (synth.FLAT, 1003)):
+        parent = synth.parents(shape, 0, n)
+        rank, load = B.partition_subtrees(parent, 8)
+        child = parent != NONE
+        assert (rank[child] == rank[parent[child]]).all()
+        assert load.sum() == n and load.max() - load.min() <= 64
+    # skewed sizes: one 500-node subtree + 500 singletons over 2 ranks
+    parent = np.full(1000, NONE, np.uint32)
+    parent[1:500] = 0
+    rank, load = B.partition_subtrees(parent, 2)
+    assert sorted(load.tolist()) == [500, 500]
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "bge_world.h")).read()
+    declared = set(re.findall(r"BGE_API\s+[\w\s\*]+?\b(bge_\w+)\s*\(", header))
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    lib = ctypes.CDLL(_capi.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert B.lib().bge_version() == 0x00010000
+
+
+def test_product_does_not_touch_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "banggameengine_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "synth.py" and "oracle/synth.h" in text, f
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(B.BgeError) as e:
+        B.World()
+    assert "no CPU path" in str(e.value)
