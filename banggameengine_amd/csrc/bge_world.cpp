@@ -114,7 +114,7 @@ struct bge_world {
     uint64_t n_bodies_hint = 0;
 
     // device arrays
-    DevBuf flags, parent, tile_hdr, slot_of_entity, root_slots;
+    DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
     DevBuf root_worlds, counter, stage, stage2;
     bge::Broadphase broadphase;
@@ -140,7 +140,7 @@ struct bge_world {
     }
     void release_all()
     {
-        for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &root_slots, &pos, &euler, &scale, &world, &vel,
+        for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
                           &stage2}) {
             b->release();
@@ -349,6 +349,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     HIP_TRY(w->parent.ensure(S * 4));
     HIP_TRY(w->tile_hdr.ensure(T * 4));
     HIP_TRY(w->slot_of_entity.ensure(std::max<uint64_t>(n, 1) * 4));
+    HIP_TRY(w->entity_of_slot.ensure(S * 4));
     HIP_TRY(w->root_slots.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 4));
     HIP_TRY(w->pos.ensure(S * 12));
     HIP_TRY(w->euler.ensure(S * 12));
@@ -368,6 +369,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
 
     if (nf.n_slots) {
         HIP_TRY(hipMemcpyAsync(w->parent.p, nf.parent_field.data(), nf.n_slots * 4, hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(hipMemcpyAsync(w->entity_of_slot.p, nf.entity_of_slot.data(), nf.n_slots * 4, hipMemcpyHostToDevice, w->stream));
         HIP_TRY(hipMemcpyAsync(w->tile_hdr.p, nf.tile_hdr.data(), static_cast<size_t>(nf.n_tiles_total) * 4,
                                hipMemcpyHostToDevice, w->stream));
         // structural flags travel through the staging buffer, k_init_slots merges them
@@ -413,12 +415,6 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
         for (Carry& c : carries) c.tmp.release();
         old_flags_tmp.release();
         map_dev.release();
-    }
-
-    uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(4 * n, 1024);
-    {
-        const int rc = w->broadphase.configure(S, cap);
-        if (rc != BGE_OK) return fail(rc, "broadphase allocation failed");
     }
 
     w->flat = std::move(nf);
@@ -548,8 +544,12 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             HIP_TRY(bge::launch_tick(w->stream, w->view, p, n_tiles, flags));
         }
         if (flags & BGE_TICK_BROADPHASE) {
-            const int rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
-                                             w->slot_of_entity.as<uint32_t>());
+            // buffers are sized on first use: a world that never asks for pairs does not pay for them
+            const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(4 * w->flat.n_entities, 1024);
+            int rc = w->broadphase.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
+            if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->broadphase.error());
+            rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
+                                   w->entity_of_slot.as<uint32_t>());
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
         }
         w->maybe_dirty = phys && !xform;
