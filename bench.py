@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--workload", default=None, help="flat1m | chains4 | subtree64 | chains4_shard | cube4m | flat10k")
     ap.add_argument("--entities", type=int, default=None, help="entities per GPU (default: the configuration's size)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-frame all-gather of roots")
+    ap.add_argument("--force-gather", action="store_true", help="run the root all-gather even with one rank (rehearsal)")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the all-gather on the compute stream instead of "
+                                                              "double-buffered on a side stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     return ap.parse_args()
@@ -88,9 +91,12 @@ def main():
     n_gpus = world_size
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    if world_size > 1 or args.force_gather:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world_size,
+                                device_id=torch.device("cuda", local_rank))
 
     import banggameengine_amd as B
     from banggameengine_amd import synth
@@ -115,20 +121,26 @@ def main():
     world.set_velocities(wl.vel)            # synthetic initial velocities
     info = world.info()
 
-    gather = n_gpus > 1 and not args.no_gather
+    gather = (n_gpus > 1 and not args.no_gather) or args.force_gather
     n_roots = info["n_roots"]
     if gather:
-        mine = torch.empty((n_roots, 16), dtype=torch.float32, device="cuda")
-        table = torch.empty((n_gpus * n_roots, 16), dtype=torch.float32, device="cuda")
+        from banggameengine_amd.sharding import RootTable
+        roots = RootTable(n_roots, torch.device("cuda", local_rank), overlap=not args.no_overlap)
+
+    def gather_roots():
+        # frame t's roots: packed on the compute stream, gathered on the side stream under frame t+1's tick
+        world.pack_roots(roots.send_buffer().data_ptr())
+        roots.gather()
 
     def step():
         world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags)
         if gather:
-            world.pack_roots(mine.data_ptr())
-            dist.all_gather_into_tensor(table, mine)
+            gather_roots()
 
     def barrier():
-        if world_size > 1:
+        if gather:
+            roots.finish()
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,8 +161,7 @@ def main():
             a.record(stream)
             world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags)
             b.record(stream)
-            world.pack_roots(mine.data_ptr())
-            dist.all_gather_into_tensor(table, mine)
+            gather_roots()
     barrier()
     t1 = time.perf_counter()
     if not gather:
@@ -159,7 +170,7 @@ def main():
         kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    if world_size > 1:
+    if dist.is_initialized():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
     total_entities = per_gpu * n_gpus
@@ -193,7 +204,8 @@ def main():
                 "entities_per_gpu": per_gpu,
                 "tiles": info["n_tiles"], "passes": info["n_passes"], "roots_per_gpu": n_roots,
                 "collective": (f"all_gather_into_tensor of {n_roots} x 64 B root world matrices per rank per step "
-                               "(RCCL)") if gather else "none",
+                               f"(RCCL), {'side stream, double-buffered' if not args.no_overlap else 'compute stream'}")
+                              if gather else "none",
                 "dt": FIXED_DT, "gravity": list(GRAVITY),
                 "bytes_per_update_algorithmic": wl.bytes_per_update,
             },
@@ -214,7 +226,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     world.close()
-    if world_size > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
