@@ -1,0 +1,168 @@
+// bge_comm.cpp — the sharded tick's only collective: ONE ncclAllGather (RCCL over xGMI) of the root world
+// matrices per frame, on a side stream, double-buffered so that frame t's gather overlaps frame t+1's tick.
+//
+// xGMI on an MI355X node is a full mesh of point-to-point links; the gathered message is small (64 B per root:
+// 2 MiB per rank for 31,250 subtree roots), so the collective is latency-bound and the point of the side
+// stream is to keep that latency off the compute stream.  librccl.so.1 is loaded with dlopen so that the
+// library also loads on hosts without RCCL and shares the copy a host process (e.g. PyTorch) already mapped.
+#include "bge_comm.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "../../include/bge_world.h"
+
+namespace bge {
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl& rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.handle) break;
+        }
+        if (!x.handle) {
+            x.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "unknown");
+            return x;
+        }
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.handle, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.handle, "ncclCommInitRank"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
+        if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.CommDestroy || !x.GetErrorString) {
+            x.why = "librccl is missing an expected symbol";
+            x.handle = nullptr;
+        }
+        return x;
+    }();
+    return r;
+}
+
+} // namespace
+
+int RootComm::fail(int code, const std::string& what)
+{
+    error_ = what;
+    return code;
+}
+
+#define COMM_HIP(expr)                                                                         \
+    do {                                                                                       \
+        const hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return fail(BGE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define COMM_NCCL(expr)                                                                        \
+    do {                                                                                       \
+        const ncclResult_t r_ = (expr);                                                        \
+        if (r_ != ncclSuccess) return fail(BGE_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
+    } while (0)
+
+int RootComm::unique_id(void* out128, std::string& err)
+{
+    Rccl& r = rccl();
+    if (!r.handle) {
+        err = r.why;
+        return BGE_ERR_UNSUPPORTED;
+    }
+    ncclUniqueId id;
+    const ncclResult_t rc = r.GetUniqueId(&id);
+    if (rc != ncclSuccess) {
+        err = std::string("ncclGetUniqueId: ") + r.GetErrorString(rc);
+        return BGE_ERR_HIP;
+    }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out128, &id, sizeof id);
+    return BGE_OK;
+}
+
+int RootComm::init(int nranks, int rank, const void* id128, uint64_t rows_per_rank)
+{
+    Rccl& r = rccl();
+    if (!r.handle) return fail(BGE_ERR_UNSUPPORTED, r.why);
+    destroy();
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    COMM_NCCL(r.CommInitRank(&comm, nranks, id, rank));
+    comm_ = comm;
+    nranks_ = nranks;
+    rank_ = rank;
+    rows_ = rows_per_rank ? rows_per_rank : 1;
+    frame_ = 0;
+    COMM_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        COMM_HIP(hipMalloc(reinterpret_cast<void**>(&send_[b]), rows_ * 64));
+        COMM_HIP(hipMalloc(reinterpret_cast<void**>(&table_[b]), rows_ * 64 * static_cast<size_t>(nranks)));
+        COMM_HIP(hipMemset(send_[b], 0, rows_ * 64));
+        COMM_HIP(hipEventCreateWithFlags(&packed_[b], hipEventDisableTiming));
+        COMM_HIP(hipEventCreateWithFlags(&gathered_[b], hipEventDisableTiming));
+        in_flight_[b] = false;
+    }
+    return BGE_OK;
+}
+
+int RootComm::begin_frame(hipStream_t compute, float** send)
+{
+    const int b = static_cast<int>(frame_ & 1);
+    if (in_flight_[b]) COMM_HIP(hipStreamWaitEvent(compute, gathered_[b], 0));
+    *send = send_[b];
+    return BGE_OK;
+}
+
+int RootComm::gather(hipStream_t compute, void** table_device)
+{
+    const int b = static_cast<int>(frame_ & 1);
+    COMM_HIP(hipEventRecord(packed_[b], compute));
+    COMM_HIP(hipStreamWaitEvent(side_, packed_[b], 0));
+    COMM_NCCL(rccl().AllGather(send_[b], table_[b], rows_ * 16, ncclFloat32, static_cast<ncclComm_t>(comm_), side_));
+    COMM_HIP(hipEventRecord(gathered_[b], side_));
+    in_flight_[b] = true;
+    if (table_device) *table_device = table_[b];
+    ++frame_;
+    return BGE_OK;
+}
+
+int RootComm::wait(hipStream_t compute)
+{
+    for (int b = 0; b < 2; ++b) {
+        if (in_flight_[b]) COMM_HIP(hipStreamWaitEvent(compute, gathered_[b], 0));
+    }
+    return BGE_OK;
+}
+
+void RootComm::destroy()
+{
+    if (side_) (void)hipStreamSynchronize(side_);
+    if (comm_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
+    comm_ = nullptr;
+    for (int b = 0; b < 2; ++b) {
+        if (send_[b]) (void)hipFree(send_[b]);
+        if (table_[b]) (void)hipFree(table_[b]);
+        if (packed_[b]) (void)hipEventDestroy(packed_[b]);
+        if (gathered_[b]) (void)hipEventDestroy(gathered_[b]);
+        send_[b] = table_[b] = nullptr;
+        packed_[b] = gathered_[b] = nullptr;
+        in_flight_[b] = false;
+    }
+    if (side_) (void)hipStreamDestroy(side_);
+    side_ = nullptr;
+    rows_ = 0;
+}
+
+} // namespace bge

@@ -1,0 +1,40 @@
+// bge_comm.hpp — per-frame all-gather of root world matrices over RCCL (see bge_comm.cpp).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+
+namespace bge {
+
+class RootComm {
+public:
+    static int unique_id(void* out128, std::string& err);
+    int init(int nranks, int rank, const void* id128, uint64_t rows_per_rank);
+    bool ready() const { return comm_ != nullptr; }
+    uint64_t rows_per_rank() const { return rows_; }
+    // Returns the send buffer of this frame after making `compute` wait until the gather that last read it is done.
+    int begin_frame(hipStream_t compute, float** send);
+    // Enqueue the all-gather of this frame's send buffer on the side stream (after everything queued on `compute`).
+    int gather(hipStream_t compute, void** table_device);
+    int wait(hipStream_t compute);
+    void destroy();
+    const char* error() const { return error_.c_str(); }
+
+private:
+    int fail(int code, const std::string& what);
+    std::string error_;
+    void* comm_ = nullptr; // ncclComm_t
+    int nranks_ = 0, rank_ = 0;
+    uint64_t rows_ = 0;
+    uint64_t frame_ = 0;
+    hipStream_t side_ = nullptr;
+    float* send_[2] = {nullptr, nullptr};
+    float* table_[2] = {nullptr, nullptr};
+    hipEvent_t packed_[2] = {nullptr, nullptr};   // compute -> side: roots of the frame are packed
+    hipEvent_t gathered_[2] = {nullptr, nullptr}; // side -> compute: the buffer pair may be reused
+    bool in_flight_[2] = {false, false};
+};
+
+} // namespace bge

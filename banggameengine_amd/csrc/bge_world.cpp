@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "bge_broadphase.hpp"
+#include "bge_comm.hpp"
 #include "bge_flatten.hpp"
 #include "bge_kernels.hpp"
 
@@ -118,6 +119,7 @@ struct bge_world {
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
     DevBuf root_worlds, counter, stage, stage2;
     bge::Broadphase broadphase;
+    bge::RootComm comm;
     bge::WorldView view{};
 
     void rebuild_view()
@@ -146,6 +148,7 @@ struct bge_world {
             b->release();
         }
         broadphase.release();
+        comm.destroy();
     }
 };
 
@@ -678,6 +681,62 @@ int bge_world_device_array(bge_world* w, int which, void** device_ptr, uint64_t*
     }
     *device_ptr = p;
     if (elements) *elements = n;
+    return BGE_OK;
+}
+
+int bge_comm_unique_id(void* out128)
+{
+    if (!out128) return fail(BGE_ERR_INVALID, "out128 is NULL");
+    std::string err;
+    const int rc = bge::RootComm::unique_id(out128, err);
+    if (rc != BGE_OK) return fail(rc, "%s", err.c_str());
+    return BGE_OK;
+}
+
+int bge_world_comm_init(bge_world* w, int nranks, int rank, const void* id128, uint64_t rows_per_rank)
+{
+    if (!w || !id128) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return fail(BGE_ERR_INVALID, "rank %d of %d", rank, nranks);
+    DeviceGuard guard(w->device);
+    const int rc = w->comm.init(nranks, rank, id128, rows_per_rank);
+    if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
+    return BGE_OK;
+}
+
+int bge_world_gather_roots(bge_world* w, void** table_device)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    if (!w->comm.ready()) return fail(BGE_ERR_STATE, "bge_world_comm_init has not been called");
+    if (w->flat.root_slots.size() > w->comm.rows_per_rank()) {
+        return fail(BGE_ERR_INVALID, "%zu roots but the communicator was sized for %llu rows per rank", w->flat.root_slots.size(),
+                    (unsigned long long)w->comm.rows_per_rank());
+    }
+    DeviceGuard guard(w->device);
+    float* send = nullptr;
+    int rc = w->comm.begin_frame(w->stream, &send);
+    if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
+    HIP_TRY(bge::launch_pack_roots(w->stream, w->flat.root_slots.size(), w->root_slots.as<uint32_t>(), w->world.as<float>(), send));
+    rc = w->comm.gather(w->stream, table_device);
+    if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
+    return BGE_OK;
+}
+
+int bge_world_comm_wait(bge_world* w)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    const int rc = w->comm.wait(w->stream);
+    if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
+    return BGE_OK;
+}
+
+int bge_world_comm_destroy(bge_world* w)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    (void)hipStreamSynchronize(w->stream);
+    w->comm.destroy();
     return BGE_OK;
 }
 

@@ -147,6 +147,29 @@ class World:
     def pack_roots(self, dst_device_ptr: int | None = None):
         check(lib().bge_world_pack_roots(self._h, C.c_void_p(dst_device_ptr) if dst_device_ptr else None))
 
+    # native RCCL collective (see include/bge_world.h)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(lib().bge_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes, rows_per_rank: int):
+        buf = C.create_string_buffer(unique_id, 128)
+        check(lib().bge_world_comm_init(self._h, nranks, rank, buf, rows_per_rank))
+
+    def gather_roots(self) -> int:
+        """Pack this rank's roots and enqueue the frame's all-gather; returns the device pointer of the table."""
+        ptr = C.c_void_p()
+        check(lib().bge_world_gather_roots(self._h, C.byref(ptr)))
+        return int(ptr.value or 0)
+
+    def comm_wait(self):
+        check(lib().bge_world_comm_wait(self._h))
+
+    def comm_destroy(self):
+        check(lib().bge_world_comm_destroy(self._h))
+
     def device_array(self, which: int):
         ptr, n = C.c_void_p(), C.c_uint64(0)
         check(lib().bge_world_device_array(self._h, which, C.byref(ptr), C.byref(n)))

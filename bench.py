@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--entities", type=int, default=None, help="entities per GPU (default: the configuration's size)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-frame all-gather of roots")
     ap.add_argument("--force-gather", action="store_true", help="run the root all-gather even with one rank (rehearsal)")
+    ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
+                    help="rccl: native ncclAllGather inside libbge_world (side stream, double-buffered); "
+                         "torch: torch.distributed.all_gather_into_tensor")
     ap.add_argument("--no-overlap", action="store_true", help="issue the all-gather on the compute stream instead of "
                                                               "double-buffered on a side stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -123,14 +126,35 @@ def main():
 
     gather = (n_gpus > 1 and not args.no_gather) or args.force_gather
     n_roots = info["n_roots"]
+    collective = "none"
     if gather:
-        from banggameengine_amd.sharding import RootTable
-        roots = RootTable(n_roots, torch.device("cuda", local_rank), overlap=not args.no_overlap)
+        rows = torch.tensor([n_roots], dtype=torch.int64, device="cuda")
+        dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+        rows_per_rank = int(rows.item())
+        native = args.collective == "rccl"
+        if native:
+            try:
+                uid = [B.World.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                world.comm_init(n_gpus, rank, uid[0], rows_per_rank)
+                collective = (f"ncclAllGather (RCCL, native in libbge_world) of {rows_per_rank} x 64 B root world matrices "
+                              "per rank per step, side stream, double-buffered")
+            except Exception as e:  # transport choice only: the torch path moves the same bytes
+                print(f"[bench] native RCCL init failed ({e}); using torch.distributed", file=sys.stderr)
+                native = False
+        if not native:
+            from banggameengine_amd.sharding import RootTable
+            roots = RootTable(n_roots, torch.device("cuda", local_rank), overlap=not args.no_overlap)
+            collective = (f"torch.distributed.all_gather_into_tensor (RCCL) of {roots.rows} x 64 B root world matrices per "
+                          f"rank per step, {'side stream, double-buffered' if roots.overlap else 'compute stream'}")
 
     def gather_roots():
         # frame t's roots: packed on the compute stream, gathered on the side stream under frame t+1's tick
-        world.pack_roots(roots.send_buffer().data_ptr())
-        roots.gather()
+        if native:
+            world.gather_roots()
+        else:
+            world.pack_roots(roots.send_buffer().data_ptr())
+            roots.gather()
 
     def step():
         world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags)
@@ -139,7 +163,7 @@ def main():
 
     def barrier():
         if gather:
-            roots.finish()
+            world.comm_wait() if native else roots.finish()
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
@@ -203,9 +227,7 @@ def main():
                                "flat10k": "flat 10k (configs[0])"}[name],
                 "entities_per_gpu": per_gpu,
                 "tiles": info["n_tiles"], "passes": info["n_passes"], "roots_per_gpu": n_roots,
-                "collective": (f"all_gather_into_tensor of {n_roots} x 64 B root world matrices per rank per step "
-                               f"(RCCL), {'side stream, double-buffered' if not args.no_overlap else 'compute stream'}")
-                              if gather else "none",
+                "collective": collective,
                 "dt": FIXED_DT, "gravity": list(GRAVITY),
                 "bytes_per_update_algorithmic": wl.bytes_per_update,
             },
@@ -225,6 +247,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
+    if gather and native:
+        world.comm_destroy()
     world.close()
     if dist.is_initialized():
         dist.barrier()

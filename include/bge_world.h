@@ -166,6 +166,28 @@ BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, ui
  * BGE_ARRAY_ROOT_WORLDS buffer; otherwise dst is a device pointer with room for n_roots*16 floats. */
 BGE_API int bge_world_pack_roots(bge_world* world, void* dst_device);
 BGE_API int bge_world_device_array(bge_world* world, int which, void** device_ptr, uint64_t* elements);
+
+/*
+ * Native collective (RCCL over xGMI), one process per GPU.  The reference has no distributed layer; this is
+ * the only exchange of the sharded tick (BASELINE.json configs[4]): every rank contributes the world matrices
+ * of its roots and receives everybody's.
+ *   bge_comm_unique_id   rank 0 fills a 128-byte id and distributes it by any means (the bench uses
+ *                        torch.distributed's store); wraps ncclGetUniqueId.
+ *   bge_world_comm_init  joins the communicator (ncclCommInitRank) and allocates two send/receive buffer
+ *                        pairs of `rows_per_rank` x 16 floats (ranks pad to the largest root count) plus a
+ *                        side stream for the collective.
+ *   bge_world_gather_roots   packs this rank's roots on the world's stream and enqueues ONE ncclAllGather on
+ *                        the side stream; buffers alternate per frame, so frame t's gather runs under frame
+ *                        t+1's tick.  *table_device (may be NULL) receives the device pointer of the table being
+ *                        filled: nranks x rows_per_rank x 16 floats, rank-major.
+ *   bge_world_comm_wait  makes the world's stream wait for every outstanding gather.
+ * librccl.so.1 is loaded at run time (dlopen); BGE_ERR_UNSUPPORTED when it cannot be found.
+ */
+BGE_API int bge_comm_unique_id(void* out128);
+BGE_API int bge_world_comm_init(bge_world* world, int nranks, int rank, const void* id128, uint64_t rows_per_rank);
+BGE_API int bge_world_gather_roots(bge_world* world, void** table_device);
+BGE_API int bge_world_comm_wait(bge_world* world);
+BGE_API int bge_world_comm_destroy(bge_world* world);
 BGE_API int bge_world_get_info(bge_world* world, bge_world_info* info);
 
 /*
