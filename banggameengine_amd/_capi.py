@@ -42,6 +42,8 @@ SYMBOLS = {
     "bge_world_tick": (C.c_int, [_vp, _f, _vp, _u32]),
     "bge_world_tick_many": (C.c_int, [_vp, _u32, _f, _vp, _u32]),
     "bge_world_sync": (C.c_int, [_vp]),
+    "bge_world_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "bge_world_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "bge_world_download_world": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_download_pose": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
     "bge_world_download_bodies": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp]),

@@ -122,6 +122,13 @@ struct bge_world {
     bge::RootComm comm;
     bge::WorldView view{};
 
+    // optional event-pair timing of the tick kernels
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events; // start/stop pairs
+    size_t prof_used = 0;                // events recorded since the last read
+    double prof_ms_carry = 0.0;          // time of pairs folded in when the ring wrapped
+    uint64_t prof_ticks_carry = 0;
+
     void rebuild_view()
     {
         view.flags = flags.as<uint32_t>();
@@ -149,6 +156,8 @@ struct bge_world {
         }
         broadphase.release();
         comm.destroy();
+        for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
+        prof_events.clear();
     }
 };
 
@@ -204,7 +213,25 @@ int download_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, 
 
 } // namespace
 
+namespace {
+// sum the recorded event pairs into the carry (synchronises the stream)
+int fold_profile(bge_world* w)
+{
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    for (size_t k = 0; k + 1 < w->prof_used; k += 2) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, w->prof_events[k], w->prof_events[k + 1]));
+        w->prof_ms_carry += ms;
+        w->prof_ticks_carry += 1;
+    }
+    w->prof_used = 0;
+    return BGE_OK;
+}
+} // namespace
+
 extern "C" {
+
+int bge_world_gather_roots(bge_world* w, void** table_device);
 
 const char* bge_last_error(void) { return g_last_error.c_str(); }
 uint32_t bge_version(void) { return 0x00010000u; }
@@ -533,6 +560,15 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
     DeviceGuard guard(w->device);
     const bool phys = (flags & BGE_TICK_PHYSICS) != 0;
     const bool xform = (flags & BGE_TICK_TRANSFORMS) != 0;
+    if (w->profiling) {
+        // room for every tick of this call, so that no mid-run synchronisation is needed
+        const size_t need = w->prof_used + 2 * static_cast<size_t>(ticks);
+        while (w->prof_events.size() < need && w->prof_events.size() < (1u << 20)) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            w->prof_events.push_back(e);
+        }
+    }
     for (uint32_t t = 0; t < ticks; ++t) {
         if (!phys && !w->maybe_dirty) continue; // TransformSystem::Update with nothing dirty: a no-op scan
         bge::TickParams p{};
@@ -541,10 +577,20 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         p.gy = gravity ? gravity[1] : 0.0f;
         p.gz = gravity ? gravity[2] : 0.0f;
         const size_t n_passes = w->flat.pass_tile_begin.size() - 1;
+        if (w->profiling) {
+            if (w->prof_used + 2 > w->prof_events.size()) {
+                if (int rc = fold_profile(w)) return rc;
+            }
+            HIP_TRY(hipEventRecord(w->prof_events[w->prof_used], w->stream));
+        }
         for (size_t pass = 0; pass < n_passes; ++pass) {
             p.tile_begin = w->flat.pass_tile_begin[pass];
             const uint32_t n_tiles = w->flat.pass_tile_begin[pass + 1] - p.tile_begin;
             HIP_TRY(bge::launch_tick(w->stream, w->view, p, n_tiles, flags));
+        }
+        if (w->profiling) {
+            HIP_TRY(hipEventRecord(w->prof_events[w->prof_used + 1], w->stream));
+            w->prof_used += 2;
         }
         if (flags & BGE_TICK_BROADPHASE) {
             // buffers are sized on first use: a world that never asks for pairs does not pay for them
@@ -556,6 +602,9 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
         }
         w->maybe_dirty = phys && !xform;
+        if (flags & BGE_TICK_GATHER_ROOTS) {
+            if (int rc = bge_world_gather_roots(w, nullptr)) return rc;
+        }
     }
     return BGE_OK;
 }
@@ -563,6 +612,36 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
 int bge_world_tick(bge_world* w, float dt, const float gravity[3], uint32_t flags)
 {
     return bge_world_tick_many(w, 1, dt, gravity, flags);
+}
+
+int bge_world_profile_enable(bge_world* w, int enable)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    if (enable && w->prof_events.empty()) {
+        w->prof_events.resize(2048);
+        for (hipEvent_t& e : w->prof_events) {
+            e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+        }
+    }
+    if (int rc = fold_profile(w)) return rc;
+    w->prof_ms_carry = 0.0;
+    w->prof_ticks_carry = 0;
+    w->profiling = enable != 0;
+    return BGE_OK;
+}
+
+int bge_world_profile_read(bge_world* w, double* tick_kernel_ms, uint64_t* ticks)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    if (int rc = fold_profile(w)) return rc;
+    if (tick_kernel_ms) *tick_kernel_ms = w->prof_ms_carry;
+    if (ticks) *ticks = w->prof_ticks_carry;
+    w->prof_ms_carry = 0.0;
+    w->prof_ticks_carry = 0;
+    return BGE_OK;
 }
 
 int bge_world_sync(bge_world* w)

@@ -11,7 +11,7 @@ from ._capi import WorldDesc, WorldInfo, check, lib
 NO_PARENT = 0xFFFFFFFF
 BODY_STATIC, BODY_DYNAMIC, BODY_KINEMATIC, BODY_NONE = 0, 1, 2, 255
 SHAPE_BOX, SHAPE_CAPSULE = 0, 1
-TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL = 1, 2, 4, 3
+TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL, TICK_GATHER_ROOTS = 1, 2, 4, 3, 8
 ARRAY_WORLD, ARRAY_ROOT_WORLDS, ARRAY_SLOT_OF_ENTITY, ARRAY_POSITION, ARRAY_PAIRS = 0, 1, 2, 3, 4
 
 # fixed step and gravity of the reference (assets/config/physics.json:2-3)
@@ -92,6 +92,15 @@ class World:
 
     def sync(self):
         check(lib().bge_world_sync(self._h))
+
+    def profile_enable(self, enable=True):
+        check(lib().bge_world_profile_enable(self._h, int(enable)))
+
+    def profile_read(self):
+        """(summed tick-kernel milliseconds, ticks) since the last read; synchronises the stream."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(lib().bge_world_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     # -- results
     def download_world(self, first=0, count=None):

@@ -171,27 +171,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    kernel_ms = 0.0
+    # Timed region: exactly K steps.  The tick kernels are timed with HIP event pairs recorded by the library on
+    # the launch stream (bge_world_profile_*), so the roofline figure comes from inside the timed region.
+    world.profile_enable(True)
     t0 = time.perf_counter()
     if not gather:
-        # the step IS the tick kernel(s): one event pair around the K launches, on the launch stream
-        ev[0].record(stream)
         world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags, ticks=args.steps)
-        ev[1].record(stream)
+    elif native:
+        # one native call enqueues K frames: tick kernels, root packing, ncclAllGather on the side stream
+        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags | B.TICK_GATHER_ROOTS, ticks=args.steps)
     else:
-        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for a, b in pairs:
-            a.record(stream)
-            world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags)
-            b.record(stream)
-            gather_roots()
+        for _ in range(args.steps):
+            step()
     barrier()
     t1 = time.perf_counter()
-    if not gather:
-        kernel_ms = ev[0].elapsed_time(ev[1]) / args.steps
-    else:
-        kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
+    kernel_total_ms, kernel_ticks = world.profile_read()
+    world.profile_enable(False)
+    assert kernel_ticks == args.steps, (kernel_ticks, args.steps)
+    kernel_ms = kernel_total_ms / kernel_ticks
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     if dist.is_initialized():

@@ -53,7 +53,8 @@ enum bge_tick_flags {
     BGE_TICK_PHYSICS = 1u,    /* rigid-body slice of PhysicsSystem::Update (src/physics/PhysicsSystem.cpp:1208-1328) */
     BGE_TICK_TRANSFORMS = 2u, /* TransformSystem::Update (src/ecs/TransformSystem.cpp:40-46) */
     BGE_TICK_BROADPHASE = 4u, /* AABB update + overlapping pairs (Bullet updateAabbs/calculateOverlappingPairs) */
-    BGE_TICK_ALL = 3u         /* Application::Update's physics + transform steps (src/core/Application.cpp:256,284) */
+    BGE_TICK_ALL = 3u,        /* Application::Update's physics + transform steps (src/core/Application.cpp:256,284) */
+    BGE_TICK_GATHER_ROOTS = 8u /* after the tick: bge_world_gather_roots (needs bge_world_comm_init) */
 };
 
 enum bge_device_array {
@@ -148,6 +149,14 @@ BGE_API int bge_world_tick(bge_world* world, float dt, const float gravity[3], u
 /* Enqueue `ticks` identical ticks back to back (the catch-up loop of Application::Run, Application.cpp:96-101). */
 BGE_API int bge_world_tick_many(bge_world* world, uint32_t ticks, float dt, const float gravity[3], uint32_t flags);
 BGE_API int bge_world_sync(bge_world* world);
+/*
+ * Kernel timing with HIP events on the world's stream (the reference times its step with chrono around
+ * stepSimulation, src/physics/PhysicsSystem.cpp:862-866).  While enabled, every tick records an event pair
+ * around its tick-kernel launches (not around the broadphase or the collective); bge_world_profile_read
+ * synchronises the stream and returns the summed kernel time of the ticks since the last read.
+ */
+BGE_API int bge_world_profile_enable(bge_world* world, int enable);
+BGE_API int bge_world_profile_read(bge_world* world, double* tick_kernel_ms, uint64_t* ticks);
 
 /* Results.  `Transform::world` after TransformSystem::Update; position/rotationEuler after PhysicsSystem::Update. */
 BGE_API int bge_world_download_world(bge_world* world, uint64_t first, uint64_t count, float* out16);
