@@ -123,9 +123,10 @@ struct bge_world {
     bge::WorldView view{};
 
     // optional event-pair timing of the tick kernels
-    bool profiling = false;
+    int profiling = 0;                   // 0 off, 1 one pair per tick_many call, 2 one pair per tick
     std::vector<hipEvent_t> prof_events; // start/stop pairs
     size_t prof_used = 0;                // events recorded since the last read
+    std::vector<uint32_t> prof_ticks_pending; // ticks covered by each recorded pair
     double prof_ms_carry = 0.0;          // time of pairs folded in when the ring wrapped
     uint64_t prof_ticks_carry = 0;
 
@@ -222,9 +223,10 @@ int fold_profile(bge_world* w)
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, w->prof_events[k], w->prof_events[k + 1]));
         w->prof_ms_carry += ms;
-        w->prof_ticks_carry += 1;
+        w->prof_ticks_carry += (k / 2 < w->prof_ticks_pending.size()) ? w->prof_ticks_pending[k / 2] : 1u;
     }
     w->prof_used = 0;
+    w->prof_ticks_pending.clear();
     return BGE_OK;
 }
 } // namespace
@@ -561,8 +563,8 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
     const bool phys = (flags & BGE_TICK_PHYSICS) != 0;
     const bool xform = (flags & BGE_TICK_TRANSFORMS) != 0;
     if (w->profiling) {
-        // room for every tick of this call, so that no mid-run synchronisation is needed
-        const size_t need = w->prof_used + 2 * static_cast<size_t>(ticks);
+        // room for every pair of this call, so that no mid-run synchronisation is needed
+        const size_t need = w->prof_used + 2 * static_cast<size_t>(w->profiling == 2 ? ticks : 1);
         while (w->prof_events.size() < need && w->prof_events.size() < (1u << 20)) {
             hipEvent_t e = nullptr;
             HIP_TRY(hipEventCreate(&e));
@@ -577,7 +579,9 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         p.gy = gravity ? gravity[1] : 0.0f;
         p.gz = gravity ? gravity[2] : 0.0f;
         const size_t n_passes = w->flat.pass_tile_begin.size() - 1;
-        if (w->profiling) {
+        const bool pair_begins = w->profiling == 2 || (w->profiling == 1 && t == 0);
+        const bool pair_ends = w->profiling == 2 || (w->profiling == 1 && t + 1 == ticks);
+        if (pair_begins) {
             if (w->prof_used + 2 > w->prof_events.size()) {
                 if (int rc = fold_profile(w)) return rc;
             }
@@ -588,9 +592,10 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             const uint32_t n_tiles = w->flat.pass_tile_begin[pass + 1] - p.tile_begin;
             HIP_TRY(bge::launch_tick(w->stream, w->view, p, n_tiles, flags));
         }
-        if (w->profiling) {
+        if (pair_ends) {
             HIP_TRY(hipEventRecord(w->prof_events[w->prof_used + 1], w->stream));
             w->prof_used += 2;
+            w->prof_ticks_pending.push_back(w->profiling == 2 ? 1u : ticks);
         }
         if (flags & BGE_TICK_BROADPHASE) {
             // buffers are sized on first use: a world that never asks for pairs does not pay for them
@@ -628,7 +633,7 @@ int bge_world_profile_enable(bge_world* w, int enable)
     if (int rc = fold_profile(w)) return rc;
     w->prof_ms_carry = 0.0;
     w->prof_ticks_carry = 0;
-    w->profiling = enable != 0;
+    w->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return BGE_OK;
 }
 

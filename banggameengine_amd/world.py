@@ -93,8 +93,9 @@ class World:
     def sync(self):
         check(lib().bge_world_sync(self._h))
 
-    def profile_enable(self, enable=True):
-        check(lib().bge_world_profile_enable(self._h, int(enable)))
+    def profile_enable(self, mode=1):
+        """0 off, 1 one event pair per tick() call, 2 one pair per tick (see include/bge_world.h)."""
+        check(lib().bge_world_profile_enable(self._h, int(mode)))
 
     def profile_read(self):
         """(summed tick-kernel milliseconds, ticks) since the last read; synchronises the stream."""

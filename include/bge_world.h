@@ -151,9 +151,14 @@ BGE_API int bge_world_tick_many(bge_world* world, uint32_t ticks, float dt, cons
 BGE_API int bge_world_sync(bge_world* world);
 /*
  * Kernel timing with HIP events on the world's stream (the reference times its step with chrono around
- * stepSimulation, src/physics/PhysicsSystem.cpp:862-866).  While enabled, every tick records an event pair
- * around its tick-kernel launches (not around the broadphase or the collective); bge_world_profile_read
- * synchronises the stream and returns the summed kernel time of the ticks since the last read.
+ * stepSimulation, src/physics/PhysicsSystem.cpp:862-866).
+ *   enable = 1  one event pair around each bge_world_tick_many call (all its launches, gaps included) — no
+ *               markers between back-to-back kernels, so it does not perturb what it measures
+ *   enable = 2  one pair around every tick's tick-kernel launches (excludes broadphase / collective work that
+ *               is interleaved on the stream; costs a few microseconds per tick)
+ *   enable = 0  off
+ * bge_world_profile_read synchronises the stream and returns the summed time and the number of ticks covered
+ * since the last read.
  */
 BGE_API int bge_world_profile_enable(bge_world* world, int enable);
 BGE_API int bge_world_profile_read(bge_world* world, double* tick_kernel_ms, uint64_t* ticks);
