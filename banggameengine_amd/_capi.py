@@ -37,6 +37,10 @@ SYMBOLS = {
     "bge_world_set_topology": (C.c_int, [_vp, _u64, _vp, _vp]),
     "bge_world_upload_trs": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp]),
     "bge_world_mark_dirty": (C.c_int, [_vp, _u64, _u64]),
+    "bge_world_upload_trs_indexed": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
+    "bge_world_upload_bodies_indexed": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bge_world_download_world_indexed": (C.c_int, [_vp, _u64, _vp, _vp]),
+    "bge_world_download_pose_indexed": (C.c_int, [_vp, _u64, _vp, _vp, _vp]),
     "bge_world_upload_bodies": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bge_world_set_velocities": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
     "bge_world_tick": (C.c_int, [_vp, _f, _vp, _u32]),

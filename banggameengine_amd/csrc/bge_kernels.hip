@@ -218,13 +218,15 @@ __global__ void __launch_bounds__(kTile) k_tick(WorldView w, TickParams p)
 
 // ------------------------------------------------------------------ component scatter / gather (entity order <-> slots)
 // stage holds `count` rows of `width` 32-bit words for entities [first, first+count).
-__global__ void k_scatter_rows(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+// `index` (nullable) selects entities explicitly: row i belongs to entity index[i] instead of first + i.
+__global__ void k_scatter_rows(const uint32_t* __restrict__ slot_of_entity, const uint32_t* __restrict__ index,
+                               uint64_t first, uint64_t count,
                                uint32_t width, const uint32_t* __restrict__ stage, uint32_t* __restrict__ dst,
                                uint32_t* __restrict__ flags, uint32_t or_bits)
 {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
-    const uint32_t slot = slot_of_entity[first + i];
+    const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
     if (dst) {
         for (uint32_t k = 0; k < width; ++k) dst[static_cast<uint64_t>(slot) * width + k] = stage[i * width + k];
@@ -232,26 +234,28 @@ __global__ void k_scatter_rows(const uint32_t* __restrict__ slot_of_entity, uint
     if (flags && or_bits) flags[slot] |= or_bits;
 }
 
-__global__ void k_gather_rows(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+__global__ void k_gather_rows(const uint32_t* __restrict__ slot_of_entity, const uint32_t* __restrict__ index,
+                              uint64_t first, uint64_t count,
                               uint32_t width, const uint32_t* __restrict__ src, uint32_t* __restrict__ stage)
 {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
-    const uint32_t slot = slot_of_entity[first + i];
+    const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     for (uint32_t k = 0; k < width; ++k) {
         stage[i * width + k] = slot == kNone ? 0u : src[static_cast<uint64_t>(slot) * width + k];
     }
 }
 
 // Body upload: type/shape bits + dirty, inverse mass, AABB half extents, group/mask.
-__global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, uint64_t first, uint64_t count,
+__global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, const uint32_t* __restrict__ index,
+                                 uint64_t first, uint64_t count,
                                  const uint32_t* __restrict__ type_bits, const float* __restrict__ inv_mass,
                                  const float* __restrict__ half_extent3, const uint32_t* __restrict__ group,
                                  const uint32_t* __restrict__ mask, WorldView w)
 {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
-    const uint32_t slot = slot_of_entity[first + i];
+    const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
     uint32_t f = w.flags[slot];
     f &= ~(kTypeMask | kBDirty | kSpin | kCapsule);
@@ -369,29 +373,30 @@ hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams&
 }
 
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
-                               uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits)
+                               uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits,
+                               const uint32_t* index)
 {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scatter_rows, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count, width,
+    hipLaunchKernelGGL(k_scatter_rows, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, index, first, count, width,
                        static_cast<const uint32_t*>(stage), static_cast<uint32_t*>(dst), flags, or_bits);
     return hipGetLastError();
 }
 
 hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
-                              uint32_t width, const void* src, void* stage)
+                              uint32_t width, const void* src, void* stage, const uint32_t* index)
 {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gather_rows, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count, width,
+    hipLaunchKernelGGL(k_gather_rows, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, index, first, count, width,
                        static_cast<const uint32_t*>(src), static_cast<uint32_t*>(stage));
     return hipGetLastError();
 }
 
 hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                  const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
-                                 const uint32_t* group, const uint32_t* mask, const WorldView& w)
+                                 const uint32_t* group, const uint32_t* mask, const WorldView& w, const uint32_t* index)
 {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scatter_bodies, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count,
+    hipLaunchKernelGGL(k_scatter_bodies, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, index, first, count,
                        type_bits, inv_mass, half_extent3, group, mask, w);
     return hipGetLastError();
 }

@@ -40,12 +40,14 @@ struct TickParams {
 hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams& p, uint32_t n_tiles, uint32_t flags);
 
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
-                               uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits);
+                               uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits,
+                               const uint32_t* index = nullptr);
 hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
-                              uint32_t width, const void* src, void* stage);
+                              uint32_t width, const void* src, void* stage, const uint32_t* index = nullptr);
 hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                  const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
-                                 const uint32_t* group, const uint32_t* mask, const WorldView& w);
+                                 const uint32_t* group, const uint32_t* mask, const WorldView& w,
+                                 const uint32_t* index = nullptr);
 hipError_t launch_scatter_velocities(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                      const float* lin, const float* ang, const WorldView& w);
 hipError_t launch_init_slots(hipStream_t stream, uint64_t n_slots, const uint32_t* structural_flags, const WorldView& w);

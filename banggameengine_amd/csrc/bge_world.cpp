@@ -189,24 +189,42 @@ int check_range(const bge_world* w, uint64_t first, uint64_t count)
 }
 
 // upload one host array of `count` rows x `width` words into a per-slot device array
+// device copy of an explicit entity-index list (validated against n_entities), or null for a range call
+int stage_index(bge_world* w, uint64_t count, const uint32_t* index, const uint32_t** dev)
+{
+    *dev = nullptr;
+    if (!index) return BGE_OK;
+    for (uint64_t i = 0; i < count; ++i) {
+        if (index[i] >= w->flat.n_entities) {
+            return fail(BGE_ERR_INVALID, "entity_index[%llu] = %u outside [0, %llu)", (unsigned long long)i, index[i],
+                        (unsigned long long)w->flat.n_entities);
+        }
+    }
+    HIP_TRY(w->stage2.ensure(count * 4));
+    HIP_TRY(hipMemcpyAsync(w->stage2.p, index, count * 4, hipMemcpyHostToDevice, w->stream));
+    *dev = w->stage2.as<uint32_t>();
+    return BGE_OK;
+}
+
 int upload_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, const void* host, void* dst,
-                uint32_t or_bits)
+                uint32_t or_bits, const uint32_t* dev_index = nullptr)
 {
     const size_t bytes = static_cast<size_t>(count) * width * 4;
     HIP_TRY(w->stage.ensure(bytes));
     HIP_TRY(hipMemcpyAsync(w->stage.p, host, bytes, hipMemcpyHostToDevice, w->stream));
     HIP_TRY(bge::launch_scatter_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, width, w->stage.p, dst,
-                                     w->flags.as<uint32_t>(), or_bits));
+                                     w->flags.as<uint32_t>(), or_bits, dev_index));
     // the staging buffer is reused by the next call
     HIP_TRY(hipStreamSynchronize(w->stream));
     return BGE_OK;
 }
 
-int download_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, const void* src, void* host)
+int download_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, const void* src, void* host,
+                  const uint32_t* dev_index = nullptr)
 {
     const size_t bytes = static_cast<size_t>(count) * width * 4;
     HIP_TRY(w->stage.ensure(bytes));
-    HIP_TRY(bge::launch_gather_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, width, src, w->stage.p));
+    HIP_TRY(bge::launch_gather_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, width, src, w->stage.p, dev_index));
     HIP_TRY(hipMemcpyAsync(host, w->stage.p, bytes, hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
     return BGE_OK;
@@ -457,22 +475,42 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     return BGE_OK;
 }
 
+static int upload_trs_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const float* pos3,
+                           const float* euler3, const float* scale3)
+{
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    const uint32_t* di = nullptr;
+    if (int rc = stage_index(w, count, index, &di)) return rc;
+    if (pos3) {
+        if (int rc = upload_rows(w, first, count, 3, pos3, w->pos.p, 0, di)) return rc;
+    }
+    if (euler3) {
+        if (int rc = upload_rows(w, first, count, 3, euler3, w->euler.p, 0, di)) return rc;
+    }
+    if (scale3) {
+        if (int rc = upload_rows(w, first, count, 3, scale3, w->scale.p, 0, di)) return rc;
+    }
+    HIP_TRY(bge::launch_scatter_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, 0, nullptr, nullptr,
+                                     w->flags.as<uint32_t>(), bge::kTDirty, di));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->maybe_dirty = true;
+    return BGE_OK;
+}
+
 int bge_world_upload_trs(bge_world* w, uint64_t first, uint64_t count, const float* pos3, const float* euler3,
                          const float* scale3)
 {
     if (int rc = check_range(w, first, count)) return rc;
-    if (count == 0) return BGE_OK;
-    DeviceGuard guard(w->device);
-    if (pos3) {
-        if (int rc = upload_rows(w, first, count, 3, pos3, w->pos.p, 0)) return rc;
-    }
-    if (euler3) {
-        if (int rc = upload_rows(w, first, count, 3, euler3, w->euler.p, 0)) return rc;
-    }
-    if (scale3) {
-        if (int rc = upload_rows(w, first, count, 3, scale3, w->scale.p, 0)) return rc;
-    }
-    return bge_world_mark_dirty(w, first, count);
+    return upload_trs_impl(w, first, count, nullptr, pos3, euler3, scale3);
+}
+
+int bge_world_upload_trs_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, const float* pos3,
+                                 const float* euler3, const float* scale3)
+{
+    if (int rc = check_range(w, 0, 0)) return rc;
+    if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
+    return upload_trs_impl(w, 0, count, entity_index, pos3, euler3, scale3);
 }
 
 int bge_world_mark_dirty(bge_world* w, uint64_t first, uint64_t count)
@@ -486,13 +524,35 @@ int bge_world_mark_dirty(bge_world* w, uint64_t first, uint64_t count)
     return BGE_OK;
 }
 
+static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const uint8_t* type,
+                              const float* mass, const uint8_t* shape, const float* size3, const uint32_t* layer,
+                              const uint32_t* mask);
+
 int bge_world_upload_bodies(bge_world* w, uint64_t first, uint64_t count, const uint8_t* type, const float* mass,
                             const uint8_t* shape, const float* size3, const uint32_t* layer, const uint32_t* mask)
 {
     if (int rc = check_range(w, first, count)) return rc;
+    return upload_bodies_impl(w, first, count, nullptr, type, mass, shape, size3, layer, mask);
+}
+
+int bge_world_upload_bodies_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, const uint8_t* type,
+                                    const float* mass, const uint8_t* shape, const float* size3, const uint32_t* layer,
+                                    const uint32_t* mask)
+{
+    if (int rc = check_range(w, 0, 0)) return rc;
+    if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
+    return upload_bodies_impl(w, 0, count, entity_index, type, mass, shape, size3, layer, mask);
+}
+
+static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const uint8_t* type,
+                              const float* mass, const uint8_t* shape, const float* size3, const uint32_t* layer,
+                              const uint32_t* mask)
+{
     if (!type) return fail(BGE_ERR_INVALID, "type is NULL");
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
+    const uint32_t* di = nullptr;
+    if (int rc = stage_index(w, count, index, &di)) return rc;
 
     // host: component values -> device parameters (PhysicsSystem.cpp:398-477, 686-707)
     std::vector<uint32_t> words(count * 7);
@@ -527,7 +587,7 @@ int bge_world_upload_bodies(bge_world* w, uint64_t first, uint64_t count, const 
     const uint32_t* d = w->stage.as<uint32_t>();
     HIP_TRY(bge::launch_scatter_bodies(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, d,
                                        reinterpret_cast<const float*>(d + count), reinterpret_cast<const float*>(d + 2 * count),
-                                       d + 5 * count, d + 6 * count, w->view));
+                                       d + 5 * count, d + 6 * count, w->view, di));
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->maybe_dirty = true;
     return BGE_OK;
@@ -664,6 +724,34 @@ int bge_world_download_world(bge_world* w, uint64_t first, uint64_t count, float
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
     return download_rows(w, first, count, 16, w->world.p, out16);
+}
+
+int bge_world_download_world_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, float* out16)
+{
+    if (int rc = check_range(w, 0, 0)) return rc;
+    if (count == 0) return BGE_OK;
+    if (!entity_index || !out16) return fail(BGE_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(w->device);
+    const uint32_t* di = nullptr;
+    if (int rc = stage_index(w, count, entity_index, &di)) return rc;
+    return download_rows(w, 0, count, 16, w->world.p, out16, di);
+}
+
+int bge_world_download_pose_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, float* pos3, float* euler3)
+{
+    if (int rc = check_range(w, 0, 0)) return rc;
+    if (count == 0) return BGE_OK;
+    if (!entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
+    DeviceGuard guard(w->device);
+    const uint32_t* di = nullptr;
+    if (int rc = stage_index(w, count, entity_index, &di)) return rc;
+    if (pos3) {
+        if (int rc = download_rows(w, 0, count, 3, w->pos.p, pos3, di)) return rc;
+    }
+    if (euler3) {
+        if (int rc = download_rows(w, 0, count, 3, w->euler.p, euler3, di)) return rc;
+    }
+    return BGE_OK;
 }
 
 int bge_world_download_pose(bge_world* w, uint64_t first, uint64_t count, float* pos3, float* euler3)

@@ -1,0 +1,334 @@
+// bge/gpu_systems.hpp — the reference's system call shapes on top of the C ABI (include/bge_world.h).
+//
+//   reference call site (src/core/Application.cpp)            replacement
+//   :256  m_physics.Update(m_scene, *m_camera, m_input, dt)   gpuPhysics.Update(m_scene, dt)   [rigid-body slice]
+//   :284  TransformSystem::Update(m_scene)                    bge::GpuTransformSystem<Scene>::Update(m_scene)
+//   :283,285  m_scene.CountDirtyTransforms()                  unchanged (host flags are kept coherent)
+//
+// Header-only and templated on the scene type: it needs only the accessors the reference's Scene already has
+// (GetTransforms, GetTransform, GetParent, HasTransform, GetRigidBodies, GetCollider — src/ecs/Scene.h:28-95)
+// and the field names of Transform / RigidBody / Collider, so it compiles against the reference's own headers
+// as well as against bge/scene.hpp.
+//
+// Coherence model ("coherent mode"): the host structs stay the source of truth at the points the reference's
+// callers read them —  Transform::world and Transform::dirty after TransformSystem::Update,
+// Transform::position / rotationEuler / dirty after PhysicsSystem::Update.  Per call the adapter
+//   1. re-derives the dense entity index <-> EntityId map and the parent array when the set of Transforms or a
+//      parent link changed (the reference has no topology version counter, so this is an O(N) scan — the
+//      reference's own ForEachRootTransform does the same scan every call, src/ecs/Scene.cpp:523-533);
+//   2. uploads the TRS of Transforms whose `dirty` flag is set (sparse, bge_world_upload_trs_indexed);
+//   3. ticks the device world;
+//   4. copies the results back into the host structs.
+// Errors never throw (the reference's hot path has no exceptions): a failed call logs "[GPU] ..." to stderr and
+// returns false, leaving the host structs as they were.
+//
+// Known deviations (documented in DESIGN.md): Transform::local is not refreshed; a Dynamic body whose Transform
+// is edited BETWEEN PhysicsSystem::Update and TransformSystem::Update of the same tick continues from the edited
+// position (the reference's Bullet body would ignore the edit).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/bge_world.h"
+
+namespace bge {
+
+template <class SceneT> class GpuSceneMirror {
+public:
+    using Id = uint32_t;
+
+    explicit GpuSceneMirror(int device = -1, void* stream = nullptr)
+    {
+        bge_world_desc d{};
+        d.struct_size = sizeof d;
+        d.device = device;
+        d.stream = stream;
+        if (bge_world_create(&d, &world_) != BGE_OK) Log("bge_world_create");
+    }
+    ~GpuSceneMirror() { bge_world_destroy(world_); }
+    GpuSceneMirror(const GpuSceneMirror&) = delete;
+    GpuSceneMirror& operator=(const GpuSceneMirror&) = delete;
+
+    bool ok() const { return world_ != nullptr; }
+    bge_world* world() { return world_; }
+    float gravity[3] = {0.0f, -9.81f, 0.0f}; // PhysicsSystem.cpp:130 with assets/config/physics.json:2
+
+    // --- TransformSystem::Update(Scene&)
+    bool UpdateTransforms(SceneT& scene)
+    {
+        if (!ok() || !RefreshTopology(scene) || !UploadDirtyTransforms(scene)) return false;
+        if (bge_world_tick(world_, 0.0f, gravity, BGE_TICK_TRANSFORMS) != BGE_OK) return Log("bge_world_tick");
+        const size_t n = ids_.size();
+        stage_.resize(n * 16);
+        if (n && bge_world_download_world(world_, 0, n, stage_.data()) != BGE_OK) return Log("bge_world_download_world");
+        limbo_.resize(n);
+        if (n && bge_world_download_dirty(world_, 0, n, limbo_.data()) != BGE_OK) return Log("bge_world_download_dirty");
+        for (auto& kv : scene.GetTransforms()) {
+            const uint32_t i = index_of_[kv.first];
+            if (limbo_[i]) continue; // inside a parent cycle: the reference never reaches it, it stays dirty
+            std::memcpy(kv.second.world, &stage_[16 * static_cast<size_t>(i)], 64);
+            kv.second.dirty = false;
+            written_[i] = 0;
+        }
+        return true;
+    }
+
+    // --- rigid-body slice of PhysicsSystem::Update(Scene&, camera, input, dt)
+    bool UpdatePhysics(SceneT& scene, double dt)
+    {
+        if (!ok() || !RefreshTopology(scene) || !UploadBodies(scene) || !UploadDirtyTransforms(scene)) return false;
+        if (bge_world_tick(world_, static_cast<float>(dt), gravity, BGE_TICK_PHYSICS) != BGE_OK) return Log("bge_world_tick");
+        // SyncRigidBodiesFromPhysics: Dynamic bodies only (PhysicsSystem.cpp:926-948)
+        index_list_.clear();
+        for (auto& kv : scene.GetRigidBodies()) {
+            auto it = index_of_.find(kv.first);
+            if (it == index_of_.end() || !body_[it->second].exists) continue;
+            if (static_cast<int>(kv.second.type) == 1) index_list_.push_back(it->second);
+        }
+        const size_t m = index_list_.size();
+        stage_.resize(m * 6);
+        if (m && bge_world_download_pose_indexed(world_, m, index_list_.data(), stage_.data(), stage_.data() + 3 * m) != BGE_OK) {
+            return Log("bge_world_download_pose_indexed");
+        }
+        for (size_t k = 0; k < m; ++k) {
+            const uint32_t i = index_list_[k];
+            auto* t = scene.GetTransform(ids_[i]);
+            if (!t) continue;
+            std::memcpy(static_cast<void*>(&t->position), &stage_[3 * k], 12);
+            std::memcpy(static_cast<void*>(&t->rotationEuler), &stage_[3 * m + 3 * k], 12);
+            t->MarkDirty();
+            std::memcpy(&last_pose_[6 * static_cast<size_t>(i)], &stage_[3 * k], 12);
+            std::memcpy(&last_pose_[6 * static_cast<size_t>(i) + 3], &stage_[3 * m + 3 * k], 12);
+            written_[i] = 1;
+        }
+        return true;
+    }
+
+private:
+    struct BodyState {
+        bool exists = false;
+    };
+
+    bool Log(const char* what) const
+    {
+        std::fprintf(stderr, "[GPU] %s failed: %s\n", what, bge_last_error());
+        return false;
+    }
+
+    // Stable dense indices: an entity keeps its index while it owns a Transform; freed indices are reused.
+    bool RefreshTopology(SceneT& scene)
+    {
+        auto& transforms = scene.GetTransforms();
+        bool changed = transforms.size() != live_;
+        if (!changed) {
+            for (auto& kv : transforms) {
+                auto it = index_of_.find(kv.first);
+                if (it == index_of_.end() || parent_[it->second] != ParentIndex(scene, kv.first)) {
+                    changed = true;
+                    break;
+                }
+            }
+        }
+        if (!changed) return true;
+
+        // drop entities that lost their Transform
+        for (auto it = index_of_.begin(); it != index_of_.end();) {
+            if (!scene.HasTransform(it->first)) {
+                has_tf_[it->second] = 0;
+                ids_[it->second] = 0;
+                body_[it->second] = BodyState{};
+                free_.push_back(it->second);
+                it = index_of_.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        for (auto& kv : transforms) {
+            if (index_of_.count(kv.first)) continue;
+            uint32_t i;
+            if (!free_.empty()) {
+                i = free_.back();
+                free_.pop_back();
+            } else {
+                i = static_cast<uint32_t>(ids_.size());
+                ids_.push_back(0);
+                has_tf_.push_back(0);
+                parent_.push_back(BGE_NO_PARENT);
+                body_.emplace_back();
+                written_.push_back(0);
+                last_pose_.resize(last_pose_.size() + 6, 0.0f);
+            }
+            ids_[i] = kv.first;
+            has_tf_[i] = 1;
+            written_[i] = 0;
+            index_of_[kv.first] = i;
+            fresh_.push_back(i);
+        }
+        for (auto& kv : transforms) parent_[index_of_[kv.first]] = ParentIndex(scene, kv.first);
+        for (size_t i = 0; i < ids_.size(); ++i) {
+            if (!has_tf_[i]) parent_[i] = BGE_NO_PARENT;
+        }
+        live_ = transforms.size();
+        if (bge_world_set_topology(world_, ids_.size(), parent_.data(), has_tf_.data()) != BGE_OK) return Log("bge_world_set_topology");
+        // a reused index must not inherit the previous owner's device state: force a full upload
+        for (uint32_t i : fresh_) {
+            if (auto* t = scene.GetTransform(ids_[i])) t->dirty = true;
+        }
+        fresh_.clear();
+        return true;
+    }
+
+    uint32_t ParentIndex(SceneT& scene, Id id)
+    {
+        const Id p = scene.GetParent(id);
+        if (p == 0 || !scene.HasTransform(p)) return BGE_NO_PARENT; // Scene.cpp:528
+        auto it = index_of_.find(p);
+        return it == index_of_.end() ? 0xfffffffeu /* not indexed yet: forces a refresh */ : it->second;
+    }
+
+    bool UploadDirtyTransforms(SceneT& scene)
+    {
+        index_list_.clear();
+        stage_.clear();
+        for (auto& kv : scene.GetTransforms()) {
+            auto& t = kv.second;
+            if (!t.dirty) continue;
+            const uint32_t i = index_of_[kv.first];
+            if (written_[i] && std::memcmp(&t.position, &last_pose_[6 * static_cast<size_t>(i)], 12) == 0 &&
+                std::memcmp(&t.rotationEuler, &last_pose_[6 * static_cast<size_t>(i) + 3], 12) == 0) {
+                continue; // dirty only because the physics write-back marked it: the device already has these values
+            }
+            index_list_.push_back(i);
+            const float* p = &t.position.x;
+            stage_.insert(stage_.end(), p, p + 9); // position, rotationEuler, scale are contiguous (Transform.h:14-16)
+        }
+        const size_t m = index_list_.size();
+        if (!m) return true;
+        // repack [pos|euler|scale] rows into three arrays
+        repack_.resize(m * 9);
+        for (size_t k = 0; k < m; ++k) {
+            std::memcpy(&repack_[3 * k], &stage_[9 * k], 12);
+            std::memcpy(&repack_[3 * m + 3 * k], &stage_[9 * k + 3], 12);
+            std::memcpy(&repack_[6 * m + 3 * k], &stage_[9 * k + 6], 12);
+        }
+        if (bge_world_upload_trs_indexed(world_, m, index_list_.data(), repack_.data(), repack_.data() + 3 * m,
+                                         repack_.data() + 6 * m) != BGE_OK) {
+            return Log("bge_world_upload_trs_indexed");
+        }
+        for (uint32_t i : index_list_) written_[i] = 0;
+        return true;
+    }
+
+    // EnsureRigidBody / prune loops (PhysicsSystem.cpp:1222-1260, 382-499): a body exists where RigidBody, Collider
+    // and Transform all do; it is (re)created when RigidBody.dirty or Collider.dirty is set.
+    bool UploadBodies(SceneT& scene)
+    {
+        index_list_.clear();
+        b_type_.clear(); b_mass_.clear(); b_shape_.clear(); b_size_.clear(); b_layer_.clear(); b_mask_.clear();
+        seen_.assign(ids_.size(), 0);
+        for (auto& kv : scene.GetRigidBodies()) {
+            auto it = index_of_.find(kv.first);
+            auto* col = scene.GetCollider(kv.first);
+            if (it == index_of_.end() || !col) continue;
+            const uint32_t i = it->second;
+            seen_[i] = 1;
+            auto& rb = kv.second;
+            if (body_[i].exists && !rb.dirty && !col->dirty) continue;
+            index_list_.push_back(i);
+            b_type_.push_back(static_cast<uint8_t>(static_cast<int>(rb.type)));
+            b_mass_.push_back(rb.mass);
+            b_shape_.push_back(static_cast<uint8_t>(static_cast<int>(col->shape)));
+            b_size_.push_back(col->size.x); b_size_.push_back(col->size.y); b_size_.push_back(col->size.z);
+            b_layer_.push_back(rb.layer);
+            b_mask_.push_back(rb.mask);
+            body_[i].exists = true;
+            rb.dirty = false;   // PhysicsSystem.cpp:476
+            col->dirty = false; // PhysicsSystem.cpp:403
+        }
+        for (uint32_t i = 0; i < ids_.size(); ++i) {
+            if (body_[i].exists && !seen_[i]) { // component removed: RemoveRigidBody (PhysicsSystem.cpp:1230-1233)
+                index_list_.push_back(i);
+                b_type_.push_back(BGE_BODY_NONE);
+                b_mass_.push_back(0.0f);
+                b_shape_.push_back(0);
+                b_size_.insert(b_size_.end(), {0.5f, 0.5f, 0.5f});
+                b_layer_.push_back(1);
+                b_mask_.push_back(0xffffffffu);
+                body_[i].exists = false;
+            }
+        }
+        if (index_list_.empty()) return true;
+        if (bge_world_upload_bodies_indexed(world_, index_list_.size(), index_list_.data(), b_type_.data(), b_mass_.data(),
+                                            b_shape_.data(), b_size_.data(), b_layer_.data(), b_mask_.data()) != BGE_OK) {
+            return Log("bge_world_upload_bodies_indexed");
+        }
+        return true;
+    }
+
+    bge_world* world_ = nullptr;
+    std::vector<Id> ids_;                       // dense index -> EntityId (0 = free)
+    std::unordered_map<Id, uint32_t> index_of_;
+    std::vector<uint32_t> parent_, free_, fresh_, index_list_;
+    std::vector<uint8_t> has_tf_, written_, limbo_, seen_;
+    std::vector<BodyState> body_;
+    std::vector<float> last_pose_;              // position + euler the physics write-back stored (6 floats per index)
+    std::vector<float> stage_, repack_;
+    std::vector<uint8_t> b_type_, b_shape_;
+    std::vector<float> b_mass_, b_size_;
+    std::vector<uint32_t> b_layer_, b_mask_;
+    size_t live_ = 0;
+};
+
+// One mirror per Scene object, found by address (TransformSystem::Update is a static function without state,
+// src/ecs/TransformSystem.h:5-9).  OnSceneReloaded drops it (the reference move-assigns the whole Scene on
+// reload, src/scene/SceneLoader.cpp:742).
+template <class SceneT> class GpuMirrors {
+public:
+    static GpuSceneMirror<SceneT>& Of(SceneT& scene)
+    {
+        auto& slot = Table()[&scene];
+        if (!slot) slot = std::make_unique<GpuSceneMirror<SceneT>>();
+        return *slot;
+    }
+    static void Drop(SceneT& scene) { Table().erase(&scene); }
+
+private:
+    static std::unordered_map<const void*, std::unique_ptr<GpuSceneMirror<SceneT>>>& Table()
+    {
+        static std::unordered_map<const void*, std::unique_ptr<GpuSceneMirror<SceneT>>> t;
+        return t;
+    }
+};
+
+template <class SceneT> class GpuTransformSystem {
+public:
+    static void Update(SceneT& scene) { GpuMirrors<SceneT>::Of(scene).UpdateTransforms(scene); }
+};
+
+template <class SceneT> class GpuPhysicsSystem {
+public:
+    bool Initialize() { return true; }
+    void OnSceneReloaded(SceneT& scene) { GpuMirrors<SceneT>::Drop(scene); }
+    double GetFixedStep() const { return fixedStep_; }
+    void SetGravity(float g) { gravityY_ = g; }
+    // rigid-body slice of PhysicsSystem::Update(Scene&, const Camera&, const InputSystem&, double dt)
+    void Update(SceneT& scene, double dt)
+    {
+        auto& m = GpuMirrors<SceneT>::Of(scene);
+        m.gravity[0] = 0.0f;
+        m.gravity[1] = gravityY_;
+        m.gravity[2] = 0.0f;
+        m.UpdatePhysics(scene, dt);
+    }
+
+private:
+    float gravityY_ = -9.81f;
+    double fixedStep_ = 1.0f / 120.0f; // PhysicsSystem.h:88
+};
+
+} // namespace bge

@@ -113,6 +113,9 @@ BGE_API int bge_world_set_topology(bge_world* world, uint64_t n, const uint32_t*
 BGE_API int bge_world_upload_trs(bge_world* world, uint64_t first, uint64_t count, const float* pos3,
                                  const float* euler3, const float* scale3);
 BGE_API int bge_world_mark_dirty(bge_world* world, uint64_t first, uint64_t count);
+/* Sparse form: row i belongs to entity entity_index[i] (what an adapter uploads after scanning for Transform::dirty). */
+BGE_API int bge_world_upload_trs_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index,
+                                         const float* pos3, const float* euler3, const float* scale3);
 
 /*
  * RigidBody + Collider components (src/ecs/PhysicsComponents.h:13-37) for a range of entities.
@@ -127,6 +130,9 @@ BGE_API int bge_world_mark_dirty(bge_world* world, uint64_t first, uint64_t coun
 BGE_API int bge_world_upload_bodies(bge_world* world, uint64_t first, uint64_t count, const uint8_t* type,
                                     const float* mass, const uint8_t* shape, const float* size3,
                                     const uint32_t* layer, const uint32_t* mask);
+BGE_API int bge_world_upload_bodies_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index,
+                                            const uint8_t* type, const float* mass, const uint8_t* shape,
+                                            const float* size3, const uint32_t* layer, const uint32_t* mask);
 /*
  * Extension (no reference API): overwrite linear / angular velocity without touching dirty flags.
  * The reference's bodies only ever gain velocity from gravity and contacts; synthetic workloads seed it.
@@ -166,6 +172,9 @@ BGE_API int bge_world_profile_read(bge_world* world, double* tick_kernel_ms, uin
 /* Results.  `Transform::world` after TransformSystem::Update; position/rotationEuler after PhysicsSystem::Update. */
 BGE_API int bge_world_download_world(bge_world* world, uint64_t first, uint64_t count, float* out16);
 BGE_API int bge_world_download_pose(bge_world* world, uint64_t first, uint64_t count, float* pos3, float* euler3);
+BGE_API int bge_world_download_world_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, float* out16);
+BGE_API int bge_world_download_pose_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, float* pos3,
+                                            float* euler3);
 BGE_API int bge_world_download_bodies(bge_world* world, uint64_t first, uint64_t count, float* linvel3,
                                       float* angvel3, float* quat4, float* aabb6);
 BGE_API int bge_world_download_dirty(bge_world* world, uint64_t first, uint64_t count, uint8_t* dirty);

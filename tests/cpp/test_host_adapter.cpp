@@ -1,0 +1,181 @@
+// tests/cpp/test_host_adapter.cpp — the C++ adapter (bge/gpu_systems.hpp) against the CPU oracle.
+//
+// The same scripted sequence of scene edits and ticks is applied to
+//   * orc::RefScene + orc::RefPhysicsSystem + RefTransformSystemUpdate   (oracle, CPU)
+//   * bge::Scene    + bge::GpuPhysicsSystem + bge::GpuTransformSystem    (product, GPU through the C ABI)
+// and every Transform (position, rotationEuler, world, dirty) must match bit for bit after every tick.
+// Reads like the reference's frame: physics.Update(scene, dt); TransformSystem::Update(scene)
+// (src/core/Application.cpp:256, 284).  Needs a GPU; run by tests/test_host_adapter.py.
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../banggameengine_amd/host/bge/gpu_systems.hpp"
+#include "../../banggameengine_amd/host/bge/scene.hpp"
+#include "../../oracle/physics_ref.h"
+#include "../../oracle/synth.h"
+
+namespace {
+
+int g_failures = 0;
+#define CHECK(cond, ...)                                   \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);                      \
+            std::printf("\n");                             \
+            if (++g_failures > 20) std::exit(1);           \
+        }                                                  \
+    } while (0)
+
+inline void Put(void* dst, const float* src) { std::memcpy(dst, src, 12); }
+
+struct Pair {
+    orc::RefScene ref;
+    orc::RefPhysicsSystem refPhysics;
+    bge::Scene gpu;
+    bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
+    const double dt = static_cast<double>(0.0083333333f);
+
+    uint32_t Create(const float* p, const float* e, const float* s)
+    {
+        const uint32_t a = ref.CreateEntity();
+        const uint32_t b = gpu.CreateEntity();
+        CHECK(a == b, "entity ids diverged: %u vs %u", a, b);
+        orc::RefTransform* rt = ref.AddTransform(a);
+        bge::Transform* gt = gpu.AddTransform(b);
+        Put(&rt->position, p); Put(&rt->rotationEuler, e); Put(&rt->scale, s);
+        Put(&gt->position, p); Put(&gt->rotationEuler, e); Put(&gt->scale, s);
+        return a;
+    }
+    void Body(uint32_t id, int type, float mass, const float* size, int shape, uint32_t layer, uint32_t mask)
+    {
+        auto* rc = ref.AddCollider(id);
+        auto* gc = gpu.AddCollider(id);
+        rc->shape = static_cast<orc::RefShape>(shape);
+        gc->shape = static_cast<bge::ColliderShape>(shape);
+        Put(&rc->size, size);
+        Put(&gc->size, size);
+        auto* rb = ref.AddRigidBody(id);
+        auto* gb = gpu.AddRigidBody(id);
+        rb->type = static_cast<orc::RefBodyType>(type); gb->type = static_cast<bge::RigidBodyType>(type);
+        rb->mass = gb->mass = mass;
+        rb->layer = gb->layer = layer;
+        rb->mask = gb->mask = mask;
+    }
+    void SetParent(uint32_t c, uint32_t p) { ref.SetParent(c, p); gpu.SetParent(c, p); }
+    void Destroy(uint32_t id) { ref.DestroyEntity(id); gpu.DestroyEntity(id); }
+    void Move(uint32_t id, const float* p, bool markDirty)
+    {
+        if (auto* t = ref.GetTransform(id)) { Put(&t->position, p); if (markDirty) t->MarkDirty(); }
+        if (auto* t = gpu.GetTransform(id)) { Put(&t->position, p); if (markDirty) t->MarkDirty(); }
+    }
+    void Tick()
+    {
+        refPhysics.Update(ref, dt);
+        gpuPhysics.Update(gpu, dt);
+        ComparePose("after physics");
+        orc::RefTransformSystemUpdate(ref);
+        bge::GpuTransformSystem<bge::Scene>::Update(gpu);
+        CompareAll("after transforms");
+    }
+    void ComparePose(const char* when)
+    {
+        for (auto& kv : ref.GetTransforms()) {
+            const bge::Transform* g = gpu.GetTransform(kv.first);
+            CHECK(g != nullptr, "%s: entity %u missing", when, kv.first);
+            if (!g) continue;
+            CHECK(std::memcmp(&kv.second.position, &g->position, 12) == 0, "%s: position of %u: %g %g %g vs %g %g %g", when,
+                  kv.first, kv.second.position.x, kv.second.position.y, kv.second.position.z, g->position.x, g->position.y, g->position.z);
+            CHECK(std::memcmp(&kv.second.rotationEuler, &g->rotationEuler, 12) == 0, "%s: euler of %u", when, kv.first);
+            CHECK(kv.second.dirty == g->dirty, "%s: dirty of %u: %d vs %d", when, kv.first, kv.second.dirty, g->dirty);
+        }
+    }
+    void CompareAll(const char* when)
+    {
+        CHECK(ref.GetTransformCount() == gpu.GetTransformCount(), "%s: transform counts", when);
+        CHECK(ref.CountDirtyTransforms() == gpu.CountDirtyTransforms(), "%s: dirty counts %zu vs %zu", when,
+              ref.CountDirtyTransforms(), gpu.CountDirtyTransforms());
+        ComparePose(when);
+        for (auto& kv : ref.GetTransforms()) {
+            const bge::Transform* g = gpu.GetTransform(kv.first);
+            if (!g) continue;
+            CHECK(std::memcmp(kv.second.world, g->world, 64) == 0, "%s: world of %u (row3 %g %g %g vs %g %g %g)", when, kv.first,
+                  kv.second.world[12], kv.second.world[13], kv.second.world[14], g->world[12], g->world[13], g->world[14]);
+        }
+    }
+};
+
+} // namespace
+
+int main()
+{
+    {
+        bge::GpuSceneMirror<bge::Scene> probe;
+        if (!probe.ok()) {
+            std::printf("no usable GPU: %s\n", bge_last_error());
+            return 77;
+        }
+    }
+    Pair w;
+    std::mt19937 rng(1234);
+    const int n = 4000;
+    std::vector<uint32_t> ids;
+    for (int i = 0; i < n; ++i) {
+        float p[3], e[3], s[3];
+        orc::synth::trs(0x5EED, i, 0, p, e, s);
+        ids.push_back(w.Create(p, e, s));
+    }
+    // forest: 85 % of the entities hang under an earlier one
+    for (int i = 1; i < n; ++i) {
+        if (rng() % 100 < 85) w.SetParent(ids[i], ids[i - 1 - rng() % std::min(i, 40)]);
+    }
+    // bodies: mixed types, a huge static ground, capsules, filtered layers; some on children (local TRS quirk)
+    for (int i = 0; i < n; ++i) {
+        const int r = rng() % 10;
+        if (r < 4) {
+            float size[3] = {0.5f, 0.5f, 0.5f};
+            const int type = (r == 0) ? 0 : (r == 1 ? 2 : 1);
+            w.Body(ids[i], type, 0.5f + (rng() % 8) * 0.25f, size, rng() % 5 == 0, 1u << (rng() % 3), 0xffffffffu);
+        }
+    }
+    for (int k = 0; k < 3; ++k) w.Tick();
+
+    // second Update without changes must be a no-op (Renderer::BeginFrame calls it again, src/render/Renderer.cpp:606)
+    bge::GpuTransformSystem<bge::Scene>::Update(w.gpu);
+    orc::RefTransformSystemUpdate(w.ref);
+    w.CompareAll("idle update");
+
+    // edits between ticks
+    for (int k = 0; k < 60; ++k) {                       // re-link subtrees (never under a descendant: ids only grow)
+        const int c = 1 + rng() % (n - 1);
+        w.SetParent(ids[c], rng() % 4 == 0 ? 0 : ids[rng() % c]);
+    }
+    for (int k = 0; k < 40; ++k) w.Destroy(ids[100 + 37 * k]);   // orphans children, frees ids
+    for (int k = 0; k < 25; ++k) {                        // new entities reuse the freed ids
+        float p[3], e[3], s[3];
+        orc::synth::trs(0xFEED, k, 0, p, e, s);
+        const uint32_t id = w.Create(p, e, s);
+        if (k % 2) {
+            float size[3] = {0.3f, 0.6f, 0.4f};
+            w.Body(id, 1, 2.0f, size, 0, 1, 0xffffffffu);
+        }
+        if (k % 3 == 0) w.SetParent(id, ids[5]);
+    }
+    for (int k = 0; k < 50; ++k) {                        // teleports (dirty) and stale edits (not dirty)
+        float p[3] = {float(k), 10.0f + k, -float(k)};
+        w.Move(ids[2000 + 13 * k], p, k % 2 == 0);
+    }
+    w.ref.RemoveRigidBody(ids[7]); w.gpu.RemoveRigidBody(ids[7]);
+    w.ref.RemoveCollider(ids[9]); w.gpu.RemoveCollider(ids[9]);
+    for (int k = 0; k < 4; ++k) w.Tick();
+
+    // body flagged dirty: re-created from its Transform with zero velocity
+    for (auto& kv : w.ref.GetRigidBodies()) { if (kv.first % 7 == 0) kv.second.dirty = true; }
+    for (auto& kv : w.gpu.GetRigidBodies()) { if (kv.first % 7 == 0) kv.second.dirty = true; }
+    for (int k = 0; k < 3; ++k) w.Tick();
+
+    if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, 10 ticks)\n", w.gpu.GetTransformCount());
+    return g_failures ? 1 : 0;
+}
