@@ -2,6 +2,7 @@
 #include "bge_flatten.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace bge {
@@ -16,6 +17,7 @@ struct Graph {
     std::vector<uint32_t> child_list;
     std::vector<uint32_t> bfs;         // every node reachable from a root, parents before children
     std::vector<uint32_t> subtree;     // node count of the subtree rooted here (reachable nodes only)
+    std::vector<uint32_t> height;      // levels below this node (leaf = 0)
     std::vector<uint32_t> depth;       // global depth, roots = 0 (kNone if unreachable)
     std::vector<uint32_t> roots;       // in entity order
 };
@@ -67,28 +69,54 @@ void build_graph(uint64_t n, const uint32_t* parent, const uint8_t* has_transfor
         }
     }
     g.subtree.assign(n, 0);
+    g.height.assign(n, 0);
     for (size_t k = g.bfs.size(); k-- > 0;) {
         const uint32_t u = g.bfs[k];
         g.subtree[u] += 1;
-        if (g.eff_parent[u] != kNone) g.subtree[g.eff_parent[u]] += g.subtree[u];
+        const uint32_t p = g.eff_parent[u];
+        if (p != kNone) {
+            g.subtree[p] += g.subtree[u];
+            g.height[p] = std::max(g.height[p], g.height[u] + 1);
+        }
     }
 }
 
 struct TileBuilder {
-    // nodes of the tile being filled, with their in-tile level
-    std::vector<uint32_t> nodes;
-    std::vector<uint8_t> levels;
+    // Nodes of the tile being filled with their in-tile level.  A wave-local tile keeps four groups (one per
+    // wave64) and only ever receives whole subtrees of <= 64 nodes; a block tile uses group 0 as a flat list.
+    std::vector<uint32_t> nodes[4];
+    std::vector<uint8_t> levels[4];
+    bool wave_local = false;
     void clear()
     {
-        nodes.clear();
-        levels.clear();
+        for (int g = 0; g < 4; ++g) {
+            nodes[g].clear();
+            levels[g].clear();
+        }
     }
-    uint32_t room() const { return kTile - static_cast<uint32_t>(nodes.size()); }
+    bool empty() const { return nodes[0].empty() && nodes[1].empty() && nodes[2].empty() && nodes[3].empty(); }
+    uint32_t size() const { return static_cast<uint32_t>(nodes[0].size() + nodes[1].size() + nodes[2].size() + nodes[3].size()); }
+    uint32_t room() const { return kTile - size(); } // block tiles
+    int group_with_room(uint32_t need) const
+    {
+        for (int g = 0; g < 4; ++g) {
+            if (kGroup - nodes[g].size() >= need) return g;
+        }
+        return -1;
+    }
 };
 
 } // namespace
 
-void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, Flattened& out)
+FlattenOptions flatten_options_from_env()
+{
+    FlattenOptions o;
+    if (const char* s = std::getenv("BGE_WAVE_LOCAL_HEIGHT")) o.wave_local_max_height = static_cast<uint32_t>(std::atoi(s));
+    return o;
+}
+
+void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, Flattened& out,
+                      const FlattenOptions& opt)
 {
     Graph g;
     build_graph(n, parent, has_transform, g);
@@ -99,42 +127,64 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
     out.pass_of_entity.assign(n, kNone);
     out.pass_tile_begin.assign(1, 0);
 
-    std::vector<uint32_t> tile_nodes_all;  // concatenated slots -> entity (kNone padding)
     std::vector<uint32_t> in_tile_index(n, kNone);
     std::vector<uint32_t> tile_of_node(n, kNone);
 
-    auto emit_tile = [&](TileBuilder& tb, bool limbo) {
-        if (tb.nodes.empty()) return;
-        const uint32_t tile = static_cast<uint32_t>(out.tile_hdr.size());
-        const uint32_t count = static_cast<uint32_t>(tb.nodes.size());
-        // stable counting sort by level
+    // stable counting sort of one node list by level; returns the highest level
+    auto sort_by_level = [](const std::vector<uint32_t>& nodes, const std::vector<uint8_t>& levels,
+                            std::vector<uint32_t>& out_nodes, std::vector<uint8_t>& out_levels) {
         uint32_t max_level = 0;
-        for (uint8_t l : tb.levels) max_level = std::max<uint32_t>(max_level, l);
+        for (uint8_t l : levels) max_level = std::max<uint32_t>(max_level, l);
         std::vector<uint32_t> start(max_level + 2, 0);
-        for (uint8_t l : tb.levels) start[l + 1]++;
+        for (uint8_t l : levels) start[l + 1]++;
         for (uint32_t l = 0; l <= max_level; ++l) start[l + 1] += start[l];
-        std::vector<uint32_t> ordered(count);
-        std::vector<uint8_t> ordered_level(count);
-        for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t dst = start[tb.levels[k]]++;
-            ordered[dst] = tb.nodes[k];
-            ordered_level[dst] = tb.levels[k];
+        out_nodes.resize(nodes.size());
+        out_levels.resize(nodes.size());
+        for (size_t k = 0; k < nodes.size(); ++k) {
+            const uint32_t dst = start[levels[k]]++;
+            out_nodes[dst] = nodes[k];
+            out_levels[dst] = levels[k];
         }
+        return max_level;
+    };
+
+    auto emit_tile = [&](TileBuilder& tb, bool limbo) {
+        if (tb.empty()) return;
+        const uint32_t tile = static_cast<uint32_t>(out.tile_hdr.size());
         const uint64_t base = static_cast<uint64_t>(tile) * kTile;
         out.entity_of_slot.resize(base + kTile, kNone);
         out.parent_field.resize(base + kTile, kNone);
         out.flags.resize(base + kTile, 0);
+
+        // (in-tile position, entity, level) of every node of the tile
+        std::vector<uint32_t> place, ent;
+        std::vector<uint8_t> lvl;
+        uint32_t max_level = 0;
+        std::vector<uint32_t> sn;
+        std::vector<uint8_t> sl;
+        const int n_groups = tb.wave_local ? 4 : 1;
+        for (int grp = 0; grp < n_groups; ++grp) {
+            if (tb.nodes[grp].empty()) continue;
+            max_level = std::max(max_level, sort_by_level(tb.nodes[grp], tb.levels[grp], sn, sl));
+            for (size_t k = 0; k < sn.size(); ++k) {
+                place.push_back(static_cast<uint32_t>(grp * kGroup + k)); // block tiles: grp == 0, a prefix of the tile
+                ent.push_back(sn[k]);
+                lvl.push_back(sl[k]);
+            }
+        }
+        const uint32_t count = static_cast<uint32_t>(ent.size());
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t e = ent[k];
+            in_tile_index[e] = place[k];
+            tile_of_node[e] = tile;
+            out.slot_of_entity[e] = static_cast<uint32_t>(base + place[k]);
+            out.entity_of_slot[base + place[k]] = e;
+        }
         bool any_ext = false;
         for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t e = ordered[k];
-            in_tile_index[e] = k;
-            tile_of_node[e] = tile;
-            out.slot_of_entity[e] = static_cast<uint32_t>(base + k);
-            out.entity_of_slot[base + k] = e;
-        }
-        for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t e = ordered[k];
-            uint32_t f = kValid | (static_cast<uint32_t>(ordered_level[k]) << kLevelShift);
+            const uint32_t e = ent[k];
+            const uint64_t s = base + place[k];
+            uint32_t f = kValid | (static_cast<uint32_t>(lvl[k]) << kLevelShift);
             if (limbo) {
                 f |= kLimbo;
             } else {
@@ -142,18 +192,19 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
                 if (p != kNone) {
                     f |= kHasParent;
                     if (tile_of_node[p] == tile) {
-                        out.parent_field[base + k] = in_tile_index[p];
+                        out.parent_field[s] = in_tile_index[p];
                     } else {
                         f |= kExtParent;
                         any_ext = true;
-                        out.parent_field[base + k] = out.slot_of_entity[p]; // placed in an earlier pass
+                        out.parent_field[s] = out.slot_of_entity[p]; // placed in an earlier pass
                     }
                 }
             }
-            out.flags[base + k] = f;
+            out.flags[s] = f;
         }
         uint32_t hdr = (max_level & kHdrLevelMask) | (count << kHdrCountShift);
         if (any_ext) hdr |= kHdrExt;
+        if (tb.wave_local) hdr |= kHdrWaveLocal;
         out.tile_hdr.push_back(hdr);
         tb.clear();
     };
@@ -163,16 +214,35 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
     std::vector<uint32_t> next_pending;
     std::vector<uint32_t> queue;
     std::vector<uint8_t> queue_level;
-    TileBuilder tb;
+    TileBuilder wl, bk; // the open wave-local tile and the open block tile
+    wl.wave_local = true;
+    bk.wave_local = false;
     uint32_t pass = 0;
     while (!pending.empty()) {
         next_pending.clear();
         for (uint32_t r : pending) {
             const uint32_t size = g.subtree[r];
-            const bool whole = size <= kTile;
-            if (whole && size > tb.room()) emit_tile(tb, false);
-            if (!whole && !tb.nodes.empty()) emit_tile(tb, false);
-            // breadth-first over the subtree; an oversize subtree is cut when the tile is full
+            // destination of the subtree's nodes
+            std::vector<uint32_t>* dst_nodes;
+            std::vector<uint8_t>* dst_levels;
+            uint32_t budget; // nodes that may still be placed (oversize subtrees are cut when it reaches 0)
+            if (size <= kGroup && g.height[r] <= opt.wave_local_max_height) {
+                int grp = wl.group_with_room(size);
+                if (grp < 0) {
+                    emit_tile(wl, false);
+                    grp = 0;
+                }
+                dst_nodes = &wl.nodes[grp];
+                dst_levels = &wl.levels[grp];
+                budget = size;
+            } else {
+                const bool whole = size <= kTile;
+                if (whole ? size > bk.room() : !bk.empty()) emit_tile(bk, false);
+                dst_nodes = &bk.nodes[0];
+                dst_levels = &bk.levels[0];
+                budget = whole ? size : kTile;
+            }
+            // breadth-first over the subtree; an oversize subtree is cut when its tile is full
             queue.clear();
             queue_level.clear();
             queue.push_back(r);
@@ -180,22 +250,24 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
             for (size_t head = 0; head < queue.size(); ++head) {
                 const uint32_t u = queue[head];
                 const uint8_t lvl = queue_level[head];
-                if (tb.room() == 0) {
+                if (budget == 0) {
                     // cut: u (whose parent is already placed) starts a subtree of the next pass
                     next_pending.push_back(u);
                     continue;
                 }
-                tb.nodes.push_back(u);
-                tb.levels.push_back(lvl);
+                --budget;
+                dst_nodes->push_back(u);
+                dst_levels->push_back(lvl);
                 out.pass_of_entity[u] = pass;
-                for (uint32_t c = g.child_begin[u]; c < g.child_begin[u + 1]; ++c) {
-                    queue.push_back(g.child_list[c]);
+                for (uint32_t ch = g.child_begin[u]; ch < g.child_begin[u + 1]; ++ch) {
+                    queue.push_back(g.child_list[ch]);
                     queue_level.push_back(static_cast<uint8_t>(lvl + 1));
                 }
             }
-            if (!whole) emit_tile(tb, false);
+            if (size > kTile) emit_tile(bk, false);
         }
-        emit_tile(tb, false);
+        emit_tile(wl, false);
+        emit_tile(bk, false);
         out.pass_tile_begin.push_back(static_cast<uint32_t>(out.tile_hdr.size()));
         pending.swap(next_pending);
         ++pass;
@@ -203,15 +275,17 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
     out.n_tiles_ticked = static_cast<uint32_t>(out.tile_hdr.size());
 
     // ---- limbo: Transform-bearing entities never reached from a root (parent cycles)
+    TileBuilder lb;
+    lb.wave_local = false;
     for (uint64_t i = 0; i < n; ++i) {
         if (g.has_tf[i] && g.depth[i] == kNone) {
-            if (tb.room() == 0) emit_tile(tb, true);
-            tb.nodes.push_back(static_cast<uint32_t>(i));
-            tb.levels.push_back(0);
+            if (lb.room() == 0) emit_tile(lb, true);
+            lb.nodes[0].push_back(static_cast<uint32_t>(i));
+            lb.levels[0].push_back(0);
             out.n_limbo++;
         }
     }
-    emit_tile(tb, true);
+    emit_tile(lb, true);
     out.n_tiles_total = static_cast<uint32_t>(out.tile_hdr.size());
     out.n_slots = static_cast<uint64_t>(out.n_tiles_total) * kTile;
     out.entity_of_slot.resize(out.n_slots, kNone);

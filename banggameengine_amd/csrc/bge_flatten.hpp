@@ -8,6 +8,10 @@
 //   * every Transform-bearing entity gets a SLOT; slots are grouped in TILES of 256 (one workgroup);
 //   * a tile holds whole subtrees, its nodes sorted by their depth inside the tile ("level"), so the
 //     kernel resolves level d after level d-1 with the parent's world matrix staged in LDS;
+//   * shallow subtrees of at most 64 nodes (FlattenOptions; by default only singletons, i.e. flat scenes) are
+//     packed first-fit into the tile's four 64-slot GROUPS, one group per wave64: such a "wave-local" tile needs
+//     no workgroup barrier at all — each wave resolves and writes out its own subtrees.  Everything else shares
+//     level-major "block" tiles (one barrier per level, every level step runs with full waves);
 //   * a subtree larger than a tile is cut breadth-first; the cut-off children are placed in a later
 //     PASS (a dependent launch) and read their parent's world matrix from global memory;
 //   * entities in a parent cycle are unreachable from any root (the reference never updates them,
@@ -40,6 +44,8 @@ constexpr uint32_t kHdrLevelMask = 0xffu;   // max level in the tile
 constexpr uint32_t kHdrCountShift = 8;      // bits 8..16: valid slots (0..256)
 constexpr uint32_t kHdrCountMask = 0x1ffu;
 constexpr uint32_t kHdrExt = 1u << 17;      // some node has an external parent
+constexpr uint32_t kHdrWaveLocal = 1u << 18; // every in-tile parent sits in its child's 64-slot group: no workgroup barrier
+constexpr uint32_t kGroup = 64;             // slots per wave64
 
 struct Flattened {
     uint64_t n_entities = 0;
@@ -59,8 +65,18 @@ struct Flattened {
     std::vector<uint32_t> pass_of_entity;   // [n_entities] (kNone for no-transform / limbo)
 };
 
+struct FlattenOptions {
+    // Subtrees of <= 64 nodes and at most this many levels below their root are packed into wave-local groups
+    // (no workgroup barrier, but the level loop runs with only that level's lanes of the group active).
+    // Measured on MI355X: with 25 % of the lanes per level (depth-4 chains, 64-node subtrees) the level-major
+    // block layout is faster (kernel is close to VALU-bound), so the default keeps only singletons wave-local.
+    uint32_t wave_local_max_height = 0;
+};
+FlattenOptions flatten_options_from_env(); // BGE_WAVE_LOCAL_HEIGHT overrides the default (experiments)
+
 // parent[i] == kNone or >= n means "no parent".  has_transform may be null (all true).
-void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, Flattened& out);
+void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, Flattened& out,
+                      const FlattenOptions& opt = flatten_options_from_env());
 
 // Greedy whole-subtree partition (largest first).  rank_of_entity[n]; nodes_per_rank[nranks].
 void partition_subtrees(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, uint32_t nranks,

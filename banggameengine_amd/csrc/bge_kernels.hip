@@ -6,7 +6,8 @@
 //           :916-950 write-back + mark dirty)
 //   XFORM  TransformSystem::Update (src/ecs/TransformSystem.cpp:10-46): local = mtxSRT, then
 //          world = parentWorld * local level by level inside the tile, the parents' world matrices
-//          staged in LDS (16 KiB per workgroup), one workgroup barrier per level
+//          staged in LDS (16 KiB per workgroup).  Wave-local tiles (every subtree inside one 64-slot
+//          group) run without any workgroup barrier; block tiles use one barrier per level
 //   AABB   the per-body AABB Bullet feeds its broadphase (current pose U predicted pose, +0.02)
 //
 // Memory plan (all streams indexed by slot, 256 consecutive slots per workgroup):
@@ -51,8 +52,31 @@ __device__ __forceinline__ void lds_get(const float4* lds, uint32_t n, float (&m
     }
 }
 
+__device__ __forceinline__ void load_world(const float* __restrict__ world, uint32_t slot, float (&m)[16])
+{
+    const float4* src = reinterpret_cast<const float4*>(world) + 4ull * slot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 t = src[r];
+        m[4 * r] = t.x;
+        m[4 * r + 1] = t.y;
+        m[4 * r + 2] = t.z;
+        m[4 * r + 3] = t.w;
+    }
+}
+
+// LDS hand-over between lanes of ONE wave: the hardware keeps a wave's DS operations in order; the fences
+// keep the compiler from moving them across this point.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool PHYS, bool XFORM, bool AABB>
-__global__ void __launch_bounds__(kTile) k_tick(WorldView w, TickParams p)
+// 8 waves per SIMD (<= 64 VGPRs): the kernel waits on memory and, in block tiles, on barriers; occupancy hides both
+__global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
 {
     __shared__ float4 lds[kTile * 4];
 
@@ -163,27 +187,61 @@ __global__ void __launch_bounds__(kTile) k_tick(WorldView w, TickParams p)
     if (XFORM) {
         float local[16];
         bx_mtx_srt(local, scl, eul, pos);
+        const uint32_t level = (f & kLevelMask) >> kLevelShift;
+        float4* dst = reinterpret_cast<float4*>(w.world) + 4ull * kTile * tile;
 
-        if (max_level == 0 && (hdr & kHdrExt) == 0) {
-            // flat tile: every node is a root, world = local (Transform.cpp:32-35)
-            if (valid) lds_put(lds, tid, local);
+        if (hdr & kHdrWaveLocal) {
+            // Every parent sits in its child's own 64-slot group (one wave64): the level loop and the write-out
+            // need no workgroup barrier — DS operations of one wave execute in order.
+            float world[16];
+            if (valid && level == 0) {
+                if (f & kExtParent) {
+                    float pw[16];
+                    load_world(w.world, w.parent[slot], pw);
+                    bx_mtx_mul(world, pw, local);
+                    lds_put(lds, tid, world);
+                } else {
+                    lds_put(lds, tid, local); // root: world = local (Transform.cpp:32-35)
+                }
+            }
+            if (max_level != 0) {
+                const uint32_t parent = (f & kHasParent) && !(f & kExtParent) ? w.parent[slot] : 0u;
+                uint32_t wave_max = level;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) wave_max = max(wave_max, static_cast<uint32_t>(__shfl_xor(wave_max, off, 64)));
+                for (uint32_t d = 1; d <= wave_max; ++d) {
+                    wave_lds_sync();
+                    if (valid && level == d) {
+                        float pw[16];
+                        lds_get(lds, parent, pw);
+                        bx_mtx_mul(world, pw, local); // parent * local — the reference's order
+                        lds_put(lds, tid, world);
+                    }
+                }
+            }
+            wave_lds_sync();
+            // write-out of this wave's own 4 KiB: lane l stores float4 number l + 64k of the group's image
+            const unsigned long long valid_mask = __ballot(valid);
+            const uint32_t lane = tid & 63u;
+            const uint32_t wbase = tid & ~63u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t qi = lane + 64u * k;      // float4 index inside the group's image
+                const uint32_t nl = qi >> 2;             // node inside the group
+                const uint32_t n = wbase + nl;
+                const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
+                if ((valid_mask >> nl) & 1ull) dst[n * 4u + r] = lds[wbase * 4u + qi];
+            }
         } else {
-            const uint32_t level = (f & kLevelMask) >> kLevelShift;
+            // block tile (a subtree of 65..256 nodes, or the breadth-first prefix of a larger one): levels are
+            // separated by workgroup barriers, parents staged in LDS
             const uint32_t parent = (f & kHasParent) ? w.parent[slot] : kNone;
             float world[16];
             if (valid && level == 0) {
                 if (f & kExtParent) {
                     // parent resolved by an earlier launch: read its world matrix from memory
                     float pw[16];
-                    const float4* src = reinterpret_cast<const float4*>(w.world) + 4ull * parent;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float4 t = src[r];
-                        pw[4 * r] = t.x;
-                        pw[4 * r + 1] = t.y;
-                        pw[4 * r + 2] = t.z;
-                        pw[4 * r + 3] = t.w;
-                    }
+                    load_world(w.world, parent, pw);
                     bx_mtx_mul(world, pw, local);
                     lds_put(lds, tid, world);
                 } else {
@@ -199,16 +257,15 @@ __global__ void __launch_bounds__(kTile) k_tick(WorldView w, TickParams p)
                     lds_put(lds, tid, world);
                 }
             }
-        }
-        __syncthreads();
-        // coalesced write-out: lane t stores float4 #(t + 256k) of the tile's 16 KiB image
-        float4* dst = reinterpret_cast<float4*>(w.world) + 4ull * kTile * tile;
+            __syncthreads();
+            // coalesced write-out: lane t stores float4 #(t + 256k) of the tile's 16 KiB image
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t qi = tid + kTile * k;
-            const uint32_t n = qi >> 2;
-            const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
-            if (n < count) dst[n * 4u + r] = lds[qi];
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t qi = tid + kTile * k;
+                const uint32_t n = qi >> 2;
+                const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
+                if (n < count) dst[n * 4u + r] = lds[qi];
+            }
         }
         f &= ~kTDirty; // transform->dirty = false
     }
