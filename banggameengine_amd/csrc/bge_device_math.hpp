@@ -47,42 +47,43 @@ __device__ __forceinline__ void st4(float* __restrict__ base, uint32_t slot, con
 }
 
 // ------------------------------------------------------------------ bx
-__device__ __forceinline__ float bx_floor(float a)
-{
-    if (a < 0.0f) {
-        const float na = -a;
-        const float fr = na - static_cast<float>(static_cast<int>(na));
-        const float result = na - fr;
-        return -(0.0f != fr ? result + 1.0f : result);
-    }
-    return a - (a - static_cast<float>(static_cast<int>(a)));
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// bx::floor is built from int casts (a - fract(a) with a +1 fix-up for negatives); for |a| < 2^31 it equals
+// floorf except that it returns +0 for -0.  bx_cos only feeds it `scaled` and uses the result as
+// `real * kPiHalf` and `int(real) & 3`, where the sign of a zero cannot change the outcome (quadrant 0 multiplies
+// by c0 = 1), so the single-instruction v_floor_f32 is used.  tests/test_gpu_parity.py compares against the
+// cast-based restatement in the oracle, including negative, tiny and -0 angles.
 __device__ __forceinline__ float bx_cos(float a)
 {
     const float kPiHalf = 1.5707963267948966f;
     const float kInvPi = 0.31830988618379067f;
     const float scaled = (a * 2.0f) * kInvPi;
-    const float real = bx_floor(scaled);
+    const float real = __builtin_floorf(scaled);
     const float xx = a - real * kPiHalf;
     const int quadrant = static_cast<int>(real) & 3;
-    const bool even = (quadrant & 1) == 0;
 
-    const float c0 = even ? 1.0f : xx;
-    const float c2 = even ? -0.5f : __uint_as_float(0xbe2aaaabu);
-    const float c4 = __uint_as_float(even ? 0x3d2aaaa4u : 0x3c088898u);
-    const float c6 = __uint_as_float(even ? 0xbab60981u : 0xb9501096u);
-    const float c8 = __uint_as_float(even ? 0x37cfab9cu : 0x363938a8u);
-    const float c10 = __uint_as_float(even ? 0xb48b634du : 0xb2d70013u);
-
-    const float xsq = xx * xx;
-    float acc = c10 * xsq + c8;
+    // Both coefficient sets ride one packed Horner chain (v_pk_mul_f32 / v_pk_add_f32: one IEEE rounding per
+    // component and operation, exactly the scalar sequence); .x = quadrants 0/2, .y = quadrants 1/3.
+    const f32x2 c2 = {-0.5f, __uint_as_float(0xbe2aaaabu)};
+    const f32x2 c4 = {__uint_as_float(0x3d2aaaa4u), __uint_as_float(0x3c088898u)};
+    const f32x2 c6 = {__uint_as_float(0xbab60981u), __uint_as_float(0xb9501096u)};
+    const f32x2 c8 = {__uint_as_float(0x37cfab9cu), __uint_as_float(0x363938a8u)};
+    const f32x2 c10 = {__uint_as_float(0xb48b634du), __uint_as_float(0xb2d70013u)};
+    const f32x2 one = {1.0f, 1.0f};
+    const float xsq1 = xx * xx;
+    const f32x2 xsq = {xsq1, xsq1};
+    f32x2 acc = c10 * xsq + c8;
     acc = acc * xsq + c6;
     acc = acc * xsq + c4;
     acc = acc * xsq + c2;
-    acc = acc * xsq + 1.0f;
-    const float result = acc * c0;
-    return (quadrant == 1 || quadrant == 2) ? -result : result;
+    acc = acc * xsq + one;
+    // result = acc * c0 with c0 = 1 (even quadrant: the product is acc itself) or xx (odd)
+    const float odd = acc.y * xx;
+    const float result = (quadrant & 1) ? odd : acc.x;
+    // negate in quadrants 1 and 2
+    const uint32_t sign = (static_cast<uint32_t>(quadrant + 1) & 2u) << 30;
+    return __uint_as_float(__float_as_uint(result) ^ sign);
 }
 
 __device__ __forceinline__ float bx_sin(float a) { return bx_cos(a - 1.5707963267948966f); }

@@ -177,3 +177,32 @@ def test_pairs_full_size_properties():
     want = np.array(sorted(want), np.uint32).reshape(-1, 2)
     sel = np.isin(got[:, 0], inside) & np.isin(got[:, 1], inside)
     assert len(want) > 100 and np.array_equal(got[sel], want)
+
+
+def test_trig_edge_angles_match_oracle_bitwise():
+    """bx::cos/sin through mtxSRT on awkward angles: signed zeros, denormals, exact quadrant boundaries, values just
+    around them, negative and large angles (the device uses v_floor_f32 + a packed Horner chain; the oracle the
+    cast-based bx::floor and scalar arithmetic)."""
+    half_pi = np.float32(1.5707963267948966)
+    specials = [0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38, 1e-20, -1e-20]
+    for k in range(-9, 10):
+        base = np.float32(k) * half_pi
+        specials += [base, np.nextafter(base, np.float32(np.inf)), np.nextafter(base, np.float32(-np.inf))]
+    specials += [3.1415927, -3.1415927, 6.2831855, -6.2831855, 100.0, -100.0, 12345.678, -54321.0, 1.0e6, -1.0e6, 3.0e7]
+    rng = np.random.default_rng(17)
+    rand = np.concatenate([rng.uniform(-50, 50, 20000), rng.normal(0, 1e-3, 2000), rng.uniform(-1e5, 1e5, 2000)])
+    angles = np.concatenate([np.array(specials, np.float32), rand.astype(np.float32)])
+    n = len(angles)
+    euler = np.stack([angles, np.roll(angles, 7), np.roll(angles, 13)], axis=1).astype(np.float32)
+    wl = synth.Workload("angles", synth.FLAT, n, 5)
+    wl.euler = euler
+    wl.body_type[:] = 255
+    ref = build_oracle(wl)
+    ref.TransformSystemUpdate()
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.tick(flags=B.TICK_TRANSFORMS)
+        got = w.download_world()
+    want, _ = ref.bulk_world()
+    assert_bits_equal(got, want, "world")
