@@ -185,14 +185,13 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
             const uint32_t e = ent[k];
             const uint64_t s = base + place[k];
             uint32_t f = kValid | (static_cast<uint32_t>(lvl[k]) << kLevelShift);
-            if (limbo) {
-                f |= kLimbo;
-            } else {
+            if (!limbo) {
                 const uint32_t p = g.eff_parent[e];
                 if (p != kNone) {
                     f |= kHasParent;
                     if (tile_of_node[p] == tile) {
                         out.parent_field[s] = in_tile_index[p];
+                        f |= in_tile_index[p] << kParentShift; // the kernel reads it from the flag word
                     } else {
                         f |= kExtParent;
                         any_ext = true;

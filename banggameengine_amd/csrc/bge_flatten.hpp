@@ -36,8 +36,11 @@ constexpr uint32_t kHasParent = 0x40u;
 constexpr uint32_t kExtParent = 0x80u;   // parent field is a global slot resolved in an earlier pass
 constexpr uint32_t kLevelShift = 8;      // bits 8..15: level inside the tile
 constexpr uint32_t kLevelMask = 0xff00u;
-constexpr uint32_t kCapsule = 0x10000u;  // collider shape (informational)
-constexpr uint32_t kLimbo = 0x20000u;    // in a parent cycle: never ticked
+constexpr uint32_t kParentShift = 16;    // bits 16..23: in-tile index of the parent (when kHasParent && !kExtParent)
+constexpr uint32_t kParentMask = 0xff0000u;
+constexpr uint32_t kMassShift = 24;      // bits 24..31: mass class (index into the world's mass palette);
+constexpr uint32_t kMassMask = 0xff000000u; //            255 = read the per-slot inv_mass array instead
+constexpr uint32_t kMassClassArray = 255;
 
 // per-tile header word
 constexpr uint32_t kHdrLevelMask = 0xffu;   // max level in the tile

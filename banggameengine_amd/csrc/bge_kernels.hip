@@ -11,8 +11,8 @@
 //   AABB   the per-body AABB Bullet feeds its broadphase (current pose U predicted pose, +0.02)
 //
 // Memory plan (all streams indexed by slot, 256 consecutive slots per workgroup):
-//   reads   flags 4 B, pos/euler/scale 12 B each, vel 12 B + inv_mass 4 B (Dynamic bodies only),
-//           parent 4 B (only in tiles that have a hierarchy)
+//   reads   flags 4 B (body type, dirty bits, level, in-tile parent index, mass class), pos/euler/scale 12 B
+//           each, vel 12 B (Dynamic bodies only); parent slot 4 B only for nodes whose parent is in an earlier pass
 //   writes  pos 12 B + vel 12 B (Dynamic only), world 64 B; flags only when a bit changed
 //   The world matrices leave through LDS so that every wave-level store instruction writes 1 KiB of
 //   contiguous memory (16 B per lane), whatever the per-node compute layout was.
@@ -152,10 +152,20 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
             }
 
             if (dynamic) {
-                const float inv_mass = w.inv_mass[slot];
+                // mass class -> (inv_mass, 1/inv_mass) from the world's palette (a few distinct masses per scene,
+                // L1/L2-resident); class 255 falls back to the per-slot array
+                const uint32_t cls = f >> kMassShift;
+                float inv_mass, mass;
+                if (cls != kMassClassArray) {
+                    const float2 mm = w.mass_palette[cls];
+                    inv_mass = mm.x;
+                    mass = mm.y;
+                } else {
+                    inv_mass = w.inv_mass[slot];
+                    mass = 1.0f / inv_mass;
+                }
                 if (inv_mass != 0.0f) {
                     // applyGravity (F = g * (1/invMass)) + solver write-back of the external force impulse
-                    const float mass = 1.0f / inv_mass;
                     v.x = v.x + ((p.gx * mass) * inv_mass) * p.dt;
                     v.y = v.y + ((p.gy * mass) * inv_mass) * p.dt;
                     v.z = v.z + ((p.gz * mass) * inv_mass) * p.dt;
@@ -205,7 +215,7 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
                 }
             }
             if (max_level != 0) {
-                const uint32_t parent = (f & kHasParent) && !(f & kExtParent) ? w.parent[slot] : 0u;
+                const uint32_t parent = (f & kParentMask) >> kParentShift;
                 uint32_t wave_max = level;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) wave_max = max(wave_max, static_cast<uint32_t>(__shfl_xor(wave_max, off, 64)));
@@ -235,13 +245,13 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
         } else {
             // block tile (a subtree of 65..256 nodes, or the breadth-first prefix of a larger one): levels are
             // separated by workgroup barriers, parents staged in LDS
-            const uint32_t parent = (f & kHasParent) ? w.parent[slot] : kNone;
+            const uint32_t parent = (f & kParentMask) >> kParentShift;
             float world[16];
             if (valid && level == 0) {
                 if (f & kExtParent) {
                     // parent resolved by an earlier launch: read its world matrix from memory
                     float pw[16];
-                    load_world(w.world, parent, pw);
+                    load_world(w.world, w.parent[slot], pw);
                     bx_mtx_mul(world, pw, local);
                     lds_put(lds, tid, world);
                 } else {
@@ -315,8 +325,8 @@ __global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, co
     const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
     uint32_t f = w.flags[slot];
-    f &= ~(kTypeMask | kBDirty | kSpin | kCapsule);
-    f |= type_bits[i];
+    f &= ~(kTypeMask | kBDirty | kSpin | kMassMask);
+    f |= type_bits[i]; // body type, kBDirty and the mass class
     w.flags[slot] = f;
     w.inv_mass[slot] = inv_mass[i];
     w.half_extent[3ull * slot + 0] = half_extent3[3 * i + 0];

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 
 #include <cstdint>
 
@@ -23,7 +24,8 @@ struct WorldView {
     float* vel;               // [slots][3]
     float* angvel;            // [slots][3]
     float* quat;              // [slots][4]
-    float* inv_mass;          // [slots]
+    float* inv_mass;          // [slots]     only read for mass class 255 (more than 254 distinct masses)
+    const float2* mass_palette; // [256]     (inv_mass, 1/inv_mass) per mass class
     float* half_extent;       // [slots][3]  AABB half extents of the collider in its own frame
     uint32_t* group;          // [slots]     collision filter group (layer)
     uint32_t* mask;           // [slots]

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "bge_broadphase.hpp"
@@ -117,7 +118,9 @@ struct bge_world {
     // device arrays
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
-    DevBuf root_worlds, counter, stage, stage2;
+    DevBuf root_worlds, counter, stage, stage2, mass_palette;
+    std::vector<float> palette_inv_mass;            // class -> inv_mass (class 0 = 0: Static / Kinematic)
+    std::unordered_map<uint32_t, uint32_t> palette_class; // inv_mass bits -> class
     bge::Broadphase broadphase;
     bge::RootComm comm;
     bge::WorldView view{};
@@ -147,12 +150,13 @@ struct bge_world {
         view.group = group.as<uint32_t>();
         view.mask = mask.as<uint32_t>();
         view.aabb = aabb.as<float>();
+        view.mass_palette = mass_palette.as<float2>();
     }
     void release_all()
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2}) {
+                          &stage2, &mass_palette}) {
             b->release();
         }
         broadphase.release();
@@ -163,6 +167,22 @@ struct bge_world {
 };
 
 namespace {
+
+// Mass class of an inverse mass: scenes use a handful of distinct masses, so the kernel reads (inv_mass, mass)
+// from a 256-entry palette instead of 4 B per body; the 255th distinct value onwards uses the per-slot array.
+uint32_t mass_class(bge_world* w, float inv_mass, bool& palette_changed)
+{
+    uint32_t bits;
+    std::memcpy(&bits, &inv_mass, 4);
+    auto it = w->palette_class.find(bits);
+    if (it != w->palette_class.end()) return it->second;
+    if (w->palette_inv_mass.size() >= bge::kMassClassArray) return bge::kMassClassArray;
+    const uint32_t cls = static_cast<uint32_t>(w->palette_inv_mass.size());
+    w->palette_inv_mass.push_back(inv_mass);
+    w->palette_class[bits] = cls;
+    palette_changed = true;
+    return cls;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -415,6 +435,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     HIP_TRY(w->aabb.ensure(S * 24));
     HIP_TRY(w->root_worlds.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 64));
     HIP_TRY(w->counter.ensure(64));
+    HIP_TRY(w->mass_palette.ensure(256 * sizeof(float2)));
     w->rebuild_view();
 
     if (nf.n_slots) {
@@ -449,7 +470,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
         std::vector<uint32_t> old_flags(n_keep);
         HIP_TRY(hipMemcpy(old_flags.data(), old_flags_tmp.p, n_keep * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> merged(nf.flags);
-        const uint32_t keep_bits = bge::kTypeMask | bge::kTDirty | bge::kBDirty | bge::kSpin | bge::kCapsule;
+        const uint32_t keep_bits = bge::kTypeMask | bge::kTDirty | bge::kBDirty | bge::kSpin | bge::kMassMask;
         for (uint64_t s = 0; s < nf.n_slots; ++s) {
             if (merged[s] & bge::kValid) merged[s] |= bge::kTDirty;
         }
@@ -555,6 +576,11 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
     if (int rc = stage_index(w, count, index, &di)) return rc;
 
     // host: component values -> device parameters (PhysicsSystem.cpp:398-477, 686-707)
+    bool palette_changed = w->palette_inv_mass.empty();
+    if (palette_changed) {
+        w->palette_inv_mass.push_back(0.0f);
+        w->palette_class[0u] = 0;
+    }
     std::vector<uint32_t> words(count * 7);
     uint32_t* type_bits = words.data();
     float* inv_mass = reinterpret_cast<float*>(words.data() + count);
@@ -571,15 +597,24 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
             type_bits[i] = 0;
             inv_mass[i] = 0.0f;
         } else {
-            type_bits[i] = (static_cast<uint32_t>(t) + 1u) | bge::kBDirty | (sh == BGE_SHAPE_CAPSULE ? bge::kCapsule : 0u);
             float m = 0.0f;
             if (t == BGE_BODY_DYNAMIC) m = std::max(mass ? mass[i] : 1.0f, 0.01f);
             inv_mass[i] = m != 0.0f ? 1.0f / m : 0.0f;
+            type_bits[i] = (static_cast<uint32_t>(t) + 1u) | bge::kBDirty | (mass_class(w, inv_mass[i], palette_changed) << bge::kMassShift);
         }
         collider_half_extents(sh, sz, he + 3 * i);
         const uint32_t l = layer ? layer[i] : 1u;
         group[i] = l ? l : 1u;
         msk[i] = mask ? mask[i] : 0xffffffffu;
+    }
+    if (palette_changed) {
+        std::vector<float2> pal(256, float2{0.0f, 0.0f});
+        for (size_t k = 0; k < w->palette_inv_mass.size(); ++k) {
+            const float im = w->palette_inv_mass[k];
+            pal[k] = float2{im, im != 0.0f ? 1.0f / im : 0.0f}; // same IEEE divide the kernel's fallback path performs
+        }
+        HIP_TRY(hipMemcpyAsync(w->mass_palette.p, pal.data(), pal.size() * sizeof(float2), hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
     }
     const size_t bytes = words.size() * 4;
     HIP_TRY(w->stage.ensure(bytes));

@@ -206,3 +206,26 @@ def test_trig_edge_angles_match_oracle_bitwise():
         got = w.download_world()
     want, _ = ref.bulk_world()
     assert_bits_equal(got, want, "world")
+
+
+@pytest.mark.parametrize("distinct", [5, 3000])
+def test_mass_palette_and_per_slot_fallback(distinct):
+    """Masses ride an 8-bit class in the flag word (palette of (inv_mass, mass)); beyond 254 distinct values the
+    kernel falls back to the per-slot array.  Gravity goes through F = g*m, v += (F*inv_m)*dt, so mass matters."""
+    n = 3000
+    wl = synth.config("flat10k", n=n)
+    rng = np.random.default_rng(distinct)
+    mass = rng.choice(rng.uniform(0.001, 50.0, distinct).astype(np.float32), n).astype(np.float32)
+    ref = run_oracle(build_oracle(wl, mass=mass), wl, 6)
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, mass=mass)
+        run_world(w, wl, 6)
+        got_pos, _ = w.download_pose()
+        got_vel = w.download_bodies()["linvel"]
+        got_world = w.download_world()
+    want_pos, _ = ref.bulk_pose()
+    assert_bits_equal(got_vel, ref.bulk_bodies()["linvel"], "linvel")
+    assert_bits_equal(got_pos, want_pos, "position")
+    assert_bits_equal(got_world, ref.bulk_world()[0], "world")
