@@ -1,5 +1,5 @@
 // bge_comm.cpp — the sharded tick's only collective: ONE ncclAllGather (RCCL over xGMI) of the root world
-// matrices per frame, on a side stream, double-buffered so that frame t's gather overlaps frame t+1's tick.
+// matrices per frame, on a side stream, over a ring of buffers so that frame t's gather overlaps the following ticks.
 //
 // xGMI on an MI355X node is a full mesh of point-to-point links; the gathered message is small (64 B per root:
 // 2 MiB per rank for 31,250 subtree roots), so the collective is latency-bound and the point of the side
@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/bge_world.h"
@@ -106,7 +107,7 @@ int RootComm::init(int nranks, int rank, const void* id128, uint64_t rows_per_ra
     rows_ = rows_per_rank ? rows_per_rank : 1;
     frame_ = 0;
     COMM_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < kRing; ++b) {
         COMM_HIP(hipMalloc(reinterpret_cast<void**>(&send_[b]), rows_ * 64));
         COMM_HIP(hipMalloc(reinterpret_cast<void**>(&table_[b]), rows_ * 64 * static_cast<size_t>(nranks)));
         COMM_HIP(hipMemset(send_[b], 0, rows_ * 64));
@@ -119,15 +120,20 @@ int RootComm::init(int nranks, int rank, const void* id128, uint64_t rows_per_ra
 
 int RootComm::begin_frame(hipStream_t compute, float** send)
 {
-    const int b = static_cast<int>(frame_ & 1);
-    if (in_flight_[b]) COMM_HIP(hipStreamWaitEvent(compute, gathered_[b], 0));
+    const int b = static_cast<int>(frame_ % kRing);
+    if (frame_ >= static_cast<uint64_t>(kWaitEvery) && frame_ % kWaitEvery == 0) {
+        // everything up to the gather of frame (t - kWaitEvery) is complete once this wait passes; the pairs used by
+        // frames t .. t + kWaitEvery - 1 were last read by gathers of frames <= t - (kRing - kWaitEvery + 1)
+        const int done = static_cast<int>((frame_ - kWaitEvery) % kRing);
+        if (in_flight_[done]) COMM_HIP(hipStreamWaitEvent(compute, gathered_[done], 0));
+    }
     *send = send_[b];
     return BGE_OK;
 }
 
 int RootComm::gather(hipStream_t compute, void** table_device)
 {
-    const int b = static_cast<int>(frame_ & 1);
+    const int b = static_cast<int>(frame_ % kRing);
     COMM_HIP(hipEventRecord(packed_[b], compute));
     COMM_HIP(hipStreamWaitEvent(side_, packed_[b], 0));
     COMM_NCCL(rccl().AllGather(send_[b], table_[b], rows_ * 16, ncclFloat32, static_cast<ncclComm_t>(comm_), side_));
@@ -140,7 +146,7 @@ int RootComm::gather(hipStream_t compute, void** table_device)
 
 int RootComm::wait(hipStream_t compute)
 {
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < kRing; ++b) {
         if (in_flight_[b]) COMM_HIP(hipStreamWaitEvent(compute, gathered_[b], 0));
     }
     return BGE_OK;
@@ -151,7 +157,7 @@ void RootComm::destroy()
     if (side_) (void)hipStreamSynchronize(side_);
     if (comm_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
     comm_ = nullptr;
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < kRing; ++b) {
         if (send_[b]) (void)hipFree(send_[b]);
         if (table_[b]) (void)hipFree(table_[b]);
         if (packed_[b]) (void)hipEventDestroy(packed_[b]);

@@ -14,6 +14,14 @@ public:
     int init(int nranks, int rank, const void* id128, uint64_t rows_per_rank);
     bool ready() const { return comm_ != nullptr; }
     uint64_t rows_per_rank() const { return rows_; }
+    int nranks() const { return nranks_; }
+    const void* last_table() const { return frame_ ? table_[(frame_ - 1) % kRing] : nullptr; }
+    // Buffer ring: frame t uses pair t % kRing.  The compute stream waits on the side stream only every kWaitEvery
+    // frames (on the gather of frame t - kWaitEvery); a pair is therefore reused no earlier than kRing - kWaitEvery + 1
+    // frames after a gather that is known to be complete.  A cross-stream wait costs ~4 us of dispatch gap on the
+    // compute stream (measured), a tick of 2 M entities ~38 us.
+    static constexpr int kRing = 8;
+    static constexpr int kWaitEvery = 4;
     // Returns the send buffer of this frame after making `compute` wait until the gather that last read it is done.
     int begin_frame(hipStream_t compute, float** send);
     // Enqueue the all-gather of this frame's send buffer on the side stream (after everything queued on `compute`).
@@ -30,11 +38,11 @@ private:
     uint64_t rows_ = 0;
     uint64_t frame_ = 0;
     hipStream_t side_ = nullptr;
-    float* send_[2] = {nullptr, nullptr};
-    float* table_[2] = {nullptr, nullptr};
-    hipEvent_t packed_[2] = {nullptr, nullptr};   // compute -> side: roots of the frame are packed
-    hipEvent_t gathered_[2] = {nullptr, nullptr}; // side -> compute: the buffer pair may be reused
-    bool in_flight_[2] = {false, false};
+    float* send_[kRing] = {};
+    float* table_[kRing] = {};
+    hipEvent_t packed_[kRing] = {};   // compute -> side: roots of the frame are packed
+    hipEvent_t gathered_[kRing] = {}; // side -> compute: the gather of that frame is complete
+    bool in_flight_[kRing] = {};
 };
 
 } // namespace bge

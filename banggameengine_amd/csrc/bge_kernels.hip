@@ -65,6 +65,15 @@ __device__ __forceinline__ void load_world(const float* __restrict__ world, uint
     }
 }
 
+// Root table for the per-frame all-gather, filled by the roots themselves (consecutive roots of a tile are
+// consecutive lanes, so the 64-byte rows of a wave form one contiguous run).
+__device__ __forceinline__ void store_root(float* __restrict__ root_out, uint32_t index, const float (&m)[16])
+{
+    float4* dst = reinterpret_cast<float4*>(root_out) + 4ull * index;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = make_float4(m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]);
+}
+
 // LDS hand-over between lanes of ONE wave: the hardware keeps a wave's DS operations in order; the fences
 // keep the compiler from moving them across this point.
 __device__ __forceinline__ void wave_lds_sync()
@@ -212,6 +221,7 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
                     lds_put(lds, tid, world);
                 } else {
                     lds_put(lds, tid, local); // root: world = local (Transform.cpp:32-35)
+                    if (p.root_out && !(f & kHasParent)) store_root(p.root_out, w.root_index[slot], local);
                 }
             }
             if (max_level != 0) {
@@ -256,6 +266,7 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
                     lds_put(lds, tid, world);
                 } else {
                     lds_put(lds, tid, local);
+                    if (p.root_out && !(f & kHasParent)) store_root(p.root_out, w.root_index[slot], local);
                 }
             }
             for (uint32_t d = 1; d <= max_level; ++d) {

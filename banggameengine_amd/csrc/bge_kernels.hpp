@@ -30,12 +30,14 @@ struct WorldView {
     uint32_t* group;          // [slots]     collision filter group (layer)
     uint32_t* mask;           // [slots]
     float* aabb;              // [slots][6]  min xyz, max xyz fed to the broadphase
+    const uint32_t* root_index; // [slots]   position of a root in the root table (read by roots only, when packing)
 };
 
 struct TickParams {
     float dt;
     float gx, gy, gz;
     uint32_t tile_begin;
+    float* root_out; // when non-null: roots also write their world matrix to root_out[root_index] (send buffer of the all-gather)
 };
 
 // flags: bit0 physics, bit1 transforms, bit2 aabb (bge_tick_flags)

@@ -116,7 +116,7 @@ struct bge_world {
     uint64_t n_bodies_hint = 0;
 
     // device arrays
-    DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots;
+    DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
     DevBuf root_worlds, counter, stage, stage2, mass_palette;
     std::vector<float> palette_inv_mass;            // class -> inv_mass (class 0 = 0: Static / Kinematic)
@@ -151,10 +151,11 @@ struct bge_world {
         view.mask = mask.as<uint32_t>();
         view.aabb = aabb.as<float>();
         view.mass_palette = mass_palette.as<float2>();
+        view.root_index = root_index.as<uint32_t>();
     }
     void release_all()
     {
-        for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &pos, &euler, &scale, &world, &vel,
+        for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
                           &stage2, &mass_palette}) {
             b->release();
@@ -420,6 +421,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     HIP_TRY(w->tile_hdr.ensure(T * 4));
     HIP_TRY(w->slot_of_entity.ensure(std::max<uint64_t>(n, 1) * 4));
     HIP_TRY(w->entity_of_slot.ensure(S * 4));
+    HIP_TRY(w->root_index.ensure(S * 4));
     HIP_TRY(w->root_slots.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 4));
     HIP_TRY(w->pos.ensure(S * 12));
     HIP_TRY(w->euler.ensure(S * 12));
@@ -449,8 +451,12 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
         HIP_TRY(bge::launch_init_slots(w->stream, nf.n_slots, w->stage.as<uint32_t>(), w->view));
     }
     if (n) HIP_TRY(hipMemcpyAsync(w->slot_of_entity.p, nf.slot_of_entity.data(), n * 4, hipMemcpyHostToDevice, w->stream));
+    std::vector<uint32_t> root_index_host;
     if (!nf.root_slots.empty()) {
         HIP_TRY(hipMemcpyAsync(w->root_slots.p, nf.root_slots.data(), nf.root_slots.size() * 4, hipMemcpyHostToDevice, w->stream));
+        root_index_host.assign(nf.n_slots, 0);
+        for (size_t k = 0; k < nf.root_slots.size(); ++k) root_index_host[nf.root_slots[k]] = static_cast<uint32_t>(k);
+        HIP_TRY(hipMemcpyAsync(w->root_index.p, root_index_host.data(), nf.n_slots * 4, hipMemcpyHostToDevice, w->stream));
     }
     HIP_TRY(hipStreamSynchronize(w->stream));
 
@@ -674,6 +680,20 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         p.gy = gravity ? gravity[1] : 0.0f;
         p.gz = gravity ? gravity[2] : 0.0f;
         const size_t n_passes = w->flat.pass_tile_begin.size() - 1;
+        // BGE_TICK_GATHER_ROOTS with a transform pass: the roots write the all-gather's send buffer themselves
+        const bool fused_gather = (flags & BGE_TICK_GATHER_ROOTS) && xform;
+        if (flags & BGE_TICK_GATHER_ROOTS) {
+            if (!w->comm.ready()) return fail(BGE_ERR_STATE, "BGE_TICK_GATHER_ROOTS needs bge_world_comm_init");
+            if (w->flat.root_slots.size() > w->comm.rows_per_rank()) {
+                return fail(BGE_ERR_INVALID, "%zu roots but the communicator was sized for %llu rows per rank",
+                            w->flat.root_slots.size(), (unsigned long long)w->comm.rows_per_rank());
+            }
+        }
+        if (fused_gather) {
+            float* send = nullptr;
+            if (w->comm.begin_frame(w->stream, &send) != BGE_OK) return fail(BGE_ERR_HIP, "%s", w->comm.error());
+            p.root_out = send;
+        }
         const bool pair_begins = w->profiling == 2 || (w->profiling == 1 && t == 0);
         const bool pair_ends = w->profiling == 2 || (w->profiling == 1 && t + 1 == ticks);
         if (pair_begins) {
@@ -702,7 +722,9 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
         }
         w->maybe_dirty = phys && !xform;
-        if (flags & BGE_TICK_GATHER_ROOTS) {
+        if (fused_gather) {
+            if (w->comm.gather(w->stream, nullptr) != BGE_OK) return fail(BGE_ERR_HIP, "%s", w->comm.error());
+        } else if (flags & BGE_TICK_GATHER_ROOTS) {
             if (int rc = bge_world_gather_roots(w, nullptr)) return rc;
         }
     }
@@ -926,6 +948,20 @@ int bge_world_gather_roots(bge_world* w, void** table_device)
     HIP_TRY(bge::launch_pack_roots(w->stream, w->flat.root_slots.size(), w->root_slots.as<uint32_t>(), w->world.as<float>(), send));
     rc = w->comm.gather(w->stream, table_device);
     if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
+    return BGE_OK;
+}
+
+int bge_world_download_gathered(bge_world* w, float* out, uint64_t floats)
+{
+    if (!w || !out) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->comm.ready()) return fail(BGE_ERR_STATE, "bge_world_comm_init has not been called");
+    DeviceGuard guard(w->device);
+    if (w->comm.wait(w->stream) != BGE_OK) return fail(BGE_ERR_HIP, "%s", w->comm.error());
+    const void* table = w->comm.last_table();
+    if (!table) return fail(BGE_ERR_STATE, "nothing has been gathered yet");
+    const uint64_t have = w->comm.rows_per_rank() * 16 * static_cast<uint64_t>(w->comm.nranks());
+    HIP_TRY(hipMemcpyAsync(out, table, std::min(floats, have) * 4, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
     return BGE_OK;
 }
 

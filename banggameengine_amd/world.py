@@ -174,6 +174,11 @@ class World:
         check(lib().bge_world_gather_roots(self._h, C.byref(ptr)))
         return int(ptr.value or 0)
 
+    def download_gathered(self, nranks: int, rows_per_rank: int):
+        out = np.empty((nranks, rows_per_rank, 16), np.float32)
+        check(lib().bge_world_download_gathered(self._h, _p(out), out.size))
+        return out
+
     def comm_wait(self):
         check(lib().bge_world_comm_wait(self._h))
 

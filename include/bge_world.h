@@ -210,6 +210,8 @@ BGE_API int bge_comm_unique_id(void* out128);
 BGE_API int bge_world_comm_init(bge_world* world, int nranks, int rank, const void* id128, uint64_t rows_per_rank);
 BGE_API int bge_world_gather_roots(bge_world* world, void** table_device);
 BGE_API int bge_world_comm_wait(bge_world* world);
+/* Copy the most recently gathered table to the host (waits for it): nranks x rows_per_rank x 16 floats. */
+BGE_API int bge_world_download_gathered(bge_world* world, float* out, uint64_t floats);
 BGE_API int bge_world_comm_destroy(bge_world* world);
 BGE_API int bge_world_get_info(bge_world* world, bge_world_info* info);
 

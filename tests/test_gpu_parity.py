@@ -229,3 +229,28 @@ def test_mass_palette_and_per_slot_fallback(distinct):
     assert_bits_equal(got_vel, ref.bulk_bodies()["linvel"], "linvel")
     assert_bits_equal(got_pos, want_pos, "position")
     assert_bits_equal(got_world, ref.bulk_world()[0], "world")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_native_root_gather_single_rank(fused):
+    """One-rank rehearsal of the native RCCL path: the gathered table must be this rank's root world matrices, both
+    when the roots write the send buffer from inside the tick kernel (BGE_TICK_GATHER_ROOTS) and through the
+    separate packing kernel (bge_world_gather_roots)."""
+    wl = synth.config("subtree64", n=64 * 700)
+    roots = np.flatnonzero(wl.parent == 0xFFFFFFFF)
+    with B.World() as w:
+        w.load(wl)
+        w.comm_init(1, 0, B.World.comm_unique_id(), len(roots) + 5)   # padded rows stay zero
+        for k in range(3):   # buffers alternate: exercise both
+            if fused:
+                w.tick(dt=DT, flags=B.TICK_ALL | B.TICK_GATHER_ROOTS)
+            else:
+                w.tick(dt=DT)
+                w.gather_roots()
+            if k == 0:
+                w.set_velocities(wl.vel)
+        table = w.download_gathered(1, len(roots) + 5)
+        world = w.download_world()
+        w.comm_destroy()
+    assert_bits_equal(table[0, : len(roots)], world[roots], "gathered roots")
+    assert not table[0, len(roots):].any()
