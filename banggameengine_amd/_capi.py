@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libbge_world.so")
+# BGE_WORLD_LIB selects another build of the same ABI (A/B timing experiments); default: the in-tree library
+_LIB = os.environ.get("BGE_WORLD_LIB") or os.path.join(_HERE, "libbge_world.so")
 
 
 class BgeError(RuntimeError):

@@ -270,7 +270,9 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
                 }
             }
             for (uint32_t d = 1; d <= max_level; ++d) {
+#ifndef BGE_EXPERIMENT_NO_LEVEL_BARRIER /* timing-only A/B build: results are wrong without the barrier */
                 __syncthreads();
+#endif
                 if (valid && level == d) {
                     float pw[16];
                     lds_get(lds, parent, pw);

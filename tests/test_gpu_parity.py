@@ -325,3 +325,68 @@ def test_physics_only_then_transform_only_ticks():
             assert_bits_equal(w.download_world(), ref.bulk_world()[0], f"world tick {k}")
         w.tick(flags=B.TICK_TRANSFORMS)   # nothing dirty: a no-op
         assert_bits_equal(w.download_world(), ref.bulk_world()[0], "idle update")
+
+
+def test_error_codes_and_messages():
+    """The C ABI never throws and reports misuse through status codes + bge_last_error (include/bge_world.h)."""
+    import ctypes as C
+    from banggameengine_amd import _capi
+    lib = B.lib()
+    with B.World() as w:
+        for call in (lambda: w.upload_trs(np.zeros((1, 3), np.float32)), lambda: w.tick(), lambda: w.dirty_count(),
+                     lambda: w.pack_roots(), lambda: w.info()):
+            with pytest.raises(B.BgeError) as e:
+                call()
+            assert e.value.code == -4 and "set_topology" in str(e.value)       # BGE_ERR_STATE
+        w.set_topology(np.full(10, 0xFFFFFFFF, np.uint32))
+        with pytest.raises(B.BgeError) as e:
+            w.upload_trs(np.zeros((11, 3), np.float32))
+        assert e.value.code == -1 and "outside" in str(e.value)                  # BGE_ERR_INVALID
+        with pytest.raises(B.BgeError):
+            w.upload_bodies(np.array([7], np.uint8))                             # not a bge_body_type
+        with pytest.raises(B.BgeError):
+            w.tick(flags=0)
+        with pytest.raises(B.BgeError):
+            w.tick(flags=B.TICK_TRANSFORMS | B.TICK_BROADPHASE)                  # broadphase needs the physics step
+        with pytest.raises(B.BgeError) as e:
+            w.tick(flags=B.TICK_ALL | B.TICK_GATHER_ROOTS)
+        assert "comm_init" in str(e.value)
+        idx = np.array([3, 99], np.uint32)
+        rc = lib.bge_world_upload_trs_indexed(w._h, 2, idx.ctypes.data_as(C.c_void_p), None, None, None)
+        assert rc == -1 and b"entity_index[1]" in lib.bge_last_error()
+        w.tick()                                                                   # still usable afterwards
+        assert w.dirty_count() == 0
+    assert lib.bge_world_create(None, None) == -1
+
+
+def test_retopology_keeps_state_and_marks_reparented_subtrees_dirty():
+    """bge_world_set_topology on a live world: component state of surviving indices is carried over, re-parented
+    subtrees become dirty (Scene::SetParent -> MarkHierarchyDirty, Scene.cpp:392), untouched bodies are NOT re-posed."""
+    n = 3000
+    wl = synth.config("chains4", n=n)
+    ref = build_oracle(wl)
+    with B.World() as w:
+        w.load(wl)
+        run_world(w, wl, 3)
+        run_oracle(ref, wl, 3)
+        # re-link: every chain whose root index is a multiple of 40 hangs under entity 1; grow the scene by 8 entities
+        parent = wl.parent.copy()
+        for r in range(40, n, 40):
+            parent[r] = 1
+            ref.SetParent(r + 1, 2)
+        parent = np.concatenate([parent, np.full(8, 0xFFFFFFFF, np.uint32)])
+        extra = synth.trs(77, 0, 8)
+        for k in range(8):
+            eid = ref.CreateEntity()
+            ref.AddTransform(eid, extra[0][k], extra[1][k], extra[2][k])
+        ref.n = n + 8
+        w.set_topology(parent)
+        w.upload_trs(*extra, first=n)
+        assert w.dirty_count() == ref.CountDirtyTransforms()
+        for _ in range(3):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT)
+        got_vel = w.download_bodies()["linvel"]
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world after re-topology")
+        assert_bits_equal(got_vel, ref.bulk_bodies()["linvel"], "velocities after re-topology")
