@@ -13,10 +13,12 @@
 //   3. k_bp_count    cell index of each body's AABB min corner; atomic histogram, the returned value is the
 //                    body's rank inside its cell (so the scatter needs no second atomic)
 //   4. scan          exclusive prefix sum of the histogram (3 small kernels)
-//   5. k_bp_scatter  bodies sorted by cell into 32-byte records (min xyz | slot, max xyz | cell)
-//   6. k_bp_pairs    every body scans the 5 contiguous runs of the 14 "forward" neighbour cells; overlapping
-//                    pairs are compacted per wave with a ballot + one atomic per wave per iteration
+//   5. k_bp_scatter  bodies sorted by cell into 48-byte records (min xyz | entity, max xyz | cell, filter words)
+//   6. k_bp_pairs    every body scans the 5 contiguous runs of the 14 "forward" neighbour cells, staged through
+//                    LDS per workgroup; overlapping pairs are ballot-compacted per wave into an LDS staging
+//                    buffer and written 256 at a time behind one global atomic
 //   7. k_bp_large    large bodies against everything
+//   8. k_bp_compact  the 64 shard slices of the pair list -> one compact list + totals
 // A small body's AABB is narrower than one cell (by a 2^-20 margin that dominates the f64 rounding of the
 // cell coordinates), so two overlapping small bodies sit in cells that differ by at most one per axis; scanning only forward neighbours (and, inside the own cell, only later records) reports
 // each pair once.  The kernels are bound by L2/Infinity-Cache traffic of the sorted records, not by HBM.
@@ -43,6 +45,8 @@ struct GridParams {
 
 // Extent histogram: bin = bits 21..30 of the (positive) float = 8 exponent bits + 2 mantissa bits, so
 // consecutive bin edges are 19-25 % apart.
+constexpr uint32_t kShards = 64;
+constexpr uint32_t kBoundsBlocks = 2048; // grid of k_bp_bounds: 8 workgroups per CU keep enough loads in flight
 constexpr uint32_t kExtentBins = 1024;
 __host__ __device__ inline uint32_t extent_bin(float e) { return (__builtin_bit_cast(uint32_t, e) >> 21) & (kExtentBins - 1u); }
 __host__ __device__ inline float extent_bin_upper(uint32_t b) { return __builtin_bit_cast(float, (b + 1u) << 21); }
@@ -52,8 +56,16 @@ struct Accum {
     uint32_t max_bits[3];
     uint32_t n_bodies;
     uint32_t n_large;
-    unsigned long long n_pairs;
+    unsigned long long n_pairs;        // total found (written by k_bp_compact)
+    unsigned long long n_pairs_kept;   // total present in the compact list
     GridParams grid;
+    // Pair emission is sharded: one counter (on its own 64-byte line) and one slice of the staging buffer per shard.
+    // A single counter word sustains ~10^8 atomics/s; 57 k flushes on one word cost ~0.6 ms for 12.6 M pairs.
+    unsigned long long shard_count[kShards][8];
+    // per-workgroup partial bounds of k_bp_bounds (no atomics), reduced by k_bp_params
+    float part_min[kBoundsBlocks][3];
+    float part_max[kBoundsBlocks][3];
+    uint32_t part_count[kBoundsBlocks];
     uint32_t extent_hist[kExtentBins]; // bodies per extent bin (bin = float exponent + 2 mantissa bits)
 };
 
@@ -83,7 +95,9 @@ __global__ void k_bp_reset(Accum* acc)
         acc->n_bodies = 0;
         acc->n_large = 0;
         acc->n_pairs = 0;
+        acc->n_pairs_kept = 0;
     }
+    if (blockIdx.x == 0 && threadIdx.x < kShards) acc->shard_count[threadIdx.x][0] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint32_t* __restrict__ flags,
@@ -99,8 +113,14 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
     float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t cnt = 0;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t s = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; s < n_slots; s += stride) {
-        if (!is_body(flags[s])) continue;
+    // uniform trip count per wave (the aggregation below ballots across all 64 lanes)
+    const uint64_t first = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t rounds = (n_slots + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t s = first + r * stride;
+        uint32_t my_bin = 0;
+        bool have_bin = false;
+        if (s < n_slots && is_body(flags[s])) {
         const float2* b = reinterpret_cast<const float2*>(aabb + 6 * s);
         const float2 b0 = b[0], b1 = b[1], b2 = b[2]; // min.x min.y | min.z max.x | max.y max.z
         mn[0] = fminf(mn[0], b0.x);
@@ -110,8 +130,22 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
         mx[1] = fmaxf(mx[1], b2.x);
         mx[2] = fmaxf(mx[2], b2.y);
         const float e = fmaxf(fmaxf(b1.y - b0.x, b2.x - b0.y), b2.y - b1.x);
-        atomicAdd(&hist[(e > 0.0f && e < INFINITY) ? extent_bin(e) : 0u], 1u); // LDS atomic
+        my_bin = (e > 0.0f && e < INFINITY) ? extent_bin(e) : 0u;
+        have_bin = true;
         cnt += 1;
+        }
+        // Histogram update, wave-aggregated: bodies of similar size share a bin, and 64 lanes hammering one LDS
+        // word serialise.  Each round the first pending lane's bin is broadcast, all lanes with that bin retire
+        // together and their leader adds the population count (usually one or two rounds).
+        while (true) {
+            const unsigned long long pending = __ballot(have_bin);
+            if (pending == 0) break;
+            const int leader = __ffsll(static_cast<long long>(pending)) - 1;
+            const uint32_t lead_bin = __shfl(my_bin, leader, 64);
+            const unsigned long long same = __ballot(have_bin && my_bin == lead_bin);
+            if (static_cast<int>(threadIdx.x & 63u) == leader) atomicAdd(&hist[lead_bin], static_cast<uint32_t>(__popcll(same)));
+            if (have_bin && my_bin == lead_bin) have_bin = false;
+        }
     }
     // wave64 __shfl reductions, then across the 4 waves through LDS, then one set of atomics per workgroup
 #pragma unroll
@@ -135,15 +169,11 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (int wv = 0; wv < 4; ++wv) total += red_cnt[wv];
-        if (total) {
-            for (int a = 0; a < 3; ++a) {
-                const float lo = fminf(fminf(red[0][a], red[1][a]), fminf(red[2][a], red[3][a]));
-                const float hi = fmaxf(fmaxf(red[0][3 + a], red[1][3 + a]), fmaxf(red[2][3 + a], red[3][3 + a]));
-                atomicMin(&acc->min_bits[a], f2ord(lo));
-                atomicMax(&acc->max_bits[a], f2ord(hi));
-            }
-            atomicAdd(&acc->n_bodies, total);
+        for (int a = 0; a < 3; ++a) {
+            acc->part_min[blockIdx.x][a] = fminf(fminf(red[0][a], red[1][a]), fminf(red[2][a], red[3][a]));
+            acc->part_max[blockIdx.x][a] = fmaxf(fmaxf(red[0][3 + a], red[1][3 + a]), fmaxf(red[2][3 + a], red[3][3 + a]));
         }
+        acc->part_count[blockIdx.x] = total;
     }
     for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) {
         const uint32_t h = hist[k];
@@ -156,10 +186,38 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
 //            + n_large(c) * n                        (k_bp_large: every large body against everything)
 // over the histogram's bin edges c (a body is "small" when its widest side is < c); then grow the cell
 // until the padded grid fits the table.
-__global__ void __launch_bounds__(64) k_bp_params(Accum* acc, uint32_t max_cells)
+__global__ void __launch_bounds__(64) k_bp_params(Accum* acc, uint32_t max_cells, uint32_t n_bounds_blocks)
 {
     __shared__ uint32_t below[kExtentBins + 1]; // exclusive prefix: bodies in bins < b
     const uint32_t lane = threadIdx.x;
+    {
+        // reduce the per-workgroup partial bounds (wave64 __shfl reductions)
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t cnt = 0;
+        for (uint32_t b = lane; b < n_bounds_blocks; b += 64) {
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = fminf(mn[a], acc->part_min[b][a]);
+                mx[a] = fmaxf(mx[a], acc->part_max[b][a]);
+            }
+            cnt += acc->part_count[b];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+                mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+            }
+            cnt += __shfl_xor(cnt, off, 64);
+        }
+        if (lane == 0) {
+            for (int a = 0; a < 3; ++a) {
+                acc->min_bits[a] = f2ord(mn[a]);
+                acc->max_bits[a] = f2ord(mx[a]);
+            }
+            acc->n_bodies = cnt;
+        }
+        __syncthreads();
+    }
     {
         // exclusive prefix of the histogram: 16 consecutive bins per lane + a wave64 __shfl_up scan of the lane totals
         uint32_t h[16];
@@ -364,26 +422,32 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
     }
 }
 
+// Sorted record, 48 bytes: everything the pair test and the emission need, so that a hit costs no further
+// (uncoalesced, dependent) global loads:  r0 = min.xyz | entity   r1 = max.xyz | cell   r2 = group | mask | static | slot
 __global__ void __launch_bounds__(256) k_bp_scatter(uint64_t n_slots, const uint32_t* __restrict__ flags,
                                                     const float* __restrict__ aabb, const uint32_t* __restrict__ cell_start,
                                                     const uint32_t* __restrict__ body_cell, const uint32_t* __restrict__ body_rank,
-                                                    float4* __restrict__ sorted)
+                                                    const uint32_t* __restrict__ group, const uint32_t* __restrict__ mask,
+                                                    const uint32_t* __restrict__ entity_of_slot, float4* __restrict__ sorted)
 {
     const uint64_t s = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (s >= n_slots) return;
-    if (!is_body(flags[s])) return;
+    const uint32_t f = flags[s];
+    if (!is_body(f)) return;
     const uint32_t c = body_cell[s];
     if (c == kLargeCell) return;
     const uint32_t pos = cell_start[c] + body_rank[s];
     const float* b = aabb + 6 * s;
-    sorted[2ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(static_cast<uint32_t>(s)));
-    sorted[2ull * pos + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(c));
+    sorted[3ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(entity_of_slot[s]));
+    sorted[3ull * pos + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(c));
+    sorted[3ull * pos + 2] = make_float4(__uint_as_float(group[s]), __uint_as_float(mask[s]),
+                                         __uint_as_float((f & kTypeMask) == 1u ? 1u : 0u), __uint_as_float(static_cast<uint32_t>(s)));
 }
 
 struct PairSink {
-    unsigned long long* count;
-    uint2* pairs;
-    uint64_t cap;
+    unsigned long long* shard_count; // [kShards][8]
+    uint2* pairs;                    // staging: kShards slices of shard_cap pairs
+    uint64_t shard_cap;
 };
 
 // Wave-compacted append with per-wave staging in LDS.  Each call ballots the hits of the wave, packs them
@@ -410,11 +474,13 @@ struct WaveStage {
 __device__ __forceinline__ void stage_flush(const PairSink& sink, WaveStage& st, uint32_t n_out)
 {
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t shard = blockIdx.x % kShards;
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(sink.count, static_cast<unsigned long long>(n_out));
+    if (lane == 0) base = atomicAdd(&sink.shard_count[shard * 8u], static_cast<unsigned long long>(n_out));
     base = __shfl(base, 0, 64);
+    uint2* dst = sink.pairs + static_cast<uint64_t>(shard) * sink.shard_cap;
     for (uint32_t k = lane; k < n_out; k += 64u) {
-        if (base + k < sink.cap) sink.pairs[base + k] = st.buf[k];
+        if (base + k < sink.shard_cap) dst[base + k] = st.buf[k];
     }
     // carry the remainder (< 64 entries) down to the front
     const uint32_t rest = st.fill - n_out;
@@ -452,75 +518,98 @@ __device__ __forceinline__ bool filter_ok(const uint32_t* __restrict__ flags, co
     return !both_static && (group[sa] & mask[sb]) != 0 && (group[sb] & mask[sa]) != 0;
 }
 
-__global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
-                                                  const float4* __restrict__ sorted, const uint32_t* __restrict__ flags,
-                                                  const uint32_t* __restrict__ group, const uint32_t* __restrict__ mask,
-                                                  const uint32_t* __restrict__ entity_of_slot, PairSink sink,
-                                                  uint32_t n_sorted_max)
+// Pair search, LDS-tiled.  A workgroup owns 256 consecutive sorted bodies.  For each of the 5 neighbour runs the
+// union of its bodies' candidate ranges is one contiguous range of sorted records (records are sorted by cell, x
+// fastest); it is staged through LDS in coalesced chunks of kChunk records, and every lane tests only the part of the
+// chunk that belongs to ITS OWN candidate range.  The first version walked the ranges with dependent global loads
+// (one or two candidates in flight per lane) and was latency-bound at 1.45 ms for 4 M bodies.
+constexpr uint32_t kChunk = 512; // records per staged chunk: 24 KiB of LDS
+
+__device__ __forceinline__ bool filter_rec(const float4& a2, const float4& b2)
 {
+    const bool both_static = __float_as_uint(a2.z) != 0u && __float_as_uint(b2.z) != 0u;
+    return !both_static && (__float_as_uint(a2.x) & __float_as_uint(b2.y)) != 0u && (__float_as_uint(b2.x) & __float_as_uint(a2.y)) != 0u;
+}
+
+__global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
+                                                  const float4* __restrict__ sorted, PairSink sink)
+{
+    __shared__ float4 cand[3 * kChunk];
     __shared__ uint2 stage_lds[4][kStage];
+    __shared__ uint32_t s_cell_first, s_cell_last;
+
     const GridParams g = acc->grid;
     const uint32_t n_sorted = g.n_bodies - acc->n_large;
+    const uint32_t n_blocks = (n_sorted + 255u) / 256u;
     WaveStage st{stage_lds[threadIdx.x >> 6], 0u};
-    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t tid = threadIdx.x;
 
-    // grid-stride over the sorted bodies: a wave keeps its staging buffer across chunks, so the tail flush
-    // (one atomic) is paid once per wave, not once per 64 bodies
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_sorted; i0 += stride) {
-        const uint32_t i = i0 + (threadIdx.x & 63u);
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint32_t i = blk * 256u + tid;
         const bool active = i < n_sorted;
-        float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+        float4 lo = make_float4(0, 0, 0, 0), hi = lo, fi = lo;
         uint32_t cell = 0;
         if (active) {
-            lo = sorted[2ull * i];
-            hi = sorted[2ull * i + 1];
+            lo = sorted[3ull * i];
+            hi = sorted[3ull * i + 1];
+            fi = sorted[3ull * i + 2];
             cell = __float_as_uint(hi.w);
         }
-        const uint32_t slot_i = __float_as_uint(lo.w);
+        const uint32_t entity_i = __float_as_uint(lo.w);
+        const uint32_t last_tid = min(255u, n_sorted - 1u - blk * 256u);
+        __syncthreads(); // previous block iteration is done with s_cell_*
+        if (tid == 0) s_cell_first = cell;
+        if (tid == last_tid) s_cell_last = cell;
+        __syncthreads();
+        const uint32_t cell_first = s_cell_first, cell_last = s_cell_last;
 
-        // 5 contiguous runs cover the own cell's later records and the 13 forward neighbour cells
 #pragma unroll 1
         for (int row = 0; row < 5; ++row) {
-            uint32_t j = 0, end = 0;
-            if (active) {
-                if (row == 0) {
+            // this lane's candidate range [j, end) and the workgroup's union [r_lo, r_hi)
+            uint32_t j = 0, end = 0, r_lo, r_hi;
+            if (row == 0) {
+                // own cell's later records + the cell to the right
+                if (active) {
                     j = i + 1;
                     end = cell_start[cell + 2];
-                } else {
-                    const int dy = (row == 1) ? 1 : (row - 3); // rows 2,3,4 -> dy = -1,0,1 at dz = 1
-                    const int dz = (row == 1) ? 0 : 1;
-                    const uint32_t c = cell + static_cast<uint32_t>(dy * static_cast<int>(g.dim_x)) + static_cast<uint32_t>(dz) * g.dim_xy;
-                    j = cell_start[c - 1];
-                    end = cell_start[c + 2];
                 }
+                r_lo = blk * 256u + 1u;
+                r_hi = cell_start[cell_last + 2];
+            } else {
+                const int dy = (row == 1) ? 1 : (row - 3); // rows 2,3,4 -> dy = -1,0,1 at dz = 1
+                const int dz = (row == 1) ? 0 : 1;
+                const uint32_t off = static_cast<uint32_t>(dy * static_cast<int>(g.dim_x)) + static_cast<uint32_t>(dz) * g.dim_xy;
+                if (active) {
+                    j = cell_start[cell + off - 1];
+                    end = cell_start[cell + off + 2];
+                }
+                r_lo = cell_start[cell_first + off - 1];
+                r_hi = cell_start[cell_last + off + 2];
             }
-            while (__any(j < end)) {
-                // two candidates per trip: the loads of both are in flight together
-                bool hit0 = false, hit1 = false;
-                uint32_t s0 = 0, s1 = 0;
-                if (j < end) {
-                    const bool two = j + 1 < end;
-                    const float4 alo = sorted[2ull * j], ahi = sorted[2ull * j + 1];
-                    float4 blo = alo, bhi = ahi;
-                    if (two) {
-                        blo = sorted[2ull * j + 2];
-                        bhi = sorted[2ull * j + 3];
+            for (uint32_t base = r_lo; base < r_hi; base += kChunk) {
+                const uint32_t top = min(base + kChunk, r_hi);
+                // skip chunks no lane needs (sparse worlds: far-apart cells with crowded cells in between)
+                const uint32_t jj0 = max(j, base);
+                const uint32_t e0 = min(end, top);
+                if (!__syncthreads_or(jj0 < e0)) continue;
+                for (uint32_t k = tid; k < 3u * (top - base); k += 256u) cand[k] = sorted[3ull * base + k];
+                __syncthreads();
+                uint32_t jj = jj0;
+                while (__any(jj < e0)) {
+                    bool hit = false;
+                    uint32_t entity_j = 0;
+                    if (jj < e0) {
+                        const float4 blo = cand[3u * (jj - base)];
+                        const float4 bhi = cand[3u * (jj - base) + 1u];
+                        if (overlap(lo, hi, blo, bhi)) {
+                            hit = filter_rec(fi, cand[3u * (jj - base) + 2u]);
+                            entity_j = __float_as_uint(blo.w);
+                        }
+                        ++jj;
                     }
-                    if (overlap(lo, hi, alo, ahi)) {
-                        s0 = __float_as_uint(alo.w);
-                        hit0 = filter_ok(flags, group, mask, slot_i, s0);
-                    }
-                    if (two && overlap(lo, hi, blo, bhi)) {
-                        s1 = __float_as_uint(blo.w);
-                        hit1 = filter_ok(flags, group, mask, slot_i, s1);
-                    }
-                    j += 2;
+                    if (__any(hit)) emit_pairs(sink, st, hit, entity_i, entity_j);
                 }
-                if (__any(hit0 || hit1)) {
-                    const uint32_t ei = (hit0 || hit1) ? entity_of_slot[slot_i] : 0u;
-                    emit_pairs(sink, st, hit0, ei, hit0 ? entity_of_slot[s0] : 0u);
-                    emit_pairs(sink, st, hit1, ei, hit1 ? entity_of_slot[s1] : 0u);
-                }
+                // (the __syncthreads_or at the top of the next iteration protects cand before it is overwritten)
             }
         }
     }
@@ -565,6 +654,43 @@ __global__ void __launch_bounds__(256) k_bp_large(uint64_t n_slots, const Accum*
     if (st.fill) stage_flush(sink, st, st.fill);
 }
 
+// Shard slices -> one compact list.  Block (shard, part): offset of the shard = sum of the kept counts before it.
+constexpr uint32_t kCompactParts = 32;
+__global__ void __launch_bounds__(256) k_bp_compact(Accum* acc, const uint2* __restrict__ staged, uint64_t shard_cap,
+                                                    uint2* __restrict__ out, uint64_t out_cap)
+{
+    const uint32_t shard = blockIdx.x / kCompactParts;
+    const uint32_t part = blockIdx.x % kCompactParts;
+    unsigned long long offset = 0, total = 0, kept_total = 0;
+    for (uint32_t t = 0; t < kShards; ++t) {
+        const unsigned long long c = acc->shard_count[t][0];
+        const unsigned long long k = c < shard_cap ? c : shard_cap;
+        if (t < shard) offset += k;
+        total += c;
+        kept_total += k;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        acc->n_pairs = total;
+        acc->n_pairs_kept = kept_total < out_cap ? kept_total : out_cap;
+    }
+    const unsigned long long c = acc->shard_count[shard][0];
+    const unsigned long long kept = c < shard_cap ? c : shard_cap;
+    const unsigned long long per = (kept + kCompactParts - 1) / kCompactParts;
+    const unsigned long long lo = per * part;
+    const unsigned long long hi = lo + per < kept ? lo + per : kept;
+    const uint2* src = staged + static_cast<uint64_t>(shard) * shard_cap;
+    for (unsigned long long k = lo + threadIdx.x; k < hi; k += 256) {
+        if (offset + k < out_cap) out[offset + k] = src[k];
+    }
+}
+
+// Each shard can hold far more than its even share, so that a skewed or tiny scene (few workgroups -> few shards in
+// use) does not drop pairs: min(capacity, max(capacity / 16, 65536)).
+inline uint64_t shard_capacity(uint64_t capacity)
+{
+    return std::min<uint64_t>(std::max<uint64_t>(capacity, 1), std::max<uint64_t>(capacity / 16, 65536));
+}
+
 inline uint32_t blocks_for(uint64_t n, uint32_t per) { return static_cast<uint32_t>((n + per - 1) / per); }
 
 } // namespace
@@ -578,7 +704,7 @@ int Broadphase::fail(int code, const char* what, hipError_t e)
 
 void Broadphase::release()
 {
-    for (void** p : {&pairs_, &counters_, &cell_count_, &cell_start_, &scan_tmp_, &sorted_slot_, &sorted_aabb_, &body_cell_,
+    for (void** p : {&pairs_, &scan_stage_, &counters_, &cell_count_, &cell_start_, &scan_tmp_, &sorted_slot_, &sorted_aabb_, &body_cell_,
                      &large_list_}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -611,12 +737,13 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
     // Allocation is lazy-free: a world that never runs the broadphase still pays for these buffers;
     // they total ~ (8 + 8 + 32 + 8 + 4) B per slot + 8 B per pair.
     BP_TRY(hipMalloc(&pairs_, std::max<uint64_t>(capacity_, 1) * 8));
+    BP_TRY(hipMalloc(&scan_stage_, shard_capacity(capacity_) * kShards * 8)); // sharded staging of the pair list
     BP_TRY(hipMalloc(&counters_, sizeof(Accum)));
     BP_TRY(hipMalloc(&cell_count_, (static_cast<size_t>(table_size_) + kScanBlock) * 4));
     BP_TRY(hipMalloc(&cell_start_, (static_cast<size_t>(table_size_) + kScanBlock) * 4));
     BP_TRY(hipMalloc(&scan_tmp_, (static_cast<size_t>(table_size_) / kScanBlock + 2) * 4));
     BP_TRY(hipMalloc(&sorted_slot_, std::max<uint64_t>(n_slots, 1) * 4));  // body rank inside its cell
-    BP_TRY(hipMalloc(&sorted_aabb_, std::max<uint64_t>(n_slots, 1) * 32));
+    BP_TRY(hipMalloc(&sorted_aabb_, std::max<uint64_t>(n_slots, 1) * 48));
     BP_TRY(hipMalloc(&body_cell_, std::max<uint64_t>(n_slots, 1) * 4));
     BP_TRY(hipMalloc(&large_list_, std::max<uint64_t>(n_slots, 1) * 4));
     BP_TRY(hipMemset(counters_, 0, sizeof(Accum)));
@@ -637,7 +764,8 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     uint32_t* body_cell = static_cast<uint32_t*>(body_cell_);
     uint32_t* large_list = static_cast<uint32_t*>(large_list_);
     float4* sorted = static_cast<float4*>(sorted_aabb_);
-    const PairSink sink{&acc->n_pairs, static_cast<uint2*>(pairs_), capacity_};
+    const uint64_t shard_cap = shard_capacity(capacity_);
+    const PairSink sink{&acc->shard_count[0][0], static_cast<uint2*>(scan_stage_), shard_cap};
     ran_ = true;
     if (n == 0) {
         BP_TRY(hipMemsetAsync(counters_, 0, sizeof(Accum), stream));
@@ -649,8 +777,9 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     const uint32_t slot_blocks = blocks_for(n, 256);
 
     hipLaunchKernelGGL(k_bp_reset, dim3(1), dim3(256), 0, stream, acc);
-    hipLaunchKernelGGL(k_bp_bounds, dim3(std::min<uint32_t>(slot_blocks, 1024)), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
-    hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(64), 0, stream, acc, table_size_);
+    const uint32_t bounds_blocks = std::min<uint32_t>(slot_blocks, kBoundsBlocks);
+    hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
+    hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(64), 0, stream, acc, table_size_, bounds_blocks);
     BP_TRY(hipMemsetAsync(cell_count, 0, (static_cast<size_t>(table_size_) + kScanBlock) * 4, stream));
     hipLaunchKernelGGL(k_bp_count, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc, cell_count, body_cell,
                        body_rank, large_list);
@@ -658,11 +787,12 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, block_sums, scan_blocks);
     hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, stream, cell_start, block_sums, scan_n);
     hipLaunchKernelGGL(k_bp_scatter, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, cell_start, body_cell,
-                       body_rank, sorted);
-    hipLaunchKernelGGL(k_bp_pairs, dim3(std::min<uint32_t>(slot_blocks, 2048)), dim3(256), 0, stream, acc, cell_start, sorted, w.flags, w.group, w.mask,
-                       entity_of_slot, sink, static_cast<uint32_t>(n));
+                       body_rank, w.group, w.mask, entity_of_slot, sorted);
+    hipLaunchKernelGGL(k_bp_pairs, dim3(std::min<uint32_t>(slot_blocks, 2048)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
     hipLaunchKernelGGL(k_bp_large, dim3(std::min<uint32_t>(slot_blocks, 4096)), dim3(256), 0, stream, n, acc, large_list,
                        body_cell, w.aabb, w.flags, w.group, w.mask, entity_of_slot, sink);
+    hipLaunchKernelGGL(k_bp_compact, dim3(kShards * kCompactParts), dim3(256), 0, stream, acc, static_cast<const uint2*>(scan_stage_),
+                       shard_cap, static_cast<uint2*>(pairs_), capacity_);
     BP_TRY(hipGetLastError());
     return BGE_OK;
 }
@@ -673,10 +803,18 @@ int Broadphase::download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uin
     if (!ran_) return BGE_OK;
     unsigned long long n = 0;
     const Accum* acc = static_cast<const Accum*>(counters_);
-    BP_TRY(hipMemcpyAsync(&n, &acc->n_pairs, sizeof n, hipMemcpyDeviceToHost, stream));
+    unsigned long long both[2] = {0, 0};
+    BP_TRY(hipMemcpyAsync(both, &acc->n_pairs, sizeof both, hipMemcpyDeviceToHost, stream));
     BP_TRY(hipStreamSynchronize(stream));
-    *total = n;
-    const uint64_t take = std::min<uint64_t>(std::min<uint64_t>(n, cap), capacity_);
+    n = both[0];
+    *total = n; // found; both[1] of them are present in the compact list
+    if (pairs2 && both[1] < both[0]) {
+        error_ = std::to_string(both[0]) + " pairs found but the device kept " + std::to_string(both[1]) +
+                 " (pair_capacity " + std::to_string(capacity_) + ", split over " + std::to_string(kShards) +
+                 " emission shards): create the world with a larger pair_capacity";
+        return BGE_ERR_INVALID;
+    }
+    const uint64_t take = std::min<uint64_t>(std::min<uint64_t>(both[1], cap), capacity_);
     if (take && pairs2) {
         BP_TRY(hipMemcpyAsync(pairs2, pairs_, take * 8, hipMemcpyDeviceToHost, stream));
         BP_TRY(hipStreamSynchronize(stream));

@@ -28,13 +28,14 @@ private:
     uint64_t n_slots_ = 0;
     uint64_t capacity_ = 0;
     uint32_t table_size_ = 0;
-    void* pairs_ = nullptr;      // uint32[capacity][2]
+    void* pairs_ = nullptr;      // uint32[capacity][2] compact list
+    void* scan_stage_ = nullptr; // sharded staging of the pair list
     void* counters_ = nullptr;   // device scalars (pair count, bounds, ...)
     void* cell_count_ = nullptr; // uint32[table_size + 1]
     void* cell_start_ = nullptr; // uint32[table_size + 1]
     void* scan_tmp_ = nullptr;
     void* sorted_slot_ = nullptr; // uint32[n_slots]
-    void* sorted_aabb_ = nullptr; // float[n_slots][8] (min xyz, cell key, max xyz, filter word)
+    void* sorted_aabb_ = nullptr; // float4[n_slots][3] sorted records
     void* body_cell_ = nullptr;   // int32[n_slots][4]
     void* large_list_ = nullptr;  // uint32[n_slots]
     bool ran_ = false;

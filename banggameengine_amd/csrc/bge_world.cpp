@@ -714,7 +714,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         }
         if (flags & BGE_TICK_BROADPHASE) {
             // buffers are sized on first use: a world that never asks for pairs does not pay for them
-            const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(4 * w->flat.n_entities, 1024);
+            const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * w->flat.n_entities, 4096);
             int rc = w->broadphase.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
             if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->broadphase.error());
             rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,

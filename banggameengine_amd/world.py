@@ -139,11 +139,8 @@ class World:
         cap = int(cap or max(1024, 8 * self.n))
         buf = np.empty((cap, 2), np.uint32)
         check(lib().bge_world_pairs(self._h, _p(buf), cap, C.byref(total)))
-        _, device_cap = self.device_array(ARRAY_PAIRS)
-        if total.value > min(cap, device_cap):
-            raise _capi.BgeError(-1, f"{total.value} pairs found but only {min(cap, device_cap)} kept "
-                                     f"(host cap {cap}, device pair_capacity {device_cap}): create the World with a "
-                                     "larger pair_capacity")
+        if total.value > cap:
+            raise _capi.BgeError(-1, f"{total.value} pairs found but the host buffer holds {cap}")
         out = buf[: total.value]
         order = np.lexsort((out[:, 1], out[:, 0]))
         return out[order].copy()

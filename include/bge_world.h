@@ -71,7 +71,7 @@ typedef struct bge_world_desc {
     uint32_t struct_size; /* sizeof(bge_world_desc) */
     int32_t device;       /* HIP device ordinal, or -1 for the current device */
     void* stream;         /* hipStream_t to enqueue on, or NULL for a private non-blocking stream */
-    uint64_t pair_capacity; /* max overlapping pairs kept per tick (0 = 4 x entities, set at topology time) */
+    uint64_t pair_capacity; /* max overlapping pairs kept per tick (0 = 8 x entities); emission is split over 64 shards */
 } bge_world_desc;
 
 typedef struct bge_world_info {
@@ -181,7 +181,8 @@ BGE_API int bge_world_download_dirty(bge_world* world, uint64_t first, uint64_t 
 /* Scene::CountDirtyTransforms (src/ecs/Scene.cpp:435-446): a device-side wave-reduced count. */
 BGE_API int bge_world_dirty_count(bge_world* world, uint64_t* out);
 /* Overlapping pairs of the last BROADPHASE tick as (a, b) entity indices, a < b, unordered list.
- * *total receives the number found on the device (may exceed cap; at most cap are copied). */
+ * *total receives the number found on the device (at most cap are copied).  Fails with BGE_ERR_INVALID when the
+ * device had to drop pairs (pair_capacity too small); pairs2 = NULL just queries the count. */
 BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, uint64_t* total);
 
 /* Multi-GPU support: compact the world matrices of all roots (entity order) into one buffer that the
