@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=None, help="flat1m | chains4 | subtree64 | chains4_shard | cube4m | flat10k")
     ap.add_argument("--entities", type=int, default=None, help="entities per GPU (default: the configuration's size)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-frame all-gather of roots")
@@ -69,13 +69,17 @@ def cpu_baseline(wl, target_seconds):
     }
 
 
-def load_traffic(workload_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), or None."""
+def load_traffic(workload_name, entities):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/traffic.json), or None.
+
+    The summary holds bytes per entity measured for each workload shape ((2 x FETCH_SIZE + WRITE_SIZE) x 1024 / entities,
+    gfx950 correction included); it is scaled to this run's entity count."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return t.get(workload_name, {}).get("hbm_bytes_per_launch")
+        per_entity = t[workload_name]["per_entity"]["total"]
+        return per_entity * entities
     except Exception:
         return None
 
@@ -248,7 +252,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(name),
+                "traffic": load_traffic(name, per_gpu),
                 "kernel_ms_per_launch": kernel_ms,
                 "timing": kernel_note,
                 "algorithmic_bytes_per_launch": alg_bytes,
