@@ -207,6 +207,28 @@ def main():
     assert kernel_ticks == args.steps, (kernel_ticks, args.steps)
     kernel_ms = kernel_total_ms / kernel_ticks
 
+    gather_check = None
+    if gather and native:
+        # Correctness of the collective (outside the timed region): one more frame, then every rank compares EVERY
+        # rank's segment of its gathered table with a checksum that rank computed from its own root matrices.
+        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags | B.TICK_GATHER_ROOTS)
+        table_host = world.download_gathered(n_gpus, rows_per_rank)
+        slot_world = world.download_world()
+        root_ids = np.flatnonzero(wl.parent == 0xFFFFFFFF)
+        mine = np.zeros((rows_per_rank, 16), np.float32)
+        mine[: len(root_ids)] = slot_world[root_ids]
+        own_ok = np.array_equal(table_host[rank].view(np.uint32), mine.view(np.uint32))
+        sums = torch.tensor([int(mine.view(np.uint32).astype(np.uint64).sum() & 0x7FFFFFFFFFFFFFFF)], dtype=torch.int64, device="cuda")
+        all_sums = [torch.zeros_like(sums) for _ in range(n_gpus)]
+        dist.all_gather(all_sums, sums)
+        seen = [int(table_host[r].view(np.uint32).astype(np.uint64).sum() & 0x7FFFFFFFFFFFFFFF) for r in range(n_gpus)]
+        ok = own_ok and all(int(all_sums[r].item()) == seen[r] for r in range(n_gpus))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_check = "ok: every rank holds every rank's root matrices bit for bit" if int(flag.item()) == 1 else "MISMATCH"
+        if gather_check == "MISMATCH":
+            print(f"[bench] rank {rank}: gathered root table does not match (own segment ok: {own_ok})", file=sys.stderr)
+
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     if dist.is_initialized():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -242,6 +264,7 @@ def main():
                 "entities_per_gpu": per_gpu,
                 "tiles": info["n_tiles"], "passes": info["n_passes"], "roots_per_gpu": n_roots,
                 "collective": collective,
+                "gather_check": gather_check,
                 "dt": FIXED_DT, "gravity": list(GRAVITY),
                 "bytes_per_update_algorithmic": wl.bytes_per_update,
             },
