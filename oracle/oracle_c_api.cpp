@@ -8,11 +8,16 @@
 #include <cstring>
 #include <vector>
 
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
 #include "broadphase_ref.h"
 #include "bullet_math.h"
 #include "bx_math.h"
 #include "ecs_ref.h"
 #include "physics_ref.h"
+#include "soa_ref.h"
 #include "synth.h"
 
 using namespace orc;
@@ -365,6 +370,51 @@ double orc_bench_tick(int shape, int posBox, int bodiesOnRootsOnly, int computeA
     }
     const auto t1 = std::chrono::steady_clock::now();
     if (updates) *updates = n;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---------------------------------------------------------------- CPU-opt baseline (dense SoA, all threads)
+// Same synthetic scene and the same arithmetic as orc_bench_tick for non-spinning mass-1 bodies (the euler write-back
+// is the identity for them after the first tick, so it is skipped).  world_out (nullable) receives the final world
+// matrices so that tests can compare it with the port.  threads <= 0: all hardware threads.
+double orc_bench_tick_soa(int shape, int posBox, int bodiesOnRootsOnly, uint64_t n, uint64_t seed, int warm, int ticks,
+                          double dt, int threads, int* threads_used, float* world_out)
+{
+#if defined(_OPENMP)
+    if (threads > 0) omp_set_num_threads(threads);
+    if (threads_used) *threads_used = omp_get_max_threads();
+#else
+    if (threads_used) *threads_used = 1;
+#endif
+    SoaScene s;
+    s.n = n;
+    s.parent.resize(n);
+    s.pos.resize(3 * n); s.euler.resize(3 * n); s.scale.resize(3 * n); s.vel.assign(3 * n, 0.0f);
+    s.dynamic.resize(n);
+    s.local.resize(16 * n); s.world.resize(16 * n);
+    std::vector<float> seed_vel(3 * n);
+    for (uint64_t i = 0; i < n; ++i) {
+        s.parent[i] = static_cast<int32_t>(synth::parent_of(shape, static_cast<int64_t>(i)));
+        synth::trs(seed, static_cast<int64_t>(i), posBox, &s.pos[3 * i], &s.euler[3 * i], &s.scale[3 * i]);
+        synth::velocity(seed, static_cast<int64_t>(i), &seed_vel[3 * i]);
+        s.dynamic[i] = (!bodiesOnRootsOnly || s.parent[i] < 0) ? 1 : 0;
+        if (s.dynamic[i]) {
+            // the body-creation tick re-poses the body from its Transform and writes rotationEuler back once
+            // (setEulerZYX -> basis -> getEulerZYX, physics_ref.h); afterwards a non-spinning body keeps it
+            const bt::Vec3 e = bt::TransformEulerFromMat(bt::MatFromQuat(
+                bt::QuatFromTransformEuler(s.euler[3 * i], s.euler[3 * i + 1], s.euler[3 * i + 2])));
+            s.euler[3 * i] = e.x; s.euler[3 * i + 1] = e.y; s.euler[3 * i + 2] = e.z;
+        }
+    }
+    s.build_levels();
+    const float fdt = static_cast<float>(dt);
+    s.tick(fdt, -9.81f); // body creation tick: starts from rest
+    s.vel = seed_vel;
+    for (int k = 0; k < warm; ++k) s.tick(fdt, -9.81f);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < ticks; ++k) s.tick(fdt, -9.81f);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (world_out) std::memcpy(world_out, s.world.data(), 64 * n);
     return std::chrono::duration<double>(t1 - t0).count();
 }
 

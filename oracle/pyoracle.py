@@ -53,6 +53,9 @@ class _Lib:
         l.orc_bench_tick.restype = C.c_double
         l.orc_bench_tick.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
                                      C.c_double, C.POINTER(C.c_uint64)]
+        l.orc_bench_tick_soa.restype = C.c_double
+        l.orc_bench_tick_soa.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double,
+                                         C.c_int, C.POINTER(C.c_int), C.c_void_p]
         l.orc_physics_update.argtypes = [C.c_void_p, C.c_double]
         l.orc_set_physics_options.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         l.orc_add_rigidbody.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint32, C.c_uint32]
@@ -149,6 +152,15 @@ def bench_tick(shape, pos_box, bodies_on_roots_only, compute_aabbs, n, seed, war
     sec = lib().orc_bench_tick(shape, pos_box, int(bodies_on_roots_only), int(compute_aabbs), n, seed, warm, ticks,
                                float(np.float32(dt)), C.byref(upd))
     return sec, upd.value
+
+
+def bench_tick_soa(shape, pos_box, bodies_on_roots_only, n, seed, warm, ticks, dt=1.0 / 120.0, threads=0, want_world=False):
+    """Time the dense-SoA all-thread CPU path ("CPU-opt").  Returns (seconds, threads_used[, world])."""
+    used = C.c_int(0)
+    world = np.empty((n, 16), np.float32) if want_world else None
+    sec = lib().orc_bench_tick_soa(shape, pos_box, int(bodies_on_roots_only), n, seed, warm, ticks, float(np.float32(dt)),
+                                   threads, C.byref(used), _vp(world))
+    return (sec, used.value, world) if want_world else (sec, used.value)
 
 
 # ----------------------------------------------------------------------------- scene session

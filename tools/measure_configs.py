@@ -81,7 +81,13 @@ def cpu_rate(wl, name, seconds=6.0):
     sec, _ = po.bench_tick(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), aabb, n, wl.seed, 0, 1)
     ticks = int(max(2, min(60, seconds / max(sec, 1e-9))))
     sec, upd = po.bench_tick(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), aabb, n, wl.seed, 1, ticks)
-    return dict(n=n, ticks=ticks, rate=upd * ticks / sec)
+    out = dict(n=n, ticks=ticks, rate=upd * ticks / sec)
+    if not aabb:
+        s2, threads = po.bench_tick_soa(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), n, wl.seed, 1, 3)
+        k = int(max(3, min(300, 3.0 / max(s2 / 3, 1e-9))))
+        s2, threads = po.bench_tick_soa(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), n, wl.seed, 2, k)
+        out.update(soa_rate=n * k / s2, soa_threads=threads)
+    return out
 
 
 def main():
@@ -94,13 +100,14 @@ def main():
         print(f"# {label}: {g['wall_rate']/1e9:.2f} G/s", file=sys.stderr, flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
-    print("| config | entities | GPU entity-updates/s | ms/tick (stream) | algorithmic B/update | achieved GB/s | frac of 8 TB/s | CPU port (1 core) | GPU/CPU |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("| config | entities | GPU entity-updates/s | ms/tick (stream) | algorithmic B/update | achieved GB/s | frac of 8 TB/s | CPU port (1 core) | GPU/CPU port | CPU SoA all cores |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         gbs = r["bytes_per_update"] * r["n"] / (r["stream_ms_per_tick"] * 1e-3) / 1e9
         print(f"| {r['label']} | {r['n']:,} | {r['wall_rate']/1e9:.2f} G | {r['stream_ms_per_tick']:.4f} | "
               f"{r['bytes_per_update']:.1f} | {gbs:,.0f} | {gbs/8000:.3f} | {r['cpu']['rate']/1e6:.2f} M "
-              f"({r['cpu']['n']:,} x {r['cpu']['ticks']}) | {r['wall_rate']/r['cpu']['rate']:,.0f}x |")
+              f"({r['cpu']['n']:,} x {r['cpu']['ticks']}) | {r['wall_rate']/r['cpu']['rate']:,.0f}x | "
+              + (f"{r['cpu']['soa_rate']/1e6:.0f} M ({r['cpu']['soa_threads']} thr)" if 'soa_rate' in r['cpu'] else "—") + " |")
     for r in rows:
         if "rate_with_d2h" in r:
             print(f"\nPCIe-inclusive, {r['label']}: tick + D2H of all world matrices {r['rate_with_d2h']/1e6:.0f} M updates/s; "
