@@ -46,6 +46,7 @@ def parse_args():
                                                               "double-buffered on a side stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-core CPU leg (a 1-GPU box's CPU share)")
     return ap.parse_args()
 
 
@@ -69,13 +70,13 @@ def cpu_baseline(wl, target_seconds):
     }
 
 
-def cpu_allcore(wl, target_seconds):
+def cpu_allcore(wl, target_seconds, threads):
     """BASELINE.md §3 "CPU-opt": the same arithmetic on dense SoA, depth-sorted, all host threads (oracle/soa_ref.h)."""
     from oracle import pyoracle as po
     roots_only = int(wl.bodies_on_roots_only)
-    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, wl.n, wl.seed, 1, 2)
+    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, wl.n, wl.seed, 1, 2, threads=threads)
     ticks = int(max(3, min(400, target_seconds / max(sec / 2, 1e-9))))
-    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, wl.n, wl.seed, 2, ticks)
+    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, wl.n, wl.seed, 2, ticks, threads=threads)
     return {
         "value": wl.n * ticks / sec,
         "unit": "entity-updates/s",
@@ -300,7 +301,7 @@ def main():
         }
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
-            out["cpu_allcore"] = cpu_allcore(wl, args.cpu_seconds / 2)
+            out["cpu_allcore"] = cpu_allcore(wl, args.cpu_seconds / 2, args.cpu_threads)
         print(json.dumps(out), flush=True)
 
     if gather and native:
