@@ -1,0 +1,151 @@
+// tests/cpp/test_scene_json.cpp — ingest of the reference's scene format (bge/scene_json.hpp).
+//
+//   test_scene_json <reference_demo_scene.json> [--gpu]
+// CPU part: the same text is loaded into bge::Scene (product store) and orc::RefScene (oracle store) and every
+// component must agree field for field; a richer synthetic scene covers nested children, "parent" by id and by name,
+// rotationEulerDeg, capsules, string layers, partial vectors.  With --gpu the loaded scenes are ticked through the GPU
+// adapter and the oracle and compared bit for bit.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "../../banggameengine_amd/host/bge/gpu_systems.hpp"
+#include "../../banggameengine_amd/host/bge/scene.hpp"
+#include "../../banggameengine_amd/host/bge/scene_json.hpp"
+#include "../../oracle/physics_ref.h"
+
+static int g_failures = 0;
+#define CHECK(cond, ...)                                     \
+    do {                                                     \
+        if (!(cond)) {                                       \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);                        \
+            std::printf("\n");                               \
+            ++g_failures;                                    \
+        }                                                    \
+    } while (0)
+
+static const char* kSynthetic = R"JSON({
+  "resources": {"meshes": {"crate": {"obj": "models/crate.obj"}}},
+  "entities": [
+    {"id": "car", "name": "Car", "transform": {"position": [10, 2.5, -3], "rotationEulerDeg": [0, 90, 0], "scale": [2, 1, 4]},
+     "collider": {"shape": "Box", "size": [1.0, 0.5, 2.0]},
+     "rigidBody": {"type": "Dynamic", "mass": 1200.5, "layer": "0x2", "mask": 7, "friction": 0.9},
+     "children": [
+        {"name": "WheelFL", "transform": {"position": [-1, -0.5, 1.5], "rotationEuler": [0.1, 0.2, 0.3]}},
+        {"name": "WheelFR", "transform": {"position": [1, -0.5, 1.5], "scale": [1, 1]},
+         "children": [ {"id": "hubcap", "transform": {"position": [0.1, 0, 0], "rotationEulerDeg": [45, 0, 0], "rotationEuler": [9, 9, 9]}} ]},
+        {"name": "Antenna", "parent": "roof", "transform": {"position": [0, 1, 0]}}
+     ]},
+    {"id": "roof", "transform": {"position": [0, 1.2, 0]}, "parent": "Car"},
+    {"name": "Pole", "transform": {"position": [3, 0, 3]}, "collider": {"shape": "CAPSULE", "radius": 0.25, "height": 3.0},
+     "rigidBody": {"type": "kinematic", "mass": 55}},
+    {"transform": {"position": [0, -1, 0]}, "collider": {"shape": "sphere"}, "rigidBody": {}},
+    {"name": "Orphan", "parent": "does-not-exist", "transform": {}},
+    42
+  ]
+})JSON";
+
+template <class A, class B> static void CompareStores(A& ref, B& gpu, const char* what, bool world)
+{
+    CHECK(ref.GetTransformCount() == gpu.GetTransformCount(), "%s: transform counts %zu vs %zu", what, ref.GetTransformCount(),
+          gpu.GetTransformCount());
+    for (auto& kv : ref.GetTransforms()) {
+        const auto* g = gpu.GetTransform(kv.first);
+        CHECK(g != nullptr, "%s: entity %u missing", what, kv.first);
+        if (!g) continue;
+        CHECK(std::memcmp(&kv.second.position, &g->position, 36) == 0, "%s: TRS of %u", what, kv.first);
+        CHECK(kv.second.dirty == g->dirty, "%s: dirty of %u", what, kv.first);
+        CHECK(ref.GetParent(kv.first) == gpu.GetParent(kv.first), "%s: parent of %u: %u vs %u", what, kv.first,
+              ref.GetParent(kv.first), gpu.GetParent(kv.first));
+        if (world) CHECK(std::memcmp(kv.second.world, g->world, 64) == 0, "%s: world of %u", what, kv.first);
+    }
+    for (auto& kv : ref.GetRigidBodies()) {
+        auto* g = gpu.GetRigidBody(kv.first);
+        CHECK(g != nullptr, "%s: rigid body of %u missing", what, kv.first);
+        if (!g) continue;
+        CHECK(static_cast<int>(kv.second.type) == static_cast<int>(g->type) && kv.second.mass == g->mass &&
+                  kv.second.friction == g->friction && kv.second.layer == g->layer && kv.second.mask == g->mask,
+              "%s: rigid body fields of %u", what, kv.first);
+    }
+    for (auto& kv : ref.GetColliders()) {
+        auto* g = gpu.GetCollider(kv.first);
+        CHECK(g != nullptr, "%s: collider of %u missing", what, kv.first);
+        if (!g) continue;
+        CHECK(static_cast<int>(kv.second.shape) == static_cast<int>(g->shape) && std::memcmp(&kv.second.size, &g->size, 12) == 0,
+              "%s: collider fields of %u", what, kv.first);
+    }
+}
+
+static void RunCase(const std::string& text, const char* what, bool gpu)
+{
+    orc::RefScene ref;
+    bge::Scene scene;
+    std::string err;
+    std::unordered_map<std::string, uint32_t> keys_ref, keys_gpu;
+    CHECK(bge::LoadSceneFromJsonText(text, ref, &err, &keys_ref), "%s: oracle store: %s", what, err.c_str());
+    CHECK(bge::LoadSceneFromJsonText(text, scene, &err, &keys_gpu), "%s: product store: %s", what, err.c_str());
+    CHECK(keys_ref == keys_gpu, "%s: lookups differ", what);
+    CompareStores(ref, scene, what, false);
+    std::printf("%s: %zu entities with a Transform, %zu rigid bodies\n", what, scene.GetTransformCount(), scene.GetRigidBodies().size());
+    if (!gpu) return;
+    orc::RefPhysicsSystem refPhysics;
+    bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
+    const double dt = static_cast<double>(0.0083333333f);
+    for (int k = 0; k < 5; ++k) {
+        refPhysics.Update(ref, dt);
+        gpuPhysics.Update(scene, dt);
+        orc::RefTransformSystemUpdate(ref);
+        bge::GpuTransformSystem<bge::Scene>::Update(scene);
+        CompareStores(ref, scene, what, true);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) {
+        std::printf("usage: test_scene_json <reference_demo_scene.json> [--gpu]\n");
+        return 2;
+    }
+    const bool gpu = argc > 2 && std::strcmp(argv[2], "--gpu") == 0;
+    if (gpu) {
+        bge::GpuSceneMirror<bge::Scene> probe;
+        if (!probe.ok()) {
+            std::printf("no usable GPU: %s\n", bge_last_error());
+            return 77;
+        }
+    }
+    std::ifstream f(argv[1]);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    CHECK(!ss.str().empty(), "cannot read %s", argv[1]);
+    RunCase(ss.str(), "demo.json", gpu);
+
+    // values of the synthetic scene, checked explicitly once (the two stores were already compared)
+    {
+        bge::Scene s;
+        std::unordered_map<std::string, uint32_t> keys;
+        std::string err;
+        CHECK(bge::LoadSceneFromJsonText(kSynthetic, s, &err, &keys), "synthetic: %s", err.c_str());
+        const uint32_t car = keys["car"], roof = keys["roof"], hub = keys["hubcap"], pole = keys["Pole"];
+        CHECK(keys["Car"] == car && s.GetParent(roof) == car && s.GetParent(keys["Antenna"]) == roof, "parent links by name / id");
+        CHECK(s.GetParent(keys["WheelFL"]) == car && s.GetParent(hub) == keys["WheelFR"], "nested children");
+        CHECK(s.GetParent(keys["Orphan"]) == 0, "unknown parent is skipped");
+        const float half_turn = 90.0f * 3.1415926535897932384626433832795f / 180.0f;
+        CHECK(s.GetTransform(car)->rotationEuler.y == half_turn && s.GetTransform(car)->rotationEuler.x == 0.0f, "rotationEulerDeg");
+        CHECK(s.GetTransform(hub)->rotationEuler.x == 45.0f * 3.1415926535897932384626433832795f / 180.0f, "degrees win over radians");
+        CHECK(s.GetTransform(keys["WheelFR"])->scale.z == 1.0f && s.GetTransform(keys["WheelFR"])->scale.x == 1.0f, "partial vectors");
+        CHECK(s.GetRigidBody(car)->mass == 1200.5f && s.GetRigidBody(car)->layer == 2u && s.GetRigidBody(car)->mask == 7u, "rigid body fields");
+        CHECK(static_cast<int>(s.GetCollider(pole)->shape) == 1 && s.GetCollider(pole)->size.x == 0.25f && s.GetCollider(pole)->size.y == 1.5f,
+              "capsule radius / height");
+        CHECK(s.GetRigidBody(pole)->mass == 0.0f && static_cast<int>(s.GetRigidBody(pole)->type) == 2, "kinematic bodies carry no mass");
+        CHECK(s.GetTransformCount() == 9, "entity count %zu", s.GetTransformCount());
+        std::string bad;
+        CHECK(!bge::LoadSceneFromJsonText("{\"entities\": [", s, &bad) && !bad.empty(), "malformed JSON must be reported");
+        CHECK(!bge::LoadSceneFromJsonText("{\"entities\": 3}", s, &bad), "'entities' must be an array");
+    }
+    RunCase(kSynthetic, "synthetic", gpu);
+    if (g_failures == 0) std::printf("scene json: all checks passed%s\n", gpu ? " (with GPU ticks)" : "");
+    return g_failures ? 1 : 0;
+}
