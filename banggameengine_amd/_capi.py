@@ -51,6 +51,7 @@ SYMBOLS = {
     "bge_world_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "bge_world_download_world": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_download_pose": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
+    "bge_world_download_normal": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_download_bodies": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "bge_world_download_dirty": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_dirty_count": (C.c_int, [_vp, C.POINTER(_u64)]),

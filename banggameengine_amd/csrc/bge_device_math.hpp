@@ -131,6 +131,45 @@ __device__ __forceinline__ void bx_mtx_mul(float (&o)[16], const float (&a)[16],
     }
 }
 
+// normalMtx = transpose(inverse(world)) as Renderer::BeginFrame computes it per mesh entity
+// (src/render/Renderer.cpp:633-636: bx::mtxInverse then bx::mtxTranspose).  bx::mtxInverse is the adjugate over the
+// determinant with the cofactors expanded along the first row of each minor; the transpose is folded into the stores.
+__device__ __forceinline__ void bx_normal_matrix(float (&r)[16], const float (&a)[16])
+{
+    const float xx = a[0], xy = a[1], xz = a[2], xw = a[3];
+    const float yx = a[4], yy = a[5], yz = a[6], yw = a[7];
+    const float zx = a[8], zy = a[9], zz = a[10], zw = a[11];
+    const float wx = a[12], wy = a[13], wz = a[14], ww = a[15];
+
+    float det = 0.0f;
+    det += xx * (yy * (zz * ww - zw * wz) - yz * (zy * ww - zw * wy) + yw * (zy * wz - zz * wy));
+    det -= xy * (yx * (zz * ww - zw * wz) - yz * (zx * ww - zw * wx) + yw * (zx * wz - zz * wx));
+    det += xz * (yx * (zy * ww - zw * wy) - yy * (zx * ww - zw * wx) + yw * (zx * wy - zy * wx));
+    det -= xw * (yx * (zy * wz - zz * wy) - yy * (zx * wz - zz * wx) + yz * (zx * wy - zy * wx));
+    const float invDet = 1.0f / det;
+
+    // inverse element [i][j] lands at r[4*j + i]
+    r[0] = +(yy * (zz * ww - wz * zw) - yz * (zy * ww - wy * zw) + yw * (zy * wz - wy * zz)) * invDet;
+    r[4] = -(xy * (zz * ww - wz * zw) - xz * (zy * ww - wy * zw) + xw * (zy * wz - wy * zz)) * invDet;
+    r[8] = +(xy * (yz * ww - wz * yw) - xz * (yy * ww - wy * yw) + xw * (yy * wz - wy * yz)) * invDet;
+    r[12] = -(xy * (yz * zw - zz * yw) - xz * (yy * zw - zy * yw) + xw * (yy * zz - zy * yz)) * invDet;
+
+    r[1] = -(yx * (zz * ww - wz * zw) - yz * (zx * ww - wx * zw) + yw * (zx * wz - wx * zz)) * invDet;
+    r[5] = +(xx * (zz * ww - wz * zw) - xz * (zx * ww - wx * zw) + xw * (zx * wz - wx * zz)) * invDet;
+    r[9] = -(xx * (yz * ww - wz * yw) - xz * (yx * ww - wx * yw) + xw * (yx * wz - wx * yz)) * invDet;
+    r[13] = +(xx * (yz * zw - zz * yw) - xz * (yx * zw - zx * yw) + xw * (yx * zz - zx * yz)) * invDet;
+
+    r[2] = +(yx * (zy * ww - wy * zw) - yy * (zx * ww - wx * zw) + yw * (zx * wy - wx * zy)) * invDet;
+    r[6] = -(xx * (zy * ww - wy * zw) - xy * (zx * ww - wx * zw) + xw * (zx * wy - wx * zy)) * invDet;
+    r[10] = +(xx * (yy * ww - wy * yw) - xy * (yx * ww - wx * yw) + xw * (yx * wy - wx * yy)) * invDet;
+    r[14] = -(xx * (yy * zw - zy * yw) - xy * (yx * zw - zx * yw) + xw * (yx * zy - zx * yy)) * invDet;
+
+    r[3] = -(yx * (zy * wz - wy * zz) - yy * (zx * wz - wx * zz) + yz * (zx * wy - wx * zy)) * invDet;
+    r[7] = +(xx * (zy * wz - wy * zz) - xy * (zx * wz - wx * zz) + xz * (zx * wy - wx * zy)) * invDet;
+    r[11] = -(xx * (yy * wz - wy * yz) - xy * (yx * wz - wx * yz) + xz * (yx * wy - wx * yy)) * invDet;
+    r[15] = +(xx * (yy * zz - zy * yz) - xy * (yx * zz - zx * yz) + xz * (yx * zy - zx * yy)) * invDet;
+}
+
 // ------------------------------------------------------------------ Bullet pieces
 constexpr float kBtEpsilon = 1.1920928955078125e-07f;
 constexpr float kBtPi = 3.1415926535897932384626433832795029f;

@@ -9,6 +9,7 @@
 //          staged in LDS (16 KiB per workgroup).  Wave-local tiles (every subtree inside one 64-slot
 //          group) run without any workgroup barrier; block tiles use one barrier per level
 //   AABB   the per-body AABB Bullet feeds its broadphase (current pose U predicted pose, +0.02)
+//   NORMAL the render feed's per-entity normal matrix transpose(inverse(world)) (src/render/Renderer.cpp:633-636)
 //
 // Memory plan (all streams indexed by slot, 256 consecutive slots per workgroup):
 //   reads   flags 4 B (body type, dirty bits, level, in-tile parent index, mass class), pos/euler/scale 12 B
@@ -83,9 +84,10 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool PHYS, bool XFORM, bool AABB>
+template <bool PHYS, bool XFORM, bool AABB, bool NORMAL>
 // 8 waves per SIMD (<= 64 VGPRs): the kernel waits on memory and, in block tiles, on barriers; occupancy hides both
-__global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
+// (the NORMAL variant carries a 4x4 inverse: it gets 128 VGPRs instead of spilling)
+__global__ void __launch_bounds__(kTile, NORMAL ? 4 : 8) k_tick(WorldView w, TickParams p)
 {
     __shared__ float4 lds[kTile * 4];
 
@@ -252,6 +254,26 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
                 const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
                 if ((valid_mask >> nl) & 1ull) dst[n * 4u + r] = lds[wbase * 4u + qi];
             }
+            if (NORMAL) {
+                // render feed: normalMtx = transpose(inverse(world)) (Renderer.cpp:633-636), same LDS round trip
+                float m[16], nm[16];
+                if (valid) lds_get(lds, tid, m);
+                wave_lds_sync();
+                if (valid) {
+                    bx_normal_matrix(nm, m);
+                    lds_put(lds, tid, nm);
+                }
+                wave_lds_sync();
+                float4* ndst = reinterpret_cast<float4*>(w.normal) + 4ull * kTile * tile;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t qi = lane + 64u * k;
+                    const uint32_t nl = qi >> 2;
+                    const uint32_t n = wbase + nl;
+                    const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
+                    if ((valid_mask >> nl) & 1ull) ndst[n * 4u + r] = lds[wbase * 4u + qi];
+                }
+            }
         } else {
             // block tile (a subtree of 65..256 nodes, or the breadth-first prefix of a larger one): levels are
             // separated by workgroup barriers, parents staged in LDS
@@ -288,6 +310,24 @@ __global__ void __launch_bounds__(kTile, 8) k_tick(WorldView w, TickParams p)
                 const uint32_t n = qi >> 2;
                 const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
                 if (n < count) dst[n * 4u + r] = lds[qi];
+            }
+            if (NORMAL) {
+                float m[16], nm[16];
+                if (valid) lds_get(lds, tid, m);
+                __syncthreads();
+                if (valid) {
+                    bx_normal_matrix(nm, m);
+                    lds_put(lds, tid, nm);
+                }
+                __syncthreads();
+                float4* ndst = reinterpret_cast<float4*>(w.normal) + 4ull * kTile * tile;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t qi = tid + kTile * k;
+                    const uint32_t n = qi >> 2;
+                    const uint32_t r = (qi & 3u) ^ ((n >> 2) & 3u);
+                    if (n < count) ndst[n * 4u + r] = lds[qi];
+                }
             }
         }
         f &= ~kTDirty; // transform->dirty = false
@@ -442,13 +482,19 @@ inline dim3 grid_for(uint64_t n, uint32_t block) { return dim3(static_cast<uint3
 hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams& p, uint32_t n_tiles, uint32_t flags)
 {
     if (n_tiles == 0) return hipSuccess;
-    const bool phys = (flags & 1u) != 0, xform = (flags & 2u) != 0, aabb = (flags & 4u) != 0;
+    const bool phys = (flags & 1u) != 0, xform = (flags & 2u) != 0, aabb = (flags & 4u) != 0, normal = (flags & 16u) != 0;
     const dim3 grid(n_tiles), block(kTile);
-    if (phys && xform && aabb) hipLaunchKernelGGL((k_tick<true, true, true>), grid, block, 0, stream, w, p);
-    else if (phys && xform) hipLaunchKernelGGL((k_tick<true, true, false>), grid, block, 0, stream, w, p);
-    else if (phys && aabb) hipLaunchKernelGGL((k_tick<true, false, true>), grid, block, 0, stream, w, p);
-    else if (phys) hipLaunchKernelGGL((k_tick<true, false, false>), grid, block, 0, stream, w, p);
-    else if (xform) hipLaunchKernelGGL((k_tick<false, true, false>), grid, block, 0, stream, w, p);
+#define BGE_LAUNCH(P, X, A, N) hipLaunchKernelGGL((k_tick<P, X, A, N>), grid, block, 0, stream, w, p)
+    if (normal && xform) {
+        if (phys && aabb) BGE_LAUNCH(true, true, true, true);
+        else if (phys) BGE_LAUNCH(true, true, false, true);
+        else BGE_LAUNCH(false, true, false, true);
+    } else if (phys && xform && aabb) BGE_LAUNCH(true, true, true, false);
+    else if (phys && xform) BGE_LAUNCH(true, true, false, false);
+    else if (phys && aabb) BGE_LAUNCH(true, false, true, false);
+    else if (phys) BGE_LAUNCH(true, false, false, false);
+    else if (xform) BGE_LAUNCH(false, true, false, false);
+#undef BGE_LAUNCH
     return hipGetLastError();
 }
 

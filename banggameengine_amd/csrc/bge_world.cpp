@@ -118,7 +118,7 @@ struct bge_world {
     // device arrays
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
-    DevBuf root_worlds, counter, stage, stage2, mass_palette;
+    DevBuf root_worlds, counter, stage, stage2, mass_palette, normal;
     std::vector<float> palette_inv_mass;            // class -> inv_mass (class 0 = 0: Static / Kinematic)
     std::unordered_map<uint32_t, uint32_t> palette_class; // inv_mass bits -> class
     bge::Broadphase broadphase;
@@ -152,12 +152,13 @@ struct bge_world {
         view.aabb = aabb.as<float>();
         view.mass_palette = mass_palette.as<float2>();
         view.root_index = root_index.as<uint32_t>();
+        view.normal = normal.as<float>();
     }
     void release_all()
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette}) {
+                          &stage2, &mass_palette, &normal}) {
             b->release();
         }
         broadphase.release();
@@ -660,7 +661,16 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         return fail(BGE_ERR_INVALID, "BGE_TICK_BROADPHASE needs BGE_TICK_PHYSICS (the AABBs come from the physics step)");
     }
     if ((flags & BGE_TICK_PHYSICS) && !gravity) return fail(BGE_ERR_INVALID, "gravity is NULL");
+    if ((flags & BGE_TICK_NORMAL_MATRICES) && !(flags & BGE_TICK_TRANSFORMS)) {
+        return fail(BGE_ERR_INVALID, "BGE_TICK_NORMAL_MATRICES needs BGE_TICK_TRANSFORMS (they are derived from the new world matrices)");
+    }
     DeviceGuard guard(w->device);
+    if ((flags & BGE_TICK_NORMAL_MATRICES) && w->normal.bytes < std::max<uint64_t>(w->flat.n_slots, bge::kTile) * 64) {
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        HIP_TRY(w->normal.ensure(std::max<uint64_t>(w->flat.n_slots, bge::kTile) * 64));
+        HIP_TRY(hipMemsetAsync(w->normal.p, 0, w->normal.bytes, w->stream));
+        w->rebuild_view();
+    }
     const bool phys = (flags & BGE_TICK_PHYSICS) != 0;
     const bool xform = (flags & BGE_TICK_TRANSFORMS) != 0;
     if (w->profiling) {
@@ -673,7 +683,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         }
     }
     for (uint32_t t = 0; t < ticks; ++t) {
-        if (!phys && !w->maybe_dirty) continue; // TransformSystem::Update with nothing dirty: a no-op scan
+        if (!phys && !w->maybe_dirty && !(flags & BGE_TICK_NORMAL_MATRICES)) continue; // TransformSystem::Update with nothing dirty: a no-op scan
         bge::TickParams p{};
         p.dt = dt;
         p.gx = gravity ? gravity[0] : 0.0f;
@@ -811,6 +821,16 @@ int bge_world_download_pose_indexed(bge_world* w, uint64_t count, const uint32_t
     return BGE_OK;
 }
 
+int bge_world_download_normal(bge_world* w, uint64_t first, uint64_t count, float* out16)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (!out16) return fail(BGE_ERR_INVALID, "out16 is NULL");
+    if (!w->normal.p) return fail(BGE_ERR_STATE, "no tick with BGE_TICK_NORMAL_MATRICES has run");
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    return download_rows(w, first, count, 16, w->normal.p, out16);
+}
+
 int bge_world_download_pose(bge_world* w, uint64_t first, uint64_t count, float* pos3, float* euler3)
 {
     if (int rc = check_range(w, first, count)) return rc;
@@ -906,6 +926,7 @@ int bge_world_device_array(bge_world* w, int which, void** device_ptr, uint64_t*
     case BGE_ARRAY_SLOT_OF_ENTITY: p = w->slot_of_entity.p; n = w->flat.n_entities; break;
     case BGE_ARRAY_POSITION: p = w->pos.p; n = w->flat.n_slots; break;
     case BGE_ARRAY_PAIRS: p = w->broadphase.pairs_device(); n = w->broadphase.capacity(); break;
+    case BGE_ARRAY_NORMAL: p = w->normal.p; n = w->normal.p ? w->flat.n_slots : 0; break;
     default: return fail(BGE_ERR_INVALID, "unknown device array %d", which);
     }
     *device_ptr = p;

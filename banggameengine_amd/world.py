@@ -11,7 +11,7 @@ from ._capi import WorldDesc, WorldInfo, check, lib
 NO_PARENT = 0xFFFFFFFF
 BODY_STATIC, BODY_DYNAMIC, BODY_KINEMATIC, BODY_NONE = 0, 1, 2, 255
 SHAPE_BOX, SHAPE_CAPSULE = 0, 1
-TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL, TICK_GATHER_ROOTS = 1, 2, 4, 3, 8
+TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL, TICK_GATHER_ROOTS, TICK_NORMAL_MATRICES = 1, 2, 4, 3, 8, 16
 ARRAY_WORLD, ARRAY_ROOT_WORLDS, ARRAY_SLOT_OF_ENTITY, ARRAY_POSITION, ARRAY_PAIRS = 0, 1, 2, 3, 4
 
 # fixed step and gravity of the reference (assets/config/physics.json:2-3)
@@ -108,6 +108,12 @@ class World:
         count = self.n - first if count is None else count
         out = np.empty((count, 16), np.float32)
         check(lib().bge_world_download_world(self._h, first, count, _p(out)))
+        return out
+
+    def download_normal(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((count, 16), np.float32)
+        check(lib().bge_world_download_normal(self._h, first, count, _p(out)))
         return out
 
     def download_pose(self, first=0, count=None):

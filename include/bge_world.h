@@ -54,7 +54,9 @@ enum bge_tick_flags {
     BGE_TICK_TRANSFORMS = 2u, /* TransformSystem::Update (src/ecs/TransformSystem.cpp:40-46) */
     BGE_TICK_BROADPHASE = 4u, /* AABB update + overlapping pairs (Bullet updateAabbs/calculateOverlappingPairs) */
     BGE_TICK_ALL = 3u,        /* Application::Update's physics + transform steps (src/core/Application.cpp:256,284) */
-    BGE_TICK_GATHER_ROOTS = 8u /* after the tick: bge_world_gather_roots (needs bge_world_comm_init) */
+    BGE_TICK_GATHER_ROOTS = 8u, /* after the tick: bge_world_gather_roots (needs bge_world_comm_init) */
+    BGE_TICK_NORMAL_MATRICES = 16u /* with TRANSFORMS: also write transpose(inverse(world)) per entity, the normalMtx
+                                      Renderer::BeginFrame computes on the CPU per mesh (src/render/Renderer.cpp:633-636) */
 };
 
 enum bge_device_array {
@@ -62,7 +64,8 @@ enum bge_device_array {
     BGE_ARRAY_ROOT_WORLDS = 1,    /* float[n_roots][16], filled by bge_world_pack_roots */
     BGE_ARRAY_SLOT_OF_ENTITY = 2, /* uint32[n_entities], BGE_NO_PARENT where the entity has no Transform */
     BGE_ARRAY_POSITION = 3,       /* float[n_slots][3] */
-    BGE_ARRAY_PAIRS = 4           /* uint32[pair_capacity][2], entity indices */
+    BGE_ARRAY_PAIRS = 4,          /* uint32[pair_capacity][2], entity indices */
+    BGE_ARRAY_NORMAL = 5          /* float[n_slots][16] normal matrices, slot order (after a NORMAL_MATRICES tick) */
 };
 
 typedef struct bge_world bge_world;
@@ -172,6 +175,8 @@ BGE_API int bge_world_profile_read(bge_world* world, double* tick_kernel_ms, uin
 /* Results.  `Transform::world` after TransformSystem::Update; position/rotationEuler after PhysicsSystem::Update. */
 BGE_API int bge_world_download_world(bge_world* world, uint64_t first, uint64_t count, float* out16);
 BGE_API int bge_world_download_pose(bge_world* world, uint64_t first, uint64_t count, float* pos3, float* euler3);
+/* normalMtx per entity of the last BGE_TICK_NORMAL_MATRICES tick (16 floats, bx::mtxTranspose(bx::mtxInverse(world))). */
+BGE_API int bge_world_download_normal(bge_world* world, uint64_t first, uint64_t count, float* out16);
 BGE_API int bge_world_download_world_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, float* out16);
 BGE_API int bge_world_download_pose_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, float* pos3,
                                             float* euler3);

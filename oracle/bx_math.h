@@ -145,5 +145,58 @@ inline void mtxMul(float* out, const float* a, const float* b)
     vec4MulMtx(out + 12, a + 12, b);
 }
 
+// bx::mtxInverse (bx/src/math.cpp): adjugate / determinant, cofactors expanded along the first row of each minor.
+// Used by the reference for the per-mesh normal matrix (src/render/Renderer.cpp:413-416, 633-636).
+// Restated from bx's published source; the committed binaries were not decoded for this one — unpinned.
+inline void mtxInverse(float* r, const float* a)
+{
+    const float xx = a[0], xy = a[1], xz = a[2], xw = a[3];
+    const float yx = a[4], yy = a[5], yz = a[6], yw = a[7];
+    const float zx = a[8], zy = a[9], zz = a[10], zw = a[11];
+    const float wx = a[12], wy = a[13], wz = a[14], ww = a[15];
+
+    float det = 0.0f;
+    det += xx * (yy * (zz * ww - zw * wz) - yz * (zy * ww - zw * wy) + yw * (zy * wz - zz * wy));
+    det -= xy * (yx * (zz * ww - zw * wz) - yz * (zx * ww - zw * wx) + yw * (zx * wz - zz * wx));
+    det += xz * (yx * (zy * ww - zw * wy) - yy * (zx * ww - zw * wx) + yw * (zx * wy - zy * wx));
+    det -= xw * (yx * (zy * wz - zz * wy) - yy * (zx * wz - zz * wx) + yz * (zx * wy - zy * wx));
+    const float invDet = 1.0f / det;
+
+    r[0] = +(yy * (zz * ww - wz * zw) - yz * (zy * ww - wy * zw) + yw * (zy * wz - wy * zz)) * invDet;
+    r[1] = -(xy * (zz * ww - wz * zw) - xz * (zy * ww - wy * zw) + xw * (zy * wz - wy * zz)) * invDet;
+    r[2] = +(xy * (yz * ww - wz * yw) - xz * (yy * ww - wy * yw) + xw * (yy * wz - wy * yz)) * invDet;
+    r[3] = -(xy * (yz * zw - zz * yw) - xz * (yy * zw - zy * yw) + xw * (yy * zz - zy * yz)) * invDet;
+
+    r[4] = -(yx * (zz * ww - wz * zw) - yz * (zx * ww - wx * zw) + yw * (zx * wz - wx * zz)) * invDet;
+    r[5] = +(xx * (zz * ww - wz * zw) - xz * (zx * ww - wx * zw) + xw * (zx * wz - wx * zz)) * invDet;
+    r[6] = -(xx * (yz * ww - wz * yw) - xz * (yx * ww - wx * yw) + xw * (yx * wz - wx * yz)) * invDet;
+    r[7] = +(xx * (yz * zw - zz * yw) - xz * (yx * zw - zx * yw) + xw * (yx * zz - zx * yz)) * invDet;
+
+    r[8] = +(yx * (zy * ww - wy * zw) - yy * (zx * ww - wx * zw) + yw * (zx * wy - wx * zy)) * invDet;
+    r[9] = -(xx * (zy * ww - wy * zw) - xy * (zx * ww - wx * zw) + xw * (zx * wy - wx * zy)) * invDet;
+    r[10] = +(xx * (yy * ww - wy * yw) - xy * (yx * ww - wx * yw) + xw * (yx * wy - wx * yy)) * invDet;
+    r[11] = -(xx * (yy * zw - zy * yw) - xy * (yx * zw - zx * yw) + xw * (yx * zy - zx * yy)) * invDet;
+
+    r[12] = -(yx * (zy * wz - wy * zz) - yy * (zx * wz - wx * zz) + yz * (zx * wy - wx * zy)) * invDet;
+    r[13] = +(xx * (zy * wz - wy * zz) - xy * (zx * wz - wx * zz) + xz * (zx * wy - wx * zy)) * invDet;
+    r[14] = -(xx * (yy * wz - wy * yz) - xy * (yx * wz - wx * yz) + xz * (yx * wy - wx * yy)) * invDet;
+    r[15] = +(xx * (yy * zz - zy * yz) - xy * (yx * zz - zx * yz) + xz * (yx * zy - zx * yy)) * invDet;
+}
+
+// bx::mtxTranspose
+inline void mtxTranspose(float* r, const float* a)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) r[4 * i + j] = a[4 * j + i];
+}
+
+// normalMtx of Renderer::BeginFrame: transpose(inverse(world))
+inline void normalMatrix(float* r, const float* world)
+{
+    float inv[16];
+    mtxInverse(inv, world);
+    mtxTranspose(r, inv);
+}
+
 } // namespace bxm
 } // namespace orc

@@ -45,6 +45,11 @@ void orc_bx_eval(int fn, const float* in, float* out, uint64_t n)
         out[i] = fn == 0 ? bxm::cos_(in[i]) : fn == 1 ? bxm::sin_(in[i]) : bxm::floor_(in[i]);
     }
 }
+// normal matrices of n world matrices (src/render/Renderer.cpp:633-636)
+void orc_normal_matrices(const float* world16, float* out16, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) bxm::normalMatrix(out16 + 16 * i, world16 + 16 * i);
+}
 void orc_set_libm(int which) { bt::g_libm = which; }
 // fn: 0 sin, 1 cos, 2 asin (clamped), 3 atan2(a,b)
 void orc_libm_eval(int fn, const float* a, const float* b, float* out, uint64_t n)

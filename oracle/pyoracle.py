@@ -102,6 +102,14 @@ def bx_eval(fn, x):
     return out
 
 
+def normal_matrices(world):
+    """transpose(inverse(world)) per matrix, bx::mtxInverse + bx::mtxTranspose restated."""
+    w = _c(world, np.float32).reshape(-1, 16)
+    out = np.empty_like(w)
+    lib().orc_normal_matrices(_vp(w), _vp(out), C.c_uint64(len(w)))
+    return out
+
+
 def set_libm(which: int):
     lib().orc_set_libm(C.c_int(which))
 

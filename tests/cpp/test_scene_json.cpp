@@ -1,6 +1,6 @@
 // tests/cpp/test_scene_json.cpp — ingest of the reference's scene format (bge/scene_json.hpp).
 //
-//   test_scene_json <reference_demo_scene.json> [--gpu]
+//   test_scene_json <demo_scene_reference_format.json> [--gpu]
 // CPU part: the same text is loaded into bge::Scene (product store) and orc::RefScene (oracle store) and every
 // component must agree field for field; a richer synthetic scene covers nested children, "parent" by id and by name,
 // rotationEulerDeg, capsules, string layers, partial vectors.  With --gpu the loaded scenes are ticked through the GPU
@@ -105,7 +105,7 @@ static void RunCase(const std::string& text, const char* what, bool gpu)
 int main(int argc, char** argv)
 {
     if (argc < 2) {
-        std::printf("usage: test_scene_json <reference_demo_scene.json> [--gpu]\n");
+        std::printf("usage: test_scene_json <demo_scene_reference_format.json> [--gpu]\n");
         return 2;
     }
     const bool gpu = argc > 2 && std::strcmp(argv[2], "--gpu") == 0;

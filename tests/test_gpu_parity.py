@@ -390,3 +390,26 @@ def test_retopology_keeps_state_and_marks_reparented_subtrees_dirty():
         got_vel = w.download_bodies()["linvel"]
         assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world after re-topology")
         assert_bits_equal(got_vel, ref.bulk_bodies()["linvel"], "velocities after re-topology")
+
+
+def test_normal_matrices_match_oracle_bitwise():
+    """the render feed's normalMtx = transpose(inverse(world)) fused into the tick."""
+    for name, n in (("flat10k", 5000), ("chains4", 8000), ("subtree64", 64 * 90)):
+        wl = synth.config(name, n=n)
+        ref = run_oracle(build_oracle(wl), wl, 4)
+        with B.World() as w:
+            w.load(wl)
+            with pytest.raises(B.BgeError):
+                w.download_normal()                                  # nothing computed yet
+            run_world(w, wl, 4, flags=B.TICK_ALL | B.TICK_NORMAL_MATRICES)
+            world = w.download_world()
+            normal = w.download_normal()
+            with pytest.raises(B.BgeError):
+                w.tick(flags=B.TICK_PHYSICS | B.TICK_NORMAL_MATRICES)  # needs the transform pass
+        want_world, _ = ref.bulk_world()
+        assert_bits_equal(world, want_world, f"{name} world")
+        assert_bits_equal(normal, po.normal_matrices(want_world), f"{name} normal matrix")
+        # and it IS the inverse transpose: N^T * W = I within float32 conditioning
+        inv = normal.reshape(-1, 4, 4).transpose(0, 2, 1).astype(np.float64)
+        err = np.abs(inv @ world.reshape(-1, 4, 4).astype(np.float64) - np.eye(4)).max()
+        assert err < 1e-3

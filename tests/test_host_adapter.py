@@ -33,7 +33,7 @@ def test_adapter_matches_oracle_through_scripted_scene_edits():
 def test_scene_json_ingest_cpu():
     """bge/scene_json.hpp: the reference's scene format into the product store and the oracle store (no GPU needed)."""
     _build()
-    r = subprocess.run([os.path.join(CPP, "test_scene_json"), os.path.join(ROOT, "tests", "golden", "reference_demo_scene.json")],
+    r = subprocess.run([os.path.join(CPP, "test_scene_json"), os.path.join(ROOT, "tests", "golden", "demo_scene_reference_format.json")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
@@ -42,7 +42,7 @@ def test_scene_json_ingest_cpu():
 @pytest.mark.gpu
 def test_scene_json_ingest_then_gpu_ticks():
     _build()
-    r = subprocess.run([os.path.join(CPP, "test_scene_json"), os.path.join(ROOT, "tests", "golden", "reference_demo_scene.json"), "--gpu"],
+    r = subprocess.run([os.path.join(CPP, "test_scene_json"), os.path.join(ROOT, "tests", "golden", "demo_scene_reference_format.json"), "--gpu"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "with GPU ticks" in r.stdout
