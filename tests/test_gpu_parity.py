@@ -413,3 +413,26 @@ def test_normal_matrices_match_oracle_bitwise():
         inv = normal.reshape(-1, 4, 4).transpose(0, 2, 1).astype(np.float64)
         err = np.abs(inv @ world.reshape(-1, 4, 4).astype(np.float64) - np.eye(4)).max()
         assert err < 1e-3
+
+
+@pytest.mark.parametrize("name,n", [("flat10k", 10_000), ("chains4", 6000), ("flat10k", 100)])
+def test_graph_replayed_ticks_match_oracle(name, n, monkeypatch):
+    """BGE_USE_GRAPH=1: bge_world_tick_many replays a captured hipGraph of 32 ticks (opt-in; measured slower than eager
+    launches on this ROCm).  Same kernels, so the result after 1 + 139 ticks (4 graph chunks + 11 eager ticks) must equal
+    the oracle's, bit for bit; and a second call with another dt must not reuse the stale graph."""
+    monkeypatch.setenv("BGE_USE_GRAPH", "1")
+    wl = synth.config(name, n=n)
+    ref = run_oracle(build_oracle(wl), wl, 140)
+    with B.World() as w:
+        w.load(wl)
+        w.tick(dt=DT)
+        w.set_velocities(wl.vel)
+        w.tick(dt=DT, ticks=139)
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world after graph replay")
+        assert_bits_equal(w.download_pose()[0], ref.bulk_pose()[0], "position after graph replay")
+        half = float(np.float32(DT / 2))
+        for _ in range(70):
+            ref.PhysicsSystemUpdate(half)
+            ref.TransformSystemUpdate()
+        w.tick(dt=half, ticks=70)
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world after a second graph with another dt")
