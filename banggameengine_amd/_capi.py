@@ -56,6 +56,9 @@ SYMBOLS = {
     "bge_world_download_dirty": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_dirty_count": (C.c_int, [_vp, C.POINTER(_u64)]),
     "bge_world_pairs": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "bge_world_upload_triggers": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bge_world_trigger_events": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "bge_world_trigger_active": (C.c_int, [_vp, _u64, _vp, _vp]),
     "bge_world_pack_roots": (C.c_int, [_vp, _vp]),
     "bge_world_device_array": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "bge_world_get_info": (C.c_int, [_vp, C.POINTER(WorldInfo)]),

@@ -474,6 +474,82 @@ __global__ void k_pack_roots(uint64_t n_roots, const uint32_t* __restrict__ root
     dst[t] = world[4ull * root_slots[r] + (t & 3u)];
 }
 
+// ---- trigger volumes (ghost objects): AABB of the ghost at its entity's Transform, taken BEFORE the tick integrates
+// (EnsureTrigger sets the ghost's pose at the start of PhysicsSystem::Update, src/physics/PhysicsSystem.cpp:575)
+__global__ void k_trigger_aabb(uint32_t n_triggers, TriggerView t, WorldView w)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_triggers) return;
+    const uint32_t slot = t.slot[i];
+    float* bb = t.aabb + 6ull * i;
+    if (slot == kNone || !t.active[i]) {
+        // an inactive ghost is not in the world: an empty box never overlaps
+        bb[0] = bb[1] = bb[2] = INFINITY;
+        bb[3] = bb[4] = bb[5] = -INFINITY;
+        return;
+    }
+    const F3 pos = ld3(w.pos, slot);
+    const F3 eul = ld3(w.euler, slot);
+    const F3 he = ld3(t.half_extent, i);
+    const M3 r = bt_mat_from_quat(bt_quat_from_transform_euler(eul));
+    float mn[3], mx[3];
+    bt_aabb_of_pose(pos, r, he, mn, mx);
+    for (int a = 0; a < 3; ++a) {
+        bb[a] = mn[a];
+        bb[3 + a] = mx[a];
+    }
+}
+
+// every body against every trigger (scenes carry a handful of triggers; n_bodies x n_triggers box tests); hits are
+// ballot-compacted per wave and appended behind one atomic per wave and trigger
+__global__ void __launch_bounds__(256) k_trigger_pairs(uint64_t n_slots, uint32_t n_triggers, TriggerView t, WorldView w,
+                                                       const uint32_t* __restrict__ entity_of_slot, uint32_t* __restrict__ count,
+                                                       uint2* __restrict__ out, uint32_t cap)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const uint64_t first = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t rounds = (n_slots + stride - 1) / stride; // uniform trip count: the ballot needs every lane
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t s = first + r * stride;
+        bool body = false;
+        float bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
+        uint32_t grp = 0, msk = 0, ent = 0;
+        if (s < n_slots) {
+            const uint32_t f = w.flags[s];
+            // the ghost is a static object: static bodies never pair with it
+            body = (f & kValid) && (f & kTypeMask) >= 2u;
+            if (body) {
+                const float* b = w.aabb + 6 * s;
+                for (int a = 0; a < 3; ++a) {
+                    bmn[a] = b[a];
+                    bmx[a] = b[3 + a];
+                }
+                grp = w.group[s];
+                msk = w.mask[s];
+                ent = entity_of_slot[s];
+            }
+        }
+        for (uint32_t i = 0; i < n_triggers; ++i) {
+            const float* tb = t.aabb + 6ull * i;
+            bool hit = body && ent != t.entity[i] && (t.group[i] & msk) != 0 && (grp & t.mask[i]) != 0;
+            if (hit) {
+                for (int a = 0; a < 3; ++a) hit = hit && tb[a] <= bmx[a] && tb[3 + a] >= bmn[a];
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m == 0) continue;
+            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(count, static_cast<uint32_t>(__popcll(m)));
+            base = __shfl(base, static_cast<int>(leader), 64);
+            if (hit) {
+                const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+                if (at < cap) out[at] = make_uint2(i, ent);
+            }
+        }
+    }
+}
+
 inline dim3 grid_for(uint64_t n, uint32_t block) { return dim3(static_cast<uint32_t>((n + block - 1) / block)); }
 
 } // namespace
@@ -557,6 +633,23 @@ hipError_t launch_dirty_bytes(hipStream_t stream, const uint32_t* slot_of_entity
 {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_dirty_bytes, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, first, count, flags, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_trigger_aabb(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, const WorldView& w)
+{
+    if (n_triggers == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trigger_aabb, grid_for(n_triggers, 64), dim3(64), 0, stream, n_triggers, t, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n_triggers, const TriggerView& t, const WorldView& w,
+                                const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap)
+{
+    if (n_triggers == 0 || n_slots == 0) return hipSuccess;
+    const uint64_t blocks = (n_slots + 255) / 256;
+    hipLaunchKernelGGL(k_trigger_pairs, dim3(static_cast<uint32_t>(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, n_slots,
+                       n_triggers, t, w, entity_of_slot, count, static_cast<uint2*>(out_pairs), cap);
     return hipGetLastError();
 }
 

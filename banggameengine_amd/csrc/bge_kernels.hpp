@@ -34,6 +34,17 @@ struct WorldView {
     const uint32_t* root_index; // [slots]   position of a root in the root table (read by roots only, when packing)
 };
 
+// Trigger volumes (ghost objects), indexed by trigger number
+struct TriggerView {
+    const uint32_t* slot;      // [triggers] slot of the trigger's entity (kNone: entity has no Transform)
+    const uint32_t* entity;    // [triggers] entity index
+    const float* half_extent;  // [triggers][3]
+    const uint32_t* group;     // [triggers] layer (0 -> 4, kDefaultTriggerLayer)
+    const uint32_t* mask;      // [triggers]
+    const uint8_t* active;     // [triggers]
+    float* aabb;               // [triggers][6]
+};
+
 struct TickParams {
     float dt;
     float gx, gy, gz;
@@ -59,6 +70,9 @@ hipError_t launch_init_slots(hipStream_t stream, uint64_t n_slots, const uint32_
 hipError_t launch_count_dirty(hipStream_t stream, uint64_t n_slots, const uint32_t* flags, unsigned long long* out);
 hipError_t launch_dirty_bytes(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                               const uint32_t* flags, uint8_t* out);
+hipError_t launch_trigger_aabb(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, const WorldView& w);
+hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n_triggers, const TriggerView& t, const WorldView& w,
+                                const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap);
 hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst);
 
 } // namespace bge

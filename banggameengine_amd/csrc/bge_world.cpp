@@ -125,6 +125,34 @@ struct bge_world {
     bge::RootComm comm;
     bge::WorldView view{};
 
+    // trigger volumes: host runtime (what PhysicsSystem keeps in m_triggerRuntime) + device mirrors
+    struct Trigger {
+        uint32_t entity = 0;
+        uint8_t shape = 0;
+        float size[3] = {0.5f, 0.5f, 0.5f};
+        uint32_t layer = 4, mask = 0xffffffffu;
+        bool one_shot = false;
+        bool component_active = true; // TriggerVolume::active
+        bool runtime_active = false;  // ghost is in the world
+        std::vector<uint32_t> overlaps; // sorted entity indices of the previous tick
+    };
+    std::vector<Trigger> triggers;
+    std::vector<bge_trigger_event> trigger_events; // since the last bge_world_trigger_events
+    bool triggers_device_stale = true;
+    DevBuf trig_slot, trig_entity, trig_he, trig_group, trig_mask, trig_active, trig_aabb, trig_pairs, trig_count;
+    bge::TriggerView trigger_view() const
+    {
+        bge::TriggerView t{};
+        t.slot = trig_slot.as<uint32_t>();
+        t.entity = trig_entity.as<uint32_t>();
+        t.half_extent = trig_he.as<float>();
+        t.group = trig_group.as<uint32_t>();
+        t.mask = trig_mask.as<uint32_t>();
+        t.active = trig_active.as<uint8_t>();
+        t.aabb = trig_aabb.as<float>();
+        return t;
+    }
+
     // opt-in hipGraph replay of back-to-back ticks (BGE_USE_GRAPH=1; measured slower than eager launches, see tick_many)
     static constexpr uint32_t kGraphTicks = 32;
     static constexpr uint32_t kGraphMaxTiles = 512; // ~131 k entities: above that a tick outlasts a host launch anyway
@@ -172,7 +200,8 @@ struct bge_world {
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal}) {
+                          &stage2, &mass_palette, &normal, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count}) {
             b->release();
         }
         broadphase.release();
@@ -270,6 +299,96 @@ int download_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, 
 } // namespace
 
 namespace {
+constexpr uint32_t kTriggerPairCap = 1u << 20;
+
+// device mirrors of the trigger set (slots follow the current topology)
+int sync_triggers_to_device(bge_world* w)
+{
+    const size_t n = w->triggers.size();
+    if (n == 0) return BGE_OK;
+    std::vector<uint32_t> slot(n), entity(n), group(n), mask(n);
+    std::vector<float> he(3 * n);
+    std::vector<uint8_t> active(n);
+    for (size_t i = 0; i < n; ++i) {
+        const bge_world::Trigger& t = w->triggers[i];
+        entity[i] = t.entity;
+        slot[i] = t.entity < w->flat.slot_of_entity.size() ? w->flat.slot_of_entity[t.entity] : bge::kNone;
+        collider_half_extents(t.shape, t.size, &he[3 * i]);
+        group[i] = t.layer;
+        mask[i] = t.mask;
+        active[i] = t.runtime_active && slot[i] != bge::kNone ? 1 : 0;
+    }
+    HIP_TRY(w->trig_slot.ensure(n * 4));
+    HIP_TRY(w->trig_entity.ensure(n * 4));
+    HIP_TRY(w->trig_he.ensure(n * 12));
+    HIP_TRY(w->trig_group.ensure(n * 4));
+    HIP_TRY(w->trig_mask.ensure(n * 4));
+    HIP_TRY(w->trig_active.ensure(n));
+    HIP_TRY(w->trig_aabb.ensure(n * 24));
+    HIP_TRY(w->trig_pairs.ensure(static_cast<size_t>(kTriggerPairCap) * 8));
+    HIP_TRY(w->trig_count.ensure(64));
+    HIP_TRY(hipMemcpyAsync(w->trig_slot.p, slot.data(), n * 4, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->trig_entity.p, entity.data(), n * 4, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->trig_he.p, he.data(), n * 12, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->trig_group.p, group.data(), n * 4, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->trig_mask.p, mask.data(), n * 4, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->trig_active.p, active.data(), n, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream)); // the host vectors die here
+    w->triggers_device_stale = false;
+    return BGE_OK;
+}
+
+// EnsureTrigger's activation rule, before the step (PhysicsSystem.cpp:573-590)
+void ensure_triggers(bge_world* w)
+{
+    for (bge_world::Trigger& t : w->triggers) {
+        const bool has_tf = t.entity < w->flat.slot_of_entity.size() && w->flat.slot_of_entity[t.entity] != bge::kNone;
+        const bool want = t.component_active && has_tf;
+        if (want != t.runtime_active) {
+            t.runtime_active = want;
+            t.overlaps.clear();
+            w->triggers_device_stale = true;
+        }
+    }
+}
+
+// ProcessTriggerEvents on the pair list the device produced for this tick
+int process_trigger_pairs(bge_world* w)
+{
+    uint32_t n_pairs = 0;
+    HIP_TRY(hipMemcpyAsync(&n_pairs, w->trig_count.p, 4, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (n_pairs > kTriggerPairCap) return fail(BGE_ERR_OOM, "%u trigger overlaps in one tick exceed the buffer of %u", n_pairs, kTriggerPairCap);
+    std::vector<uint32_t> pairs(2 * static_cast<size_t>(n_pairs));
+    if (n_pairs) {
+        HIP_TRY(hipMemcpyAsync(pairs.data(), w->trig_pairs.p, pairs.size() * 4, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    std::vector<std::vector<uint32_t>> current(w->triggers.size());
+    for (uint32_t k = 0; k < n_pairs; ++k) current[pairs[2 * k]].push_back(pairs[2 * k + 1]);
+    for (size_t i = 0; i < w->triggers.size(); ++i) {
+        bge_world::Trigger& t = w->triggers[i];
+        if (!t.runtime_active) continue;
+        std::vector<uint32_t>& cur = current[i];
+        std::sort(cur.begin(), cur.end());
+        for (uint32_t other : cur) {
+            const bool was = std::binary_search(t.overlaps.begin(), t.overlaps.end(), other);
+            w->trigger_events.push_back(bge_trigger_event{was ? 1u : 0u, t.entity, other});
+        }
+        for (uint32_t previous : t.overlaps) {
+            if (!std::binary_search(cur.begin(), cur.end(), previous)) w->trigger_events.push_back(bge_trigger_event{2u, t.entity, previous});
+        }
+        t.overlaps.swap(cur);
+        if (t.one_shot && !t.overlaps.empty()) {
+            t.component_active = false;
+            t.runtime_active = false;
+            t.overlaps.clear();
+            w->triggers_device_stale = true;
+        }
+    }
+    return BGE_OK;
+}
+
 // sum the recorded event pairs into the carry (synchronises the stream)
 int fold_profile(bge_world* w)
 {
@@ -517,6 +636,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     }
     w->has_topology = true;
     w->maybe_dirty = true;
+    w->triggers_device_stale = true; // slots moved
     return BGE_OK;
 }
 
@@ -771,6 +891,15 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         p.gx = gravity ? gravity[0] : 0.0f;
         p.gy = gravity ? gravity[1] : 0.0f;
         p.gz = gravity ? gravity[2] : 0.0f;
+        const bool with_triggers = (flags & BGE_TICK_BROADPHASE) && !w->triggers.empty();
+        if (with_triggers) {
+            ensure_triggers(w);
+            if (w->triggers_device_stale) {
+                if (int rc = sync_triggers_to_device(w)) return rc;
+            }
+            // ghost boxes from the Transforms as they are before the step
+            HIP_TRY(bge::launch_trigger_aabb(w->stream, static_cast<uint32_t>(w->triggers.size()), w->trigger_view(), w->view));
+        }
         const size_t n_passes = w->flat.pass_tile_begin.size() - 1;
         // BGE_TICK_GATHER_ROOTS with a transform pass: the roots write the all-gather's send buffer themselves
         const bool fused_gather = (flags & BGE_TICK_GATHER_ROOTS) && xform;
@@ -812,6 +941,14 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
                                    w->entity_of_slot.as<uint32_t>());
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
+            if (with_triggers) {
+                HIP_TRY(hipMemsetAsync(w->trig_count.p, 0, 4, w->stream));
+                HIP_TRY(bge::launch_trigger_pairs(w->stream, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
+                                                  static_cast<uint32_t>(w->triggers.size()), w->trigger_view(), w->view,
+                                                  w->entity_of_slot.as<uint32_t>(), w->trig_count.as<uint32_t>(), w->trig_pairs.p,
+                                                  kTriggerPairCap));
+                if (int rc2 = process_trigger_pairs(w)) return rc2;
+            }
         }
         w->maybe_dirty = phys && !xform;
         if (fused_gather) {
@@ -983,6 +1120,69 @@ int bge_world_pairs(bge_world* w, uint32_t* pairs2, uint64_t cap, uint64_t* tota
     DeviceGuard guard(w->device);
     const int rc = w->broadphase.download(w->stream, pairs2, cap, total);
     if (rc != BGE_OK) return fail(rc, "pair download failed: %s", w->broadphase.error());
+    return BGE_OK;
+}
+
+int bge_world_upload_triggers(bge_world* w, uint64_t count, const uint32_t* entity_index, const uint8_t* shape, const float* size3,
+                              const uint32_t* layer, const uint32_t* mask, const uint8_t* one_shot, const uint8_t* active)
+{
+    if (int rc = check_range(w, 0, 0)) return rc;
+    if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
+    std::unordered_map<uint32_t, size_t> old_index;
+    for (size_t i = 0; i < w->triggers.size(); ++i) old_index[w->triggers[i].entity] = i;
+    std::vector<bge_world::Trigger> next(count);
+    std::unordered_map<uint32_t, bool> seen;
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t e = entity_index[i];
+        if (e >= w->flat.n_entities) return fail(BGE_ERR_INVALID, "entity_index[%llu] = %u outside [0, %llu)", (unsigned long long)i, e,
+                                                  (unsigned long long)w->flat.n_entities);
+        if (seen.count(e)) return fail(BGE_ERR_INVALID, "entity %u carries two triggers", e);
+        seen[e] = true;
+        bge_world::Trigger& t = next[i];
+        t.entity = e;
+        t.shape = shape ? shape[i] : 0;
+        if (size3) std::memcpy(t.size, size3 + 3 * i, 12);
+        const uint32_t l = layer ? layer[i] : 0u;
+        t.layer = l ? l : 4u; // kDefaultTriggerLayer = 1 << 2 (PhysicsSystem.cpp:38, 557)
+        t.mask = mask ? mask[i] : 0xffffffffu;
+        t.one_shot = one_shot && one_shot[i];
+        t.component_active = !active || active[i];
+        auto it = old_index.find(e);
+        if (it != old_index.end()) {
+            bge_world::Trigger& o = w->triggers[it->second];
+            // a layer/mask change re-adds the ghost (PhysicsSystem.cpp:560-571): remembered overlaps are dropped
+            if (o.layer == t.layer && o.mask == t.mask) {
+                t.runtime_active = o.runtime_active;
+                t.overlaps.swap(o.overlaps);
+            }
+        }
+    }
+    w->triggers.swap(next);
+    w->triggers_device_stale = true;
+    return BGE_OK;
+}
+
+int bge_world_trigger_events(bge_world* w, bge_trigger_event* out, uint64_t cap, uint64_t* total)
+{
+    if (!w || !total) return fail(BGE_ERR_INVALID, "NULL argument");
+    *total = w->trigger_events.size();
+    if (out) {
+        const uint64_t take = std::min<uint64_t>(cap, w->trigger_events.size());
+        if (take) std::memcpy(out, w->trigger_events.data(), take * sizeof(bge_trigger_event));
+        w->trigger_events.clear();
+    }
+    return BGE_OK;
+}
+
+int bge_world_trigger_active(bge_world* w, uint64_t count, const uint32_t* entity_index, uint8_t* active)
+{
+    if (!w || (count && (!entity_index || !active))) return fail(BGE_ERR_INVALID, "NULL argument");
+    std::unordered_map<uint32_t, bool> state;
+    for (const bge_world::Trigger& t : w->triggers) state[t.entity] = t.component_active;
+    for (uint64_t i = 0; i < count; ++i) {
+        auto it = state.find(entity_index[i]);
+        active[i] = it != state.end() && it->second ? 1 : 0;
+    }
     return BGE_OK;
 }
 

@@ -31,12 +31,27 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../../include/bge_world.h"
 
 namespace bge {
+
+// Trigger events as PhysicsSystem publishes them on its EventBus (src/physics/PhysicsSystem.h:50-62)
+struct GpuTriggerEvent {
+    enum class Type { Enter, Stay, Exit };
+    Type type = Type::Enter;
+    uint32_t trigger = 0; // EntityId
+    uint32_t other = 0;   // EntityId
+};
+
+namespace detail {
+template <class S, class = void> struct has_trigger_volumes : std::false_type {};
+template <class S> struct has_trigger_volumes<S, std::void_t<decltype(std::declval<S&>().GetTriggerVolumes())>> : std::true_type {};
+} // namespace detail
 
 template <class SceneT> class GpuSceneMirror {
 public:
@@ -82,7 +97,17 @@ public:
     bool UpdatePhysics(SceneT& scene, double dt)
     {
         if (!ok() || !RefreshTopology(scene) || !UploadBodies(scene) || !UploadDirtyTransforms(scene)) return false;
-        if (bge_world_tick(world_, static_cast<float>(dt), gravity, BGE_TICK_PHYSICS) != BGE_OK) return Log("bge_world_tick");
+        uint32_t flags = BGE_TICK_PHYSICS;
+        bool triggers = false;
+        if constexpr (detail::has_trigger_volumes<SceneT>::value) {
+            if (!UploadTriggers(scene, triggers)) return false;
+            if (triggers) flags |= BGE_TICK_BROADPHASE; // the ghost overlaps come out of the broadphase step
+        }
+        if (bge_world_tick(world_, static_cast<float>(dt), gravity, flags) != BGE_OK) return Log("bge_world_tick");
+        trigger_events_.clear();
+        if constexpr (detail::has_trigger_volumes<SceneT>::value) {
+            if (triggers && !FetchTriggerEvents(scene)) return false;
+        }
         // SyncRigidBodiesFromPhysics: Dynamic bodies only (PhysicsSystem.cpp:926-948)
         index_list_.clear();
         for (auto& kv : scene.GetRigidBodies()) {
@@ -109,7 +134,73 @@ public:
         return true;
     }
 
+    // Enter / Stay / Exit of the last UpdatePhysics (what ProcessTriggerEvents publishes, PhysicsSystem.cpp:1017-1074)
+    const std::vector<GpuTriggerEvent>& TriggerEvents() const { return trigger_events_; }
+
 private:
+    // EnsureTrigger (PhysicsSystem.cpp:523-590): the trigger set is re-sent when a TriggerVolume appeared, vanished or
+    // changed; remembered overlaps survive on the device side for unchanged triggers
+    bool UploadTriggers(SceneT& scene, bool& any)
+    {
+        auto& vols = scene.GetTriggerVolumes();
+        t_entity_.clear(); t_shape_.clear(); t_size_.clear(); t_layer_.clear(); t_mask_.clear(); t_oneshot_.clear(); t_active_.clear();
+        bool dirty = false;
+        for (auto& kv : vols) {
+            auto it = index_of_.find(kv.first);
+            if (it == index_of_.end()) continue; // a trigger needs a Transform (PhysicsSystem.cpp:530-534)
+            auto& tv = kv.second;
+            t_entity_.push_back(it->second);
+            t_shape_.push_back(static_cast<uint8_t>(static_cast<int>(tv.shape)));
+            t_size_.push_back(tv.size.x); t_size_.push_back(tv.size.y); t_size_.push_back(tv.size.z);
+            t_layer_.push_back(tv.layer);
+            t_mask_.push_back(tv.mask);
+            t_oneshot_.push_back(tv.oneShot ? 1 : 0);
+            t_active_.push_back(tv.active ? 1 : 0);
+            dirty = dirty || tv.dirty;
+            tv.dirty = false;
+        }
+        any = !t_entity_.empty();
+        // signature of the set: everything that reaches the device
+        std::vector<uint32_t> sig;
+        sig.reserve(t_entity_.size() * 8);
+        for (size_t k = 0; k < t_entity_.size(); ++k) {
+            uint32_t sz[3];
+            std::memcpy(sz, &t_size_[3 * k], 12);
+            sig.insert(sig.end(), {t_entity_[k], t_shape_[k], sz[0], sz[1], sz[2], t_layer_[k], t_mask_[k],
+                                   static_cast<uint32_t>(t_oneshot_[k] | (t_active_[k] << 1))});
+        }
+        if (!dirty && sig == t_signature_) return true;
+        // order the set by entity index so that the signature is independent of hash-map iteration order
+        t_signature_ = sig;
+        if (bge_world_upload_triggers(world_, t_entity_.size(), t_entity_.data(), t_shape_.data(), t_size_.data(), t_layer_.data(),
+                                      t_mask_.data(), t_oneshot_.data(), t_active_.data()) != BGE_OK) {
+            return Log("bge_world_upload_triggers");
+        }
+        return true;
+    }
+
+    bool FetchTriggerEvents(SceneT& scene)
+    {
+        uint64_t total = 0;
+        if (bge_world_trigger_events(world_, nullptr, 0, &total) != BGE_OK) return Log("bge_world_trigger_events");
+        raw_events_.resize(total);
+        if (bge_world_trigger_events(world_, raw_events_.data(), total, &total) != BGE_OK) return Log("bge_world_trigger_events");
+        for (const bge_trigger_event& e : raw_events_) {
+            trigger_events_.push_back(GpuTriggerEvent{static_cast<GpuTriggerEvent::Type>(e.type), ids_[e.trigger], ids_[e.other]});
+        }
+        // one-shot triggers that fired are now inactive (PhysicsSystem.cpp:1062-1071)
+        if (!t_entity_.empty()) {
+            t_active_.resize(t_entity_.size());
+            if (bge_world_trigger_active(world_, t_entity_.size(), t_entity_.data(), t_active_.data()) != BGE_OK) return Log("bge_world_trigger_active");
+            for (size_t k = 0; k < t_entity_.size(); ++k) {
+                if (auto* tv = scene.GetTriggerVolume(ids_[t_entity_[k]])) {
+                    if (tv->active && !t_active_[k]) tv->active = false;
+                }
+            }
+        }
+        return true;
+    }
+
     struct BodyState {
         bool exists = false;
     };
@@ -282,6 +373,11 @@ private:
     std::vector<float> b_mass_, b_size_;
     std::vector<uint32_t> b_layer_, b_mask_;
     size_t live_ = 0;
+    std::vector<uint32_t> t_entity_, t_layer_, t_mask_, t_signature_;
+    std::vector<uint8_t> t_shape_, t_oneshot_, t_active_;
+    std::vector<float> t_size_;
+    std::vector<bge_trigger_event> raw_events_;
+    std::vector<GpuTriggerEvent> trigger_events_;
 };
 
 // One mirror per Scene object, found by address (TransformSystem::Update is a static function without state,
@@ -325,6 +421,8 @@ public:
         m.gravity[2] = 0.0f;
         m.UpdatePhysics(scene, dt);
     }
+    // trigger events of the last Update (publish them on the engine's EventBus, src/core/EventBus.h)
+    const std::vector<GpuTriggerEvent>& TriggerEvents(SceneT& scene) const { return GpuMirrors<SceneT>::Of(scene).TriggerEvents(); }
 
 private:
     float gravityY_ = -9.81f;

@@ -57,6 +57,17 @@ struct RigidBody {
     bool dirty = true;
 };
 
+// src/ecs/PhysicsComponents.h:39-48
+struct TriggerVolume {
+    ColliderShape shape = ColliderShape::Box;
+    float3 size{0.5f, 0.5f, 0.5f};
+    uint32_t layer = 0u;
+    uint32_t mask = 0xffffffffu;
+    bool oneShot = false;
+    bool active = true;
+    bool dirty = true;
+};
+
 class Scene {
 public:
     EntityId CreateEntity()
@@ -76,6 +87,7 @@ public:
     {
         if (!IsAlive(id)) return;
         transforms_.erase(id);
+        triggers_.erase(id);
         rigidBodies_.erase(id);
         colliders_.erase(id);
         Unlink(id);
@@ -106,6 +118,11 @@ public:
     RigidBody* AddRigidBody(EntityId id) { return Add(rigidBodies_, id); }
     RigidBody* GetRigidBody(EntityId id) { return Get(rigidBodies_, id); }
     void RemoveRigidBody(EntityId id) { rigidBodies_.erase(id); }
+
+    TriggerVolume* AddTriggerVolume(EntityId id) { return Add(triggers_, id); }
+    TriggerVolume* GetTriggerVolume(EntityId id) { return Get(triggers_, id); }
+    void RemoveTriggerVolume(EntityId id) { triggers_.erase(id); }
+    std::unordered_map<EntityId, TriggerVolume>& GetTriggerVolumes() { return triggers_; }
 
     void SetParent(EntityId child, EntityId parent)
     {
@@ -197,6 +214,7 @@ private:
     std::unordered_map<EntityId, Transform> transforms_;
     std::unordered_map<EntityId, Collider> colliders_;
     std::unordered_map<EntityId, RigidBody> rigidBodies_;
+    std::unordered_map<EntityId, TriggerVolume> triggers_;
     std::unordered_map<EntityId, EntityId> parents_;
     std::unordered_map<EntityId, std::vector<EntityId>> children_;
     std::vector<EntityId> free_;

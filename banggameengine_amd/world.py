@@ -156,6 +156,27 @@ class World:
         check(lib().bge_world_pairs(self._h, None, 0, C.byref(total)))
         return int(total.value)
 
+    # -- trigger volumes
+    def upload_triggers(self, entity_index, shape=None, size=None, layer=None, mask=None, one_shot=None, active=None):
+        e = _arr(entity_index, np.uint32)
+        check(lib().bge_world_upload_triggers(self._h, len(e), _p(e), _p(_arr(shape, np.uint8)), _p(_arr(size, np.float32, 3)),
+                                              _p(_arr(layer, np.uint32)), _p(_arr(mask, np.uint32)),
+                                              _p(_arr(one_shot, np.uint8)), _p(_arr(active, np.uint8))))
+
+    def trigger_events(self):
+        """(type, trigger entity, other entity) rows since the last call, sorted; type 0 Enter, 1 Stay, 2 Exit."""
+        total = C.c_uint64(0)
+        check(lib().bge_world_trigger_events(self._h, None, 0, C.byref(total)))
+        out = np.empty((int(total.value), 3), np.uint32)
+        check(lib().bge_world_trigger_events(self._h, _p(out), len(out), C.byref(total)))
+        return out[np.lexsort((out[:, 2], out[:, 1], out[:, 0]))].copy() if len(out) else out
+
+    def trigger_active(self, entity_index):
+        e = _arr(entity_index, np.uint32)
+        out = np.empty(len(e), np.uint8)
+        check(lib().bge_world_trigger_active(self._h, len(e), _p(e), _p(out)))
+        return out.astype(bool)
+
     # -- multi-GPU support / device-resident consumers
     def pack_roots(self, dst_device_ptr: int | None = None):
         check(lib().bge_world_pack_roots(self._h, C.c_void_p(dst_device_ptr) if dst_device_ptr else None))

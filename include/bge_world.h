@@ -190,6 +190,32 @@ BGE_API int bge_world_dirty_count(bge_world* world, uint64_t* out);
  * device had to drop pairs (pair_capacity too small); pairs2 = NULL just queries the count. */
 BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, uint64_t* total);
 
+/*
+ * Trigger volumes: TriggerVolume components (src/ecs/PhysicsComponents.h:39-48) and the
+ * Enter / Stay / Exit events of PhysicsSystem::ProcessTriggerEvents (src/physics/PhysicsSystem.cpp:1017-1074).
+ *   bge_world_upload_triggers replaces the world's whole trigger set (count may be 0).  Per trigger: the entity it
+ *       sits on (needs a Transform), shape/size as for colliders, layer (0 is treated as 4, kDefaultTriggerLayer), mask,
+ *       oneShot, active.  Triggers that were present before keep their remembered overlaps unless layer/mask changed.
+ *   Every BGE_TICK_BROADPHASE tick then (a) poses each active trigger's ghost box from its entity's Transform as it is
+ *       BEFORE the step (EnsureTrigger, PhysicsSystem.cpp:575), (b) tests it on the device against the AABB of every
+ *       Dynamic / Kinematic body (the ghost is a static object; filter (groupT & maskB) && (groupB & maskT)), (c) diffs the
+ *       overlap set with the previous tick's on the host: Enter (0) / Stay (1) / Exit (2).  A one-shot trigger turns
+ *       inactive after its first non-empty set and forgets it.  With triggers present such a tick synchronises the
+ *       stream (the events are for host code).
+ *   bge_world_trigger_events returns (and clears) the events accumulated since the previous call.
+ *   bge_world_trigger_active reports TriggerVolume::active per queried entity (0 after a one-shot fired, or no trigger).
+ */
+typedef struct bge_trigger_event {
+    uint32_t type;    /* 0 Enter, 1 Stay, 2 Exit (PhysicsSystem::TriggerEvent::Type, src/physics/PhysicsSystem.h:50-62) */
+    uint32_t trigger; /* entity index of the trigger */
+    uint32_t other;   /* entity index of the body */
+} bge_trigger_event;
+BGE_API int bge_world_upload_triggers(bge_world* world, uint64_t count, const uint32_t* entity_index, const uint8_t* shape,
+                                      const float* size3, const uint32_t* layer, const uint32_t* mask,
+                                      const uint8_t* one_shot, const uint8_t* active);
+BGE_API int bge_world_trigger_events(bge_world* world, bge_trigger_event* out, uint64_t cap, uint64_t* total);
+BGE_API int bge_world_trigger_active(bge_world* world, uint64_t count, const uint32_t* entity_index, uint8_t* active);
+
 /* Multi-GPU support: compact the world matrices of all roots (entity order) into one buffer that the
  * caller all-gathers across ranks (one collective per frame).  dst = NULL packs into the world's own
  * BGE_ARRAY_ROOT_WORLDS buffer; otherwise dst is a device pointer with room for n_roots*16 floats. */

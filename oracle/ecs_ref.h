@@ -90,6 +90,17 @@ struct RefRigidBody {
     bool dirty = true;
 };
 
+// src/ecs/PhysicsComponents.h:39-48
+struct RefTriggerVolume {
+    RefShape shape = RefShape::Box;
+    Float3 size{0.5f, 0.5f, 0.5f};
+    uint32_t layer = 0u;
+    uint32_t mask = 0xffffffffu;
+    bool oneShot = false;
+    bool active = true;
+    bool dirty = true;
+};
+
 class RefScene {
 public:
     EntityId CreateEntity()
@@ -111,6 +122,7 @@ public:
     {
         if (!IsAlive(id)) return;
         RemoveTransform(id);
+        RemoveTriggerVolume(id);
         RemoveRigidBody(id);
         RemoveCollider(id);
         if (const EntityId parent = GetParent(id); parent != kInvalidEntity) {
@@ -182,6 +194,21 @@ public:
     }
     void RemoveRigidBody(EntityId id) { rigidBodies_.erase(id); }
 
+    RefTriggerVolume* AddTriggerVolume(EntityId id)
+    {
+        if (!IsAlive(id)) return nullptr;
+        auto res = triggers_.emplace(id, RefTriggerVolume{});
+        res.first->second.dirty = true;
+        return &res.first->second;
+    }
+    RefTriggerVolume* GetTriggerVolume(EntityId id)
+    {
+        auto it = triggers_.find(id);
+        return it == triggers_.end() ? nullptr : &it->second;
+    }
+    void RemoveTriggerVolume(EntityId id) { triggers_.erase(id); }
+    std::unordered_map<EntityId, RefTriggerVolume>& GetTriggerVolumes() { return triggers_; }
+
     void SetParent(EntityId child, EntityId parent)
     {
         if (!IsAlive(child)) return;
@@ -250,6 +277,7 @@ private:
     std::unordered_map<EntityId, RefTransform> transforms_;
     std::unordered_map<EntityId, RefCollider> colliders_;
     std::unordered_map<EntityId, RefRigidBody> rigidBodies_;
+    std::unordered_map<EntityId, RefTriggerVolume> triggers_;
     std::unordered_map<EntityId, EntityId> parents_;
     std::unordered_map<EntityId, std::vector<EntityId>> children_;
     std::vector<EntityId> freeIds_;

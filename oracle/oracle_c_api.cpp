@@ -131,6 +131,37 @@ void orc_mark_body_dirty(void* h, uint32_t id)
     if (RefRigidBody* b = S(h)->scene.GetRigidBody(id)) b->dirty = true;
 }
 
+int orc_add_trigger(void* h, uint32_t id, int shape, const float* size, uint32_t layer, uint32_t mask, int oneShot, int active)
+{
+    RefTriggerVolume* t = S(h)->scene.AddTriggerVolume(id);
+    if (!t) return 0;
+    t->shape = static_cast<RefShape>(shape);
+    if (size) t->size = F3(size);
+    t->layer = layer;
+    t->mask = mask;
+    t->oneShot = oneShot != 0;
+    t->active = active != 0;
+    t->dirty = true;
+    return 1;
+}
+void orc_remove_trigger(void* h, uint32_t id) { S(h)->scene.RemoveTriggerVolume(id); }
+int orc_trigger_is_active(void* h, uint32_t id)
+{
+    const RefTriggerVolume* t = S(h)->scene.GetTriggerVolume(id);
+    return t && t->active ? 1 : 0;
+}
+// events of the last physics update as (type, trigger id, other id) triples; returns how many there are
+uint64_t orc_trigger_events(void* h, uint32_t* out3, uint64_t cap)
+{
+    const auto& ev = S(h)->physics.LastTriggerEvents();
+    for (uint64_t k = 0; k < ev.size() && k < cap; ++k) {
+        out3[3 * k] = static_cast<uint32_t>(ev[k].type);
+        out3[3 * k + 1] = ev[k].trigger;
+        out3[3 * k + 2] = ev[k].other;
+    }
+    return ev.size();
+}
+
 void orc_set_physics_options(void* h, float gravityY, int orientMode, int computeAabbs)
 {
     S(h)->physics.gravityY = gravityY;

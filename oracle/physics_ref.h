@@ -71,6 +71,34 @@ struct RefBodyRuntime {
     float aabbMax[3] = {0, 0, 0};
 };
 
+// Trigger volumes.  Follows:
+//   src/physics/PhysicsSystem.cpp:523-590   EnsureTrigger: ghost object (CF_NO_CONTACT_RESPONSE | CF_STATIC_OBJECT) whose
+//                                            shape is CreateShape(trigger.shape, trigger.size); layer 0 -> 4; while the
+//                                            trigger is active its pose is set from the Transform EVERY tick (:575);
+//                                            (re)activation clears the remembered overlaps
+//   src/physics/PhysicsSystem.cpp:1017-1074 ProcessTriggerEvents: current overlap set vs the previous one ->
+//                                            Enter / Stay / Exit; a one-shot trigger deactivates after its first
+//                                            non-empty set and forgets it (no Exit later)
+// The ghost's overlap list is Bullet's pair cache restricted to the ghost; as for the broadphase the specification here
+// is its history-free core: the ghost's AABB (shape AABB at its pose + 0.02) overlaps the body's fed AABB, the collision
+// filter passes both ways, and the body is not Static (the ghost itself is a static object).  Trigger-trigger pairs
+// (static-static) are not produced.  PARITY STATUS: unpinned (spec-derived).
+struct RefTriggerEvent {
+    int type; // 0 Enter, 1 Stay, 2 Exit   (PhysicsSystem.h:50-62)
+    EntityId trigger;
+    EntityId other;
+};
+
+struct RefTriggerRuntime {
+    bool hasGhost = false;
+    bool active = false;
+    bool oneShot = false;
+    uint32_t layer = 0, mask = 0;
+    bt::Vec3 aabbHalfExtents{0.5f, 0.5f, 0.5f};
+    float aabbMin[3] = {0, 0, 0}, aabbMax[3] = {0, 0, 0};
+    std::vector<EntityId> overlaps; // sorted
+};
+
 class RefPhysicsSystem {
 public:
     float gravityY = -9.81f; // assets/config/physics.json:2, PhysicsSystem.h:87
@@ -78,6 +106,8 @@ public:
     bool computeAabbs = false;
 
     std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
+    std::unordered_map<EntityId, RefTriggerRuntime>& TriggerRuntimes() { return triggerRuntime_; }
+    const std::vector<RefTriggerEvent>& LastTriggerEvents() const { return events_; }
 
     // The rigid-body slice of PhysicsSystem::Update(scene, camera, input, dt).
     void Update(RefScene& scene, double dt)
@@ -98,9 +128,19 @@ public:
             if (!collider) continue;
             EnsureRigidBody(scene, kv.first, *collider, kv.second);
         }
+        // :1262-1269 EnsureTrigger for every TriggerVolume (+ :1234-1246 pruning)
+        std::vector<EntityId> goneTriggers;
+        for (const auto& kv : triggerRuntime_) {
+            if (!scene.IsAlive(kv.first) || !scene.GetTriggerVolume(kv.first)) goneTriggers.push_back(kv.first);
+        }
+        for (EntityId id : goneTriggers) triggerRuntime_.erase(id);
+        for (auto& kv : scene.GetTriggerVolumes()) {
+            if (scene.IsAlive(kv.first)) EnsureTrigger(scene, kv.first, kv.second);
+        }
         SyncKinematicBodiesToPhysics(scene);
         StepSimulation(static_cast<float>(dt));
         SyncRigidBodiesFromPhysics(scene);
+        ProcessTriggerEvents(scene);
     }
 
     // Extension used by the synthetic workloads (the reference has no API to give a body an
@@ -251,7 +291,85 @@ private:
         }
     }
 
+    static bt::Vec3 ShapeHalfExtents(RefShape shape, const Float3& size)
+    {
+        if (shape == RefShape::Capsule) {
+            const float radius = std::max(size.x, 0.01f);
+            const float halfHeight = std::max(size.y, 0.0f);
+            return bt::CapsuleAabbHalfExtents(radius, 0.5f * (halfHeight * 2.0f));
+        }
+        return bt::BoxAabbHalfExtents(std::max(size.x, 0.01f), std::max(size.y, 0.01f), std::max(size.z, 0.01f));
+    }
+
+    void EnsureTrigger(RefScene& scene, EntityId entity, RefTriggerVolume& trigger)
+    {
+        RefTransform* transform = scene.GetTransform(entity);
+        if (!transform) return;
+        RefTriggerRuntime& rt = triggerRuntime_.try_emplace(entity).first->second;
+        if (trigger.dirty || !rt.hasGhost) {
+            rt.aabbHalfExtents = ShapeHalfExtents(trigger.shape, trigger.size);
+            trigger.dirty = false;
+            rt.hasGhost = true;
+        }
+        rt.oneShot = trigger.oneShot;
+        const uint32_t desiredLayer = trigger.layer ? trigger.layer : 4u; // kDefaultTriggerLayer = 1 << 2
+        if (rt.layer != desiredLayer || rt.mask != trigger.mask) {
+            rt.layer = desiredLayer;
+            rt.mask = trigger.mask;
+            rt.active = false;
+        }
+        if (trigger.active) {
+            // ghost->setWorldTransform(MakeBtTransform(*transform)) every tick; its AABB is refreshed by updateAabbs
+            const bt::Vec3 origin{transform->position.x, transform->position.y, transform->position.z};
+            const bt::Mat3 basis = bt::MatFromQuat(bt::QuatFromTransformEuler(transform->rotationEuler.x, transform->rotationEuler.y,
+                                                                              transform->rotationEuler.z));
+            bt::AabbOfPose(origin, basis, rt.aabbHalfExtents, rt.aabbMin, rt.aabbMax);
+            if (!rt.active) {
+                rt.active = true;
+                rt.overlaps.clear();
+            }
+        } else if (rt.active) {
+            rt.active = false;
+            rt.overlaps.clear();
+        }
+    }
+
+    void ProcessTriggerEvents(RefScene& scene)
+    {
+        events_.clear();
+        for (auto& kv : triggerRuntime_) {
+            RefTriggerVolume* trigger = scene.GetTriggerVolume(kv.first);
+            RefTriggerRuntime& rt = kv.second;
+            if (!trigger || !rt.hasGhost || !rt.active) continue;
+            std::vector<EntityId> current;
+            for (const auto& bk : runtime_) {
+                const RefBodyRuntime& b = bk.second;
+                if (!b.hasBody || bk.first == kv.first || b.type == RefBodyType::Static) continue;
+                if ((rt.layer & b.mask) == 0 || (b.layer & rt.mask) == 0) continue;
+                bool overlap = true;
+                for (int a = 0; a < 3; ++a) overlap = overlap && rt.aabbMin[a] <= b.aabbMax[a] && rt.aabbMax[a] >= b.aabbMin[a];
+                if (overlap) current.push_back(bk.first);
+            }
+            std::sort(current.begin(), current.end());
+            for (EntityId other : current) {
+                const bool was = std::binary_search(rt.overlaps.begin(), rt.overlaps.end(), other);
+                events_.push_back(RefTriggerEvent{was ? 1 : 0, kv.first, other});
+            }
+            for (EntityId previous : rt.overlaps) {
+                if (!std::binary_search(current.begin(), current.end(), previous)) events_.push_back(RefTriggerEvent{2, kv.first, previous});
+            }
+            rt.overlaps = std::move(current);
+            if (rt.oneShot && !rt.overlaps.empty()) {
+                trigger->active = false;
+                rt.active = false;
+                rt.overlaps.clear();
+            }
+        }
+    }
+
     std::unordered_map<EntityId, RefBodyRuntime> runtime_;
+    std::unordered_map<EntityId, RefTriggerRuntime> triggerRuntime_;
+    std::vector<RefTriggerEvent> events_;
 };
 
 } // namespace orc

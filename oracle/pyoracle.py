@@ -56,6 +56,8 @@ class _Lib:
         l.orc_bench_tick_soa.restype = C.c_double
         l.orc_bench_tick_soa.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double,
                                          C.c_int, C.POINTER(C.c_int), C.c_void_p]
+        l.orc_trigger_events.restype = C.c_uint64
+        l.orc_add_trigger.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         l.orc_physics_update.argtypes = [C.c_void_p, C.c_double]
         l.orc_set_physics_options.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         l.orc_add_rigidbody.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint32, C.c_uint32]
@@ -234,6 +236,27 @@ class RefScene:
 
     def RemoveRigidBody(self, eid):
         lib().orc_remove_rigidbody(self.h, C.c_uint32(eid))
+
+    def AddTriggerVolume(self, eid, shape=0, size=(0.5, 0.5, 0.5), layer=0, mask=0xFFFFFFFF, one_shot=False, active=True):
+        s = _c(size, np.float32)
+        return bool(lib().orc_add_trigger(self.h, eid, shape, _vp(s), layer, mask, int(one_shot), int(active)))
+
+    def RemoveTriggerVolume(self, eid):
+        lib().orc_remove_trigger(self.h, C.c_uint32(eid))
+
+    def TriggerIsActive(self, eid):
+        return bool(lib().orc_trigger_is_active(self.h, C.c_uint32(eid)))
+
+    def TriggerEvents(self):
+        """(type, trigger id, other id) rows of the last PhysicsSystemUpdate, sorted; type 0 Enter, 1 Stay, 2 Exit."""
+        cap = 1 << 16
+        while True:
+            out = np.empty((cap, 3), np.uint32)
+            k = lib().orc_trigger_events(self.h, _vp(out), C.c_uint64(cap))
+            if k <= cap:
+                ev = out[:k]
+                return ev[np.lexsort((ev[:, 2], ev[:, 1], ev[:, 0]))].copy()
+            cap = int(k)
 
     def MarkBodyDirty(self, eid):
         lib().orc_mark_body_dirty(self.h, C.c_uint32(eid))

@@ -6,6 +6,8 @@
 // and every Transform (position, rotationEuler, world, dirty) must match bit for bit after every tick.
 // Reads like the reference's frame: physics.Update(scene, dt); TransformSystem::Update(scene)
 // (src/core/Application.cpp:256, 284).  Needs a GPU; run by tests/test_host_adapter.py.
+#include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -64,6 +66,31 @@ struct Pair {
         rb->layer = gb->layer = layer;
         rb->mask = gb->mask = mask;
     }
+    void Trigger(uint32_t id, int shape, const float* size, uint32_t layer, uint32_t mask, bool oneShot)
+    {
+        auto* rt = ref.AddTriggerVolume(id);
+        auto* gt = gpu.AddTriggerVolume(id);
+        rt->shape = static_cast<orc::RefShape>(shape); gt->shape = static_cast<bge::ColliderShape>(shape);
+        Put(&rt->size, size); Put(&gt->size, size);
+        rt->layer = gt->layer = layer;
+        rt->mask = gt->mask = mask;
+        rt->oneShot = gt->oneShot = oneShot;
+    }
+    void CompareTriggerEvents()
+    {
+        std::vector<std::array<uint32_t, 3>> a, b;
+        for (const auto& e : refPhysics.LastTriggerEvents()) a.push_back({static_cast<uint32_t>(e.type), e.trigger, e.other});
+        for (const auto& e : gpuPhysics.TriggerEvents(gpu)) b.push_back({static_cast<uint32_t>(e.type), e.trigger, e.other});
+        std::sort(a.begin(), a.end());
+        std::sort(b.begin(), b.end());
+        CHECK(a == b, "trigger events differ: %zu (oracle) vs %zu (gpu)", a.size(), b.size());
+        events_seen += a.size();
+        for (auto& kv : ref.GetTriggerVolumes()) {
+            auto* g = gpu.GetTriggerVolume(kv.first);
+            CHECK(g && g->active == kv.second.active, "trigger %u active flag", kv.first);
+        }
+    }
+    size_t events_seen = 0;
     void SetParent(uint32_t c, uint32_t p) { ref.SetParent(c, p); gpu.SetParent(c, p); }
     void Destroy(uint32_t id) { ref.DestroyEntity(id); gpu.DestroyEntity(id); }
     void Move(uint32_t id, const float* p, bool markDirty)
@@ -76,6 +103,7 @@ struct Pair {
         refPhysics.Update(ref, dt);
         gpuPhysics.Update(gpu, dt);
         ComparePose("after physics");
+        CompareTriggerEvents();
         orc::RefTransformSystemUpdate(ref);
         bge::GpuTransformSystem<bge::Scene>::Update(gpu);
         CompareAll("after transforms");
@@ -140,6 +168,12 @@ int main()
             w.Body(ids[i], type, 0.5f + (rng() % 8) * 0.25f, size, rng() % 5 == 0, 1u << (rng() % 3), 0xffffffffu);
         }
     }
+    // trigger volumes: big enough to catch passers-by; one-shots, a filtered layer, one on a Dynamic body
+    w.refPhysics.computeAabbs = true; // the oracle derives the ghost overlaps from the fed body AABBs
+    for (int k = 0; k < 25; ++k) {
+        float size[3] = {6.0f + (k % 5) * 4.0f, 10.0f, 6.0f + (k % 3) * 5.0f};
+        w.Trigger(ids[40 * k + 3], k % 4 == 0, size, k % 3 == 0 ? 0u : 4u, k % 5 == 0 ? 6u : 0xffffffffu, k % 4 == 1);
+    }
     for (int k = 0; k < 3; ++k) w.Tick();
 
     // second Update without changes must be a no-op (Renderer::BeginFrame calls it again, src/render/Renderer.cpp:606)
@@ -176,6 +210,7 @@ int main()
     for (auto& kv : w.gpu.GetRigidBodies()) { if (kv.first % 7 == 0) kv.second.dirty = true; }
     for (int k = 0; k < 3; ++k) w.Tick();
 
-    if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, 10 ticks)\n", w.gpu.GetTransformCount());
+    CHECK(w.events_seen > 0, "the scripted scene produced no trigger events");
+    if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, 10 ticks, %zu trigger events)\n", w.gpu.GetTransformCount(), w.events_seen);
     return g_failures ? 1 : 0;
 }

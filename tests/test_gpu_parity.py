@@ -436,3 +436,50 @@ def test_graph_replayed_ticks_match_oracle(name, n, monkeypatch):
             ref.TransformSystemUpdate()
         w.tick(dt=half, ticks=70)
         assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world after a second graph with another dt")
+
+
+def test_trigger_events_match_oracle_every_tick():
+    """Enter / Stay / Exit events of trigger volumes (ProcessTriggerEvents), tick by tick, incl.
+    one-shot triggers, layer/mask filters, inactive triggers, a trigger riding on a moving Dynamic body, capsules."""
+    n = 3000
+    wl = synth.Workload("cube", synth.FLAT, n, 4242, pos_box=synth.CUBE)
+    wl.pos = (wl.pos * np.float32(20.0 / 262.0)).astype(np.float32)
+    wl.pos[:, 1] += np.float32(5.0)
+    rng = np.random.default_rng(9)
+    wl.body_type = rng.choice([0, 1, 1, 1, 2], n).astype(np.uint8)
+    layer = rng.choice([1, 2, 4], n).astype(np.uint32)
+    mask = rng.choice([0xFFFFFFFF, 0xFFFFFFFB, 3], n).astype(np.uint32)        # some bodies ignore layer 4 (triggers)
+    n_trig = 40
+    trig_entities = rng.choice(n, n_trig, replace=False).astype(np.uint32)
+    t_shape = rng.choice([0, 0, 1], n_trig).astype(np.uint8)
+    t_size = rng.uniform(0.3, 3.0, (n_trig, 3)).astype(np.float32)
+    t_layer = rng.choice([0, 4, 2], n_trig).astype(np.uint32)
+    t_mask = rng.choice([0xFFFFFFFF, 1, 6], n_trig).astype(np.uint32)
+    t_oneshot = (rng.random(n_trig) < 0.3).astype(np.uint8)
+    t_active = (rng.random(n_trig) < 0.9).astype(np.uint8)
+    ref = build_oracle(wl, aabbs=True, layer=layer, mask=mask)
+    for k in range(n_trig):
+        ref.AddTriggerVolume(int(trig_entities[k]) + 1, int(t_shape[k]), t_size[k], int(t_layer[k]), int(t_mask[k]),
+                             bool(t_oneshot[k]), bool(t_active[k]))
+    flags = B.TICK_ALL | B.TICK_BROADPHASE
+    seen_types = set()
+    with B.World(pair_capacity=64 * n) as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, layer=layer, mask=mask)
+        w.upload_triggers(trig_entities, t_shape, t_size, t_layer, t_mask, t_oneshot, t_active)
+        for tick in range(90):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, flags=flags)
+            if tick == 0:
+                ref.bulk_set_velocity(wl.vel * np.float32(4.0))
+                w.set_velocities(wl.vel * np.float32(4.0))
+            want = ref.TriggerEvents()
+            want[:, 1:] -= 1                                   # oracle ids are entity index + 1
+            got = w.trigger_events()
+            assert np.array_equal(got, want), f"tick {tick}: {len(got)} vs {len(want)} events"
+            seen_types |= set(got[:, 0].tolist())
+            want_active = np.array([ref.TriggerIsActive(int(e) + 1) for e in trig_entities])
+            assert np.array_equal(w.trigger_active(trig_entities), want_active), f"tick {tick}: one-shot state"
+    assert seen_types == {0, 1, 2}                              # the scene really produced Enter, Stay and Exit
