@@ -227,30 +227,50 @@ private:
         }
         if (!changed) return true;
 
-        // drop entities that lost their Transform
+        // drop entities that lost their Transform; remember which index each id had, because the reference reuses
+        // EntityIds (Scene.cpp:24-27) and everything keyed by id there (e.g. a trigger's remembered overlaps) is keyed
+        // by index here: a re-created id gets its old index back
         for (auto it = index_of_.begin(); it != index_of_.end();) {
             if (!scene.HasTransform(it->first)) {
                 has_tf_[it->second] = 0;
                 ids_[it->second] = 0;
                 body_[it->second] = BodyState{};
                 free_.push_back(it->second);
+                is_free_[it->second] = 1;
+                retired_[it->first] = it->second;
                 it = index_of_.erase(it);
             } else {
                 ++it;
             }
         }
+        // first the ids that come back, so that nobody else takes their index
+        for (auto& kv : transforms) {
+            if (index_of_.count(kv.first)) continue;
+            auto r = retired_.find(kv.first);
+            if (r == retired_.end() || !is_free_[r->second]) continue;
+            const uint32_t i = r->second;
+            is_free_[i] = 0;
+            ids_[i] = kv.first;
+            has_tf_[i] = 1;
+            written_[i] = 0;
+            index_of_[kv.first] = i;
+            fresh_.push_back(i);
+        }
         for (auto& kv : transforms) {
             if (index_of_.count(kv.first)) continue;
             uint32_t i;
+            while (!free_.empty() && !is_free_[free_.back()]) free_.pop_back(); // taken back above
             if (!free_.empty()) {
                 i = free_.back();
                 free_.pop_back();
+                is_free_[i] = 0;
             } else {
                 i = static_cast<uint32_t>(ids_.size());
                 ids_.push_back(0);
                 has_tf_.push_back(0);
                 parent_.push_back(BGE_NO_PARENT);
                 body_.emplace_back();
+                is_free_.push_back(0);
                 written_.push_back(0);
                 last_pose_.resize(last_pose_.size() + 6, 0.0f);
             }
@@ -365,7 +385,8 @@ private:
     std::vector<Id> ids_;                       // dense index -> EntityId (0 = free)
     std::unordered_map<Id, uint32_t> index_of_;
     std::vector<uint32_t> parent_, free_, fresh_, index_list_;
-    std::vector<uint8_t> has_tf_, written_, limbo_, seen_;
+    std::vector<uint8_t> has_tf_, written_, limbo_, seen_, is_free_;
+    std::unordered_map<Id, uint32_t> retired_;  // last index of ids that lost their Transform
     std::vector<BodyState> body_;
     std::vector<float> last_pose_;              // position + euler the physics write-back stored (6 floats per index)
     std::vector<float> stage_, repack_;
