@@ -186,7 +186,7 @@ private:
         raw_events_.resize(total);
         if (bge_world_trigger_events(world_, raw_events_.data(), total, &total) != BGE_OK) return Log("bge_world_trigger_events");
         for (const bge_trigger_event& e : raw_events_) {
-            trigger_events_.push_back(GpuTriggerEvent{static_cast<GpuTriggerEvent::Type>(e.type), ids_[e.trigger], ids_[e.other]});
+            trigger_events_.push_back(GpuTriggerEvent{static_cast<GpuTriggerEvent::Type>(e.type), last_ids_[e.trigger], last_ids_[e.other]});
         }
         // one-shot triggers that fired are now inactive (PhysicsSystem.cpp:1062-1071)
         if (!t_entity_.empty()) {
@@ -251,6 +251,7 @@ private:
             const uint32_t i = r->second;
             is_free_[i] = 0;
             ids_[i] = kv.first;
+            last_ids_[i] = kv.first;
             has_tf_[i] = 1;
             written_[i] = 0;
             index_of_[kv.first] = i;
@@ -267,6 +268,7 @@ private:
             } else {
                 i = static_cast<uint32_t>(ids_.size());
                 ids_.push_back(0);
+                last_ids_.push_back(0);
                 has_tf_.push_back(0);
                 parent_.push_back(BGE_NO_PARENT);
                 body_.emplace_back();
@@ -275,6 +277,7 @@ private:
                 last_pose_.resize(last_pose_.size() + 6, 0.0f);
             }
             ids_[i] = kv.first;
+            last_ids_[i] = kv.first; // survives the entity: an Exit event may name a body that was destroyed
             has_tf_[i] = 1;
             written_[i] = 0;
             index_of_[kv.first] = i;
@@ -383,6 +386,7 @@ private:
 
     bge_world* world_ = nullptr;
     std::vector<Id> ids_;                       // dense index -> EntityId (0 = free)
+    std::vector<Id> last_ids_;                  // dense index -> the id it last belonged to
     std::unordered_map<Id, uint32_t> index_of_;
     std::vector<uint32_t> parent_, free_, fresh_, index_list_;
     std::vector<uint8_t> has_tf_, written_, limbo_, seen_, is_free_;

@@ -8,6 +8,7 @@
 // (src/core/Application.cpp:256, 284).  Needs a GPU; run by tests/test_host_adapter.py.
 #include <algorithm>
 #include <array>
+#include <iterator>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -84,6 +85,13 @@ struct Pair {
         std::sort(a.begin(), a.end());
         std::sort(b.begin(), b.end());
         CHECK(a == b, "trigger events differ: %zu (oracle) vs %zu (gpu)", a.size(), b.size());
+        if (a != b) {
+            std::vector<std::array<uint32_t, 3>> only_a, only_b;
+            std::set_difference(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(only_a));
+            std::set_difference(b.begin(), b.end(), a.begin(), a.end(), std::back_inserter(only_b));
+            for (size_t k = 0; k < only_a.size() && k < 6; ++k) std::printf("  only oracle: type %u trigger %u other %u\n", only_a[k][0], only_a[k][1], only_a[k][2]);
+            for (size_t k = 0; k < only_b.size() && k < 6; ++k) std::printf("  only gpu:    type %u trigger %u other %u\n", only_b[k][0], only_b[k][1], only_b[k][2]);
+        }
         events_seen += a.size();
         for (auto& kv : ref.GetTriggerVolumes()) {
             auto* g = gpu.GetTriggerVolume(kv.first);
