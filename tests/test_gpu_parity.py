@@ -483,3 +483,59 @@ def test_trigger_events_match_oracle_every_tick():
             want_active = np.array([ref.TriggerIsActive(int(e) + 1) for e in trig_entities])
             assert np.array_equal(w.trigger_active(trig_entities), want_active), f"tick {tick}: one-shot state"
     assert seen_types == {0, 1, 2}                              # the scene really produced Enter, Stay and Exit
+
+
+def test_transform_fixtures_incl_multi_pass_layouts():
+    """tests/golden/transform_cases.npz on the GPU: flat, chains, subtrees, a forest with Transform-less parents, a
+    600-deep chain (three dependent passes) and a 700-wide root (children in a later pass read the parent from memory)."""
+    z = np.load(os.path.join(GOLD, "transform_cases.npz"))
+    for name in sorted({k.split(".")[0] for k in z.files}):
+        parent, has_tf = z[f"{name}.parent"], z[f"{name}.has_tf"]
+        with B.World() as w:
+            w.set_topology(parent, has_tf)
+            info = w.info()
+            w.upload_trs(z[f"{name}.pos"], z[f"{name}.euler"], z[f"{name}.scale"])
+            w.tick(flags=B.TICK_TRANSFORMS)
+            got = w.download_world()
+            assert w.dirty_count() == 0
+        if name == "deep_chain":
+            assert info["n_passes"] == 3 and info["max_depth"] == 599
+        if name == "wide_root":
+            assert info["n_passes"] == 2
+        want = z[f"{name}.world"].copy()
+        want[has_tf == 0] = 0                      # entities without a Transform have no slot: downloads give zeros
+        assert_bits_equal(got, want, name)
+
+
+def test_parent_cycles_are_parked_and_stay_dirty():
+    """A raw parent array can express a cycle (the reference's SetParent would overflow the stack building one): such
+    entities are never updated and stay dirty, everything else ticks normally."""
+    n = 600
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    parent[1:300] = np.arange(0, 299)             # a chain
+    parent[400], parent[401], parent[402] = 402, 400, 401   # a 3-cycle
+    parent[403] = 400                              # hangs off the cycle: unreachable too
+    pos, euler, scale = synth.trs(3, 0, n)
+    with B.World() as w:
+        w.set_topology(parent)
+        assert w.info()["n_limbo"] == 4
+        w.upload_trs(pos, euler, scale)
+        w.tick(flags=B.TICK_TRANSFORMS)
+        world = w.download_world()
+        dirty = w.download_dirty()
+        assert w.dirty_count() == 4
+    limbo = np.array([400, 401, 402, 403])
+    assert dirty[limbo].all() and not np.delete(dirty, limbo).any()
+    identity = np.eye(4, dtype=np.float32).ravel()
+    assert all(np.array_equal(world[i], identity) for i in limbo)      # untouched since construction
+    ok = np.delete(np.arange(n), limbo)
+    want = npo_world(parent[ok], pos[ok], euler[ok], scale[ok], ok)
+    assert_bits_equal(world[ok], want, "reachable nodes")
+
+
+def npo_world(parent, pos, euler, scale, ids):
+    """np_oracle.resolve_world on a subset whose parents are inside the subset (re-indexed)."""
+    from oracle import np_oracle as npo
+    remap = {int(g): k for k, g in enumerate(ids)}
+    local_parent = np.array([0xFFFFFFFF if p == 0xFFFFFFFF else remap[int(p)] for p in parent], np.uint32)
+    return npo.resolve_world(local_parent, pos, euler, scale)
