@@ -49,6 +49,7 @@ struct TickParams {
     float dt;
     float gx, gy, gz;
     uint32_t tile_begin;
+    uint32_t nt_out; // non-temporal stores for world / normal matrices (working set larger than the Infinity Cache)
     float* root_out; // when non-null: roots also write their world matrix to root_out[root_index] (send buffer of the all-gather)
 };
 

@@ -300,6 +300,7 @@ int download_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, 
 
 namespace {
 constexpr uint32_t kTriggerPairCap = 1u << 20;
+constexpr double kNtThresholdBytes = 300.0e6; // measured crossover between 2 M (plain wins) and 4 M slots (nt wins)
 
 // device mirrors of the trigger set (slots follow the current topology)
 int sync_triggers_to_device(bge_world* w)
@@ -844,6 +845,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
                 p.gx = gravity[0];
                 p.gy = gravity[1];
                 p.gz = gravity[2];
+                p.nt_out = 0; // graph replay is limited to small scenes
                 for (uint32_t t = 0; ok && t < bge_world::kGraphTicks; ++t) {
                     for (size_t pass = 0; ok && pass + 1 < w->flat.pass_tile_begin.size(); ++pass) {
                         p.tile_begin = w->flat.pass_tile_begin[pass];
@@ -884,6 +886,10 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             }
         }
     }
+    // Output stores: non-temporal once the tick's working set (~140 B per slot, 204 B with normal matrices) no longer
+    // fits the 256 MiB Infinity Cache; BGE_NT_STORES=0/1 overrides (experiments)
+    bool nt_out = static_cast<double>(w->flat.n_slots) * ((flags & BGE_TICK_NORMAL_MATRICES) ? 204.0 : 140.0) > kNtThresholdBytes;
+    if (const char* e = std::getenv("BGE_NT_STORES")) nt_out = std::atoi(e) != 0;
     for (uint32_t t = first_eager; t < ticks; ++t) {
         if (!phys && !w->maybe_dirty && !(flags & BGE_TICK_NORMAL_MATRICES)) continue; // TransformSystem::Update with nothing dirty: a no-op scan
         bge::TickParams p{};
@@ -891,6 +897,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         p.gx = gravity ? gravity[0] : 0.0f;
         p.gy = gravity ? gravity[1] : 0.0f;
         p.gz = gravity ? gravity[2] : 0.0f;
+        p.nt_out = nt_out ? 1u : 0u;
         const bool with_triggers = (flags & BGE_TICK_BROADPHASE) && !w->triggers.empty();
         if (with_triggers) {
             ensure_triggers(w);
