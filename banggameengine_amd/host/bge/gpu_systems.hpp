@@ -73,12 +73,48 @@ public:
     bge_world* world() { return world_; }
     float gravity[3] = {0.0f, -9.81f, 0.0f}; // PhysicsSystem.cpp:130 with assets/config/physics.json:2
 
+    // Resident mode: the world matrices stay on the device after TransformSystem::Update; only the host `dirty` flags
+    // are kept coherent and the caller fetches the matrices it needs (FetchWorld) — e.g. the visible set.  Coherent
+    // mode (default) copies every world matrix back each call, which is what makes the adapter a drop-in but also what
+    // bounds it (64 B per entity over PCIe + a hash-map scatter).
+    bool resident = false;
+
+    // world matrices of the given entities straight from the device into their Transform::world
+    bool FetchWorld(SceneT& scene, const std::vector<Id>& entities)
+    {
+        index_list_.clear();
+        for (Id id : entities) {
+            auto it = index_of_.find(id);
+            if (it != index_of_.end()) index_list_.push_back(it->second);
+        }
+        stage_.resize(index_list_.size() * 16);
+        if (!index_list_.empty() &&
+            bge_world_download_world_indexed(world_, index_list_.size(), index_list_.data(), stage_.data()) != BGE_OK) {
+            return Log("bge_world_download_world_indexed");
+        }
+        for (size_t k = 0; k < index_list_.size(); ++k) {
+            if (auto* t = scene.GetTransform(ids_[index_list_[k]])) std::memcpy(t->world, &stage_[16 * k], 64);
+        }
+        return true;
+    }
+
     // --- TransformSystem::Update(Scene&)
     bool UpdateTransforms(SceneT& scene)
     {
         if (!ok() || !RefreshTopology(scene) || !UploadDirtyTransforms(scene)) return false;
         if (bge_world_tick(world_, 0.0f, gravity, BGE_TICK_TRANSFORMS) != BGE_OK) return Log("bge_world_tick");
         const size_t n = ids_.size();
+        if (resident) {
+            limbo_.resize(n);
+            if (n && bge_world_download_dirty(world_, 0, n, limbo_.data()) != BGE_OK) return Log("bge_world_download_dirty");
+            for (auto& kv : scene.GetTransforms()) {
+                const uint32_t i = index_of_[kv.first];
+                if (limbo_[i]) continue;
+                kv.second.dirty = false;
+                written_[i] = 0;
+            }
+            return true;
+        }
         stage_.resize(n * 16);
         if (n && bge_world_download_world(world_, 0, n, stage_.data()) != BGE_OK) return Log("bge_world_download_world");
         limbo_.resize(n);

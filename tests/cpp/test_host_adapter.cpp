@@ -219,6 +219,41 @@ int main()
     for (int k = 0; k < 3; ++k) w.Tick();
 
     CHECK(w.events_seen > 0, "the scripted scene produced no trigger events");
+    // resident mode: nothing is copied back by Update, FetchWorld brings exactly what is asked for
+    {
+        auto& mirror = bge::GpuMirrors<bge::Scene>::Of(w.gpu);
+        mirror.resident = true;
+        std::vector<uint32_t> before_id;
+        std::vector<float> before_world;
+        for (auto& kv : w.gpu.GetTransforms()) {
+            before_id.push_back(kv.first);
+            before_world.insert(before_world.end(), kv.second.world, kv.second.world + 16);
+        }
+        w.refPhysics.Update(w.ref, w.dt);
+        w.gpuPhysics.Update(w.gpu, w.dt);
+        orc::RefTransformSystemUpdate(w.ref);
+        bge::GpuTransformSystem<bge::Scene>::Update(w.gpu);
+        CHECK(w.gpu.CountDirtyTransforms() == w.ref.CountDirtyTransforms(), "resident: dirty counts");
+        size_t untouched = 0;
+        for (size_t k = 0; k < before_id.size(); ++k) {
+            untouched += std::memcmp(w.gpu.GetTransform(before_id[k])->world, &before_world[16 * k], 64) == 0;
+        }
+        CHECK(untouched == before_id.size(), "resident: Update must not copy world matrices back (%zu of %zu untouched)", untouched, before_id.size());
+        std::vector<uint32_t> wanted;
+        for (size_t k = 0; k < before_id.size(); k += 7) wanted.push_back(before_id[k]);
+        CHECK(mirror.FetchWorld(w.gpu, wanted), "FetchWorld");
+        for (uint32_t id : wanted) {
+            CHECK(std::memcmp(w.gpu.GetTransform(id)->world, w.ref.GetTransform(id)->world, 64) == 0, "resident: fetched world of %u", id);
+        }
+        mirror.resident = false;
+        bge::GpuTransformSystem<bge::Scene>::Update(w.gpu); // nothing dirty: must not disturb anything
+        w.refPhysics.Update(w.ref, w.dt);
+        w.gpuPhysics.Update(w.gpu, w.dt);
+        orc::RefTransformSystemUpdate(w.ref);
+        bge::GpuTransformSystem<bge::Scene>::Update(w.gpu);
+        w.CompareAll("back in coherent mode");
+    }
+
     if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, 10 ticks, %zu trigger events)\n", w.gpu.GetTransformCount(), w.events_seen);
     return g_failures ? 1 : 0;
 }
