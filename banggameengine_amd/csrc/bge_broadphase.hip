@@ -454,8 +454,8 @@ struct PairSink {
 // behind the wave's staging cursor (an SGPR-uniform count), and whenever 64 pairs are staged writes them out
 // as one contiguous 512-byte burst behind ONE global atomic.  A single counter word saturates near 10^8
 // atomics/s, so one atomic per hit-bearing iteration (the first version) cost 39 ms for 12.6 M pairs.
-constexpr uint32_t kStage = 320;     // 255 carried + 64 new
-constexpr uint32_t kFlush = 256;     // pairs written per global atomic (4 per lane, 2 KiB contiguous)
+constexpr uint32_t kStage = 192;     // 127 carried + 64 new
+constexpr uint32_t kFlush = 128;     // pairs written per global atomic (2 per lane, 1 KiB contiguous)
 
 // LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the
 // compiler from moving them across the hand-over point.
@@ -523,7 +523,7 @@ __device__ __forceinline__ bool filter_ok(const uint32_t* __restrict__ flags, co
 // fastest); it is staged through LDS in coalesced chunks of kChunk records, and every lane tests only the part of the
 // chunk that belongs to ITS OWN candidate range.  The first version walked the ranges with dependent global loads
 // (one or two candidates in flight per lane) and was latency-bound at 1.45 ms for 4 M bodies.
-constexpr uint32_t kChunk = 512; // records per staged chunk: 24 KiB of LDS
+constexpr uint32_t kChunk = 256; // records per staged chunk: 12 KiB of LDS (with 6 KiB of pair staging: 8 workgroups per CU)
 
 __device__ __forceinline__ bool filter_rec(const float4& a2, const float4& b2)
 {
@@ -596,18 +596,29 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
                 __syncthreads();
                 uint32_t jj = jj0;
                 while (__any(jj < e0)) {
-                    bool hit = false;
-                    uint32_t entity_j = 0;
+                    // two candidates per trip: both LDS fetches are in flight together
+                    bool hit0 = false, hit1 = false;
+                    uint32_t e0j = 0, e1j = 0;
                     if (jj < e0) {
-                        const float4 blo = cand[3u * (jj - base)];
-                        const float4 bhi = cand[3u * (jj - base) + 1u];
-                        if (overlap(lo, hi, blo, bhi)) {
-                            hit = filter_rec(fi, cand[3u * (jj - base) + 2u]);
-                            entity_j = __float_as_uint(blo.w);
+                        const uint32_t k0 = 3u * (jj - base);
+                        const bool two = jj + 1u < e0;
+                        const uint32_t k1 = two ? k0 + 3u : k0;
+                        const float4 alo = cand[k0], ahi = cand[k0 + 1u];
+                        const float4 blo = cand[k1], bhi = cand[k1 + 1u];
+                        if (overlap(lo, hi, alo, ahi)) {
+                            hit0 = filter_rec(fi, cand[k0 + 2u]);
+                            e0j = __float_as_uint(alo.w);
                         }
-                        ++jj;
+                        if (two && overlap(lo, hi, blo, bhi)) {
+                            hit1 = filter_rec(fi, cand[k1 + 2u]);
+                            e1j = __float_as_uint(blo.w);
+                        }
+                        jj += 2u;
                     }
-                    if (__any(hit)) emit_pairs(sink, st, hit, entity_i, entity_j);
+                    if (__any(hit0 || hit1)) {
+                        emit_pairs(sink, st, hit0, entity_i, e0j);
+                        emit_pairs(sink, st, hit1, entity_i, e1j);
+                    }
                 }
                 // (the __syncthreads_or at the top of the next iteration protects cand before it is overwritten)
             }
@@ -788,7 +799,8 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, stream, cell_start, block_sums, scan_n);
     hipLaunchKernelGGL(k_bp_scatter, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, cell_start, body_cell,
                        body_rank, w.group, w.mask, entity_of_slot, sorted);
-    hipLaunchKernelGGL(k_bp_pairs, dim3(std::min<uint32_t>(slot_blocks, 2048)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
+    // persistent grid sized to residency: 18 KiB of LDS per workgroup -> 8 per CU on 256 CUs
+    hipLaunchKernelGGL(k_bp_pairs, dim3(std::min<uint32_t>(slot_blocks, 8 * 256)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
     hipLaunchKernelGGL(k_bp_large, dim3(std::min<uint32_t>(slot_blocks, 4096)), dim3(256), 0, stream, n, acc, large_list,
                        body_cell, w.aabb, w.flags, w.group, w.mask, entity_of_slot, sink);
     hipLaunchKernelGGL(k_bp_compact, dim3(kShards * kCompactParts), dim3(256), 0, stream, acc, static_cast<const uint2*>(scan_stage_),
