@@ -1,6 +1,6 @@
 // bge_kernels.hip — hand-written gfx950 kernels of the world tick.
 //
-// k_tick<PHYS, XFORM, AABB>: one workgroup (4 wave64) per 256-slot tile.
+// k_tick<PHYS, XFORM, AABB, NORMAL>: one workgroup (4 wave64) per 256-slot tile.
 //   PHYS   rigid-body slice of PhysicsSystem::Update for free bodies
 //          (src/physics/PhysicsSystem.cpp:952-989 re-pose rule, :863 one Bullet sub-step,
 //           :916-950 write-back + mark dirty)
