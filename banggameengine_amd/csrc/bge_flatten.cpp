@@ -104,6 +104,13 @@ struct TileBuilder {
         }
         return -1;
     }
+    void reserve()
+    {
+        for (int g = 0; g < 4; ++g) {
+            nodes[g].reserve(kTile);
+            levels[g].reserve(kTile);
+        }
+    }
 };
 
 } // namespace
@@ -118,6 +125,34 @@ FlattenOptions flatten_options_from_env()
 void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, Flattened& out,
                       const FlattenOptions& opt)
 {
+    // Flat scene (no parent links at all, every entity owns a Transform): slot == entity index, wave-local tiles,
+    // no graph needed.  (16 M entities: 0.6 s instead of 5-7 s, which was first-touch of ~1.2 GB of temporaries.)
+    bool flat = has_transform == nullptr;
+    if (flat && parent) {
+        for (uint64_t i = 0; i < n && flat; ++i) flat = parent[i] == kNone || parent[i] >= n;
+    }
+    if (flat) {
+        out = Flattened{};
+        out.n_entities = out.n_transforms = n;
+        out.n_tiles_ticked = out.n_tiles_total = static_cast<uint32_t>((n + kTile - 1) / kTile);
+        out.n_slots = static_cast<uint64_t>(out.n_tiles_total) * kTile;
+        out.slot_of_entity.resize(n);
+        out.root_slots.resize(n);
+        out.entity_of_slot.assign(out.n_slots, kNone);
+        out.parent_field.assign(out.n_slots, kNone);
+        out.flags.assign(out.n_slots, 0);
+        out.pass_of_entity.assign(n, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            out.slot_of_entity[i] = out.root_slots[i] = out.entity_of_slot[i] = static_cast<uint32_t>(i);
+            out.flags[i] = kValid;
+        }
+        out.tile_hdr.assign(out.n_tiles_total, (kTile << kHdrCountShift) | kHdrWaveLocal);
+        if (n % kTile) out.tile_hdr.back() = (static_cast<uint32_t>(n % kTile) << kHdrCountShift) | kHdrWaveLocal;
+        out.pass_tile_begin.assign(1, 0);
+        if (out.n_tiles_total) out.pass_tile_begin.push_back(out.n_tiles_total);
+        return;
+    }
+
     Graph g;
     build_graph(n, parent, has_transform, g);
 
@@ -216,11 +251,29 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
     TileBuilder wl, bk; // the open wave-local tile and the open block tile
     wl.wave_local = true;
     bk.wave_local = false;
+    wl.reserve();
+    bk.reserve();
+    out.tile_hdr.reserve(n / kTile + 8);
+    out.entity_of_slot.reserve(n + 2 * kTile);
+    out.parent_field.reserve(n + 2 * kTile);
+    out.flags.reserve(n + 2 * kTile);
     uint32_t pass = 0;
     while (!pending.empty()) {
         next_pending.clear();
         for (uint32_t r : pending) {
             const uint32_t size = g.subtree[r];
+            if (size == 1) {
+                // singleton (every entity of a flat scene): no walk needed
+                int grp = wl.group_with_room(1);
+                if (grp < 0) {
+                    emit_tile(wl, false);
+                    grp = 0;
+                }
+                wl.nodes[grp].push_back(r);
+                wl.levels[grp].push_back(0);
+                out.pass_of_entity[r] = pass;
+                continue;
+            }
             // destination of the subtree's nodes
             std::vector<uint32_t>* dst_nodes;
             std::vector<uint8_t>* dst_levels;

@@ -46,3 +46,11 @@ def test_scene_json_ingest_then_gpu_ticks():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "with GPU ticks" in r.stdout
+
+
+def test_header_is_plain_c99_and_links():
+    """include/bge_world.h compiled by gcc -std=c99 -pedantic; host-only entry points called from C."""
+    _build()
+    r = subprocess.run([os.path.join(CPP, "abi_check")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi ok" in r.stdout

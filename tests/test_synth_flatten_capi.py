@@ -140,3 +140,40 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(B.BgeError) as e:
         B.World()
     assert "no CPU path" in str(e.value)
+
+
+def test_flatten_invariants_property_based():
+    """hypothesis: arbitrary parent arrays (forward and backward links, cycles, self-parents, missing Transforms)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.integers(1, 700).flatmap(lambda n: st.tuples(
+        st.lists(st.one_of(st.just(NONE), st.integers(0, n - 1)), min_size=n, max_size=n),
+        st.lists(st.booleans(), min_size=n, max_size=n))))
+    def check(case):
+        parent, has_tf = np.array(case[0], np.uint32), np.array(case[1], np.uint8)
+        n = len(parent)
+        slot, level, pas, info = B.flatten_topology(parent, has_tf)
+        ht = has_tf.astype(bool)
+        assert ((slot != NONE) == ht).all()
+        used = slot[slot != NONE]
+        assert len(np.unique(used)) == len(used)
+        # reachability from roots decides between ticked and limbo
+        eff = np.where((parent != NONE) & ht[np.minimum(parent, n - 1)] & (parent < n), parent, NONE)
+        reach = np.zeros(n, bool)
+        reach[ht & (eff == NONE)] = True
+        for _ in range(n):
+            new = ht & ~reach & (eff != NONE) & reach[np.minimum(eff, n - 1)]
+            if not new.any():
+                break
+            reach |= new
+        assert ((pas != NONE) == reach).all()
+        assert info["n_limbo"] == int((ht & ~reach).sum()) and info["n_transforms"] == int(ht.sum())
+        for i in np.flatnonzero(reach & (eff != NONE)):
+            p = eff[i]
+            if slot[p] // 256 == slot[i] // 256:
+                assert level[i] == level[p] + 1 and pas[i] == pas[p]
+            else:
+                assert pas[p] < pas[i] and level[i] == 0
+
+    check()
