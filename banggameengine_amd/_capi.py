@@ -54,6 +54,8 @@ SYMBOLS = {
     "bge_world_download_normal": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_download_bodies": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "bge_world_download_dirty": (C.c_int, [_vp, _u64, _u64, _vp]),
+    "bge_world_download_activation": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
+    "bge_world_set_sleeping": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float]),
     "bge_world_dirty_count": (C.c_int, [_vp, C.POINTER(_u64)]),
     "bge_world_pairs": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "bge_world_upload_triggers": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -93,7 +95,12 @@ def lib():
             pass
         l = C.CDLL(_LIB)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            try:
+                fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            except AttributeError:
+                if os.environ.get("BGE_WORLD_LIB"):  # A/B experiments against an older build: tolerate, fail on use
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = l

@@ -38,9 +38,15 @@ constexpr uint32_t kLevelShift = 8;      // bits 8..15: level inside the tile
 constexpr uint32_t kLevelMask = 0xff00u;
 constexpr uint32_t kParentShift = 16;    // bits 16..23: in-tile index of the parent (when kHasParent && !kExtParent)
 constexpr uint32_t kParentMask = 0xff0000u;
-constexpr uint32_t kMassShift = 24;      // bits 24..31: mass class (index into the world's mass palette);
-constexpr uint32_t kMassMask = 0xff000000u; //            255 = read the per-slot inv_mass array instead
-constexpr uint32_t kMassClassArray = 255;
+constexpr uint32_t kDrowsy = 1u << 24;   // the body's deactivation record is non-zero (timer running, wants to sleep, asleep)
+constexpr uint32_t kMassShift = 25;      // bits 25..31: mass class (index into the world's mass palette);
+constexpr uint32_t kMassMask = 0xfe000000u; //            127 = read the per-slot inv_mass array instead
+constexpr uint32_t kMassClassArray = 127;
+
+// Deactivation record (one 32-bit word per slot, read only while kDrowsy is set): the bits of btCollisionObject's
+// m_deactivationTime (a float >= 0) while the body is ACTIVE_TAG, or one of two negative-NaN sentinels.
+constexpr uint32_t kDeactSleeping = 0xffc00002u; // ISLAND_SLEEPING
+constexpr uint32_t kDeactWants = 0xffc00003u;    // WANTS_DEACTIVATION
 
 // per-tile header word
 constexpr uint32_t kHdrLevelMask = 0xffu;   // max level in the tile

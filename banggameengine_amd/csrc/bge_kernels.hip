@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : 8) k_tick(WorldView w, Tic
 
             if (dynamic) {
                 // mass class -> (inv_mass, 1/inv_mass) from the world's palette (a few distinct masses per scene,
-                // L1/L2-resident); class 255 falls back to the per-slot array
+                // L1/L2-resident); class 127 falls back to the per-slot array
                 const uint32_t cls = f >> kMassShift;
                 float inv_mass, mass;
                 if (cls != kMassClassArray) {
@@ -191,7 +191,22 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : 8) k_tick(WorldView w, Tic
                     inv_mass = w.inv_mass[slot];
                     mass = 1.0f / inv_mass;
                 }
-                if (inv_mass != 0.0f) {
+                // Deactivation record: untouched (and unread) while the body is fast and its timer is zero.
+                // (kDrowsy <=> record != 0; body (re)creation clears the bit: a new btRigidBody is ACTIVE_TAG, timer 0)
+                const uint32_t dz0 = (f & kDrowsy) ? w.deact[slot] : 0u;
+                uint32_t dz = dz0;
+                // buildIslands: a free body is an island of its own; WANTS_DEACTIVATION -> ISLAND_SLEEPING
+                if (dz == kDeactWants) dz = kDeactSleeping;
+                if (inv_mass != 0.0f && dz == kDeactSleeping) {
+                    // asleep: no gravity, not solved, not integrated; updateActivationState zeroes the velocities
+                    v = F3{0.0f, 0.0f, 0.0f};
+                    st3(w.vel, slot, v);
+                    if (spin) {
+                        st3(w.angvel, slot, v);
+                        spin = false;
+                        f &= ~kSpin;
+                    }
+                } else if (inv_mass != 0.0f) {
                     // applyGravity (F = g * (1/invMass)) + solver write-back of the external force impulse
                     v.x = v.x + ((p.gx * mass) * inv_mass) * p.dt;
                     v.y = v.y + ((p.gy * mass) * inv_mass) * p.dt;
@@ -206,7 +221,20 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : 8) k_tick(WorldView w, Tic
                     }
                     st3(w.vel, slot, v);
                     st3(w.pos, slot, pos);
-                } else if (repose) {
+                    // updateActivationState: updateDeactivation + wantsSleeping
+                    const float lin2 = v.x * v.x + v.y * v.y + v.z * v.z;
+                    const float ang2 = av.x * av.x + av.y * av.y + av.z * av.z;
+                    const bool slow = lin2 < p.sleep_lin2 && ang2 < p.sleep_ang2;
+                    if (slow || dz != 0u) {
+                        const float t = slow ? __uint_as_float(dz) + p.dt : 0.0f;
+                        dz = (p.sleep_time != 0.0f && t > p.sleep_time) ? kDeactWants : __float_as_uint(t);
+                    }
+                }
+                if (dz != dz0) {
+                    w.deact[slot] = dz;
+                    f = dz ? (f | kDrowsy) : (f & ~kDrowsy);
+                }
+                if (inv_mass == 0.0f && repose) {
                     st3(w.vel, slot, v);
                 }
                 // SyncRigidBodiesFromPhysics: rotationEuler <- getEulerZYX(basis) whenever the orientation was
@@ -394,7 +422,7 @@ __global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, co
     const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
     uint32_t f = w.flags[slot];
-    f &= ~(kTypeMask | kBDirty | kSpin | kMassMask);
+    f &= ~(kTypeMask | kBDirty | kSpin | kMassMask | kDrowsy); // a (re)created body is ACTIVE_TAG with its timer at zero
     f |= type_bits[i]; // body type, kBDirty and the mass class
     w.flags[slot] = f;
     w.inv_mass[slot] = inv_mass[i];
@@ -448,6 +476,7 @@ __global__ void k_init_slots(uint64_t n_slots, const uint32_t* __restrict__ stru
     w.quat[4 * s] = w.quat[4 * s + 1] = w.quat[4 * s + 2] = 0.0f;
     w.quat[4 * s + 3] = 1.0f;
     w.inv_mass[s] = 0.0f;
+    w.deact[s] = 0u;
     w.half_extent[3 * s] = w.half_extent[3 * s + 1] = w.half_extent[3 * s + 2] = 0.5f;
     w.group[s] = 1u;
     w.mask[s] = 0xffffffffu;

@@ -24,8 +24,9 @@ struct WorldView {
     float* vel;               // [slots][3]
     float* angvel;            // [slots][3]
     float* quat;              // [slots][4]
-    float* inv_mass;          // [slots]     only read for mass class 255 (more than 254 distinct masses)
-    const float2* mass_palette; // [256]     (inv_mass, 1/inv_mass) per mass class
+    float* inv_mass;          // [slots]     only read for mass class 127 (more than 126 distinct masses)
+    const float2* mass_palette; // [128]     (inv_mass, 1/inv_mass) per mass class
+    uint32_t* deact;          // [slots]     deactivation record (bge_flatten.hpp), only touched while a body is slow or asleep
     float* half_extent;       // [slots][3]  AABB half extents of the collider in its own frame
     uint32_t* group;          // [slots]     collision filter group (layer)
     uint32_t* mask;           // [slots]
@@ -48,6 +49,7 @@ struct TriggerView {
 struct TickParams {
     float dt;
     float gx, gy, gz;
+    float sleep_lin2, sleep_ang2, sleep_time; // Bullet's sleeping thresholds (squared) and gDeactivationTime; time 0 = never sleep
     uint32_t tile_begin;
     uint32_t nt_out; // non-temporal stores for world / normal matrices (working set larger than the Infinity Cache)
     float* root_out; // when non-null: roots also write their world matrix to root_out[root_index] (send buffer of the all-gather)

@@ -118,7 +118,15 @@ struct bge_world {
     // device arrays
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
-    DevBuf root_worlds, counter, stage, stage2, mass_palette, normal;
+    DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact;
+    // Bullet's defaults (btRigidBodyConstructionInfo: 0.8 / 1.0; gDeactivationTime 2 s) — the reference never changes them
+    float sleep_lin = 0.8f, sleep_ang = 1.0f, sleep_time = 2.0f;
+    void fill_sleep(bge::TickParams& p) const
+    {
+        p.sleep_lin2 = sleep_lin * sleep_lin;
+        p.sleep_ang2 = sleep_ang * sleep_ang;
+        p.sleep_time = sleep_time;
+    }
     std::vector<float> palette_inv_mass;            // class -> inv_mass (class 0 = 0: Static / Kinematic)
     std::unordered_map<uint32_t, uint32_t> palette_class; // inv_mass bits -> class
     bge::Broadphase broadphase;
@@ -193,6 +201,7 @@ struct bge_world {
         view.mask = mask.as<uint32_t>();
         view.aabb = aabb.as<float>();
         view.mass_palette = mass_palette.as<float2>();
+        view.deact = deact.as<uint32_t>();
         view.root_index = root_index.as<uint32_t>();
         view.normal = normal.as<float>();
     }
@@ -200,7 +209,7 @@ struct bge_world {
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count}) {
             b->release();
         }
@@ -215,7 +224,7 @@ struct bge_world {
 namespace {
 
 // Mass class of an inverse mass: scenes use a handful of distinct masses, so the kernel reads (inv_mass, mass)
-// from a 256-entry palette instead of 4 B per body; the 255th distinct value onwards uses the per-slot array.
+// from a 128-entry palette instead of 4 B per body; the 127th distinct value onwards uses the per-slot array.
 uint32_t mass_class(bge_world* w, float inv_mass, bool& palette_changed)
 {
     uint32_t bits;
@@ -487,7 +496,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     if (n_keep) {
         for (auto [buf, width] : std::initializer_list<std::pair<DevBuf*, uint32_t>>{
                  {&w->pos, 3}, {&w->euler, 3}, {&w->scale, 3}, {&w->world, 16}, {&w->vel, 3}, {&w->angvel, 3},
-                 {&w->quat, 4}, {&w->inv_mass, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6}}) {
+                 {&w->quat, 4}, {&w->inv_mass, 1}, {&w->deact, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6}}) {
             carries.push_back(Carry{buf, width, DevBuf{}});
         }
         for (Carry& c : carries) {
@@ -567,6 +576,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     HIP_TRY(w->angvel.ensure(S * 12));
     HIP_TRY(w->quat.ensure(S * 16));
     HIP_TRY(w->inv_mass.ensure(S * 4));
+    HIP_TRY(w->deact.ensure(S * 4));
     HIP_TRY(w->half_extent.ensure(S * 12));
     HIP_TRY(w->group.ensure(S * 4));
     HIP_TRY(w->mask.ensure(S * 4));
@@ -612,7 +622,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
         std::vector<uint32_t> old_flags(n_keep);
         HIP_TRY(hipMemcpy(old_flags.data(), old_flags_tmp.p, n_keep * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> merged(nf.flags);
-        const uint32_t keep_bits = bge::kTypeMask | bge::kTDirty | bge::kBDirty | bge::kSpin | bge::kMassMask;
+        const uint32_t keep_bits = bge::kTypeMask | bge::kTDirty | bge::kBDirty | bge::kSpin | bge::kMassMask | bge::kDrowsy;
         for (uint64_t s = 0; s < nf.n_slots; ++s) {
             if (merged[s] & bge::kValid) merged[s] |= bge::kTDirty;
         }
@@ -846,6 +856,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
                 p.gy = gravity[1];
                 p.gz = gravity[2];
                 p.nt_out = 0; // graph replay is limited to small scenes
+                w->fill_sleep(p);
                 for (uint32_t t = 0; ok && t < bge_world::kGraphTicks; ++t) {
                     for (size_t pass = 0; ok && pass + 1 < w->flat.pass_tile_begin.size(); ++pass) {
                         p.tile_begin = w->flat.pass_tile_begin[pass];
@@ -898,6 +909,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
         p.gy = gravity ? gravity[1] : 0.0f;
         p.gz = gravity ? gravity[2] : 0.0f;
         p.nt_out = nt_out ? 1u : 0u;
+        w->fill_sleep(p);
         const bool with_triggers = (flags & BGE_TICK_BROADPHASE) && !w->triggers.empty();
         if (with_triggers) {
             ensure_triggers(w);
@@ -1089,6 +1101,47 @@ int bge_world_download_bodies(bge_world* w, uint64_t first, uint64_t count, floa
     if (aabb6) {
         if (int rc = download_rows(w, first, count, 6, w->aabb.p, aabb6)) return rc;
     }
+    return BGE_OK;
+}
+
+int bge_world_download_activation(bge_world* w, uint64_t first, uint64_t count, uint8_t* state, float* time)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    std::vector<uint32_t> rec(count), fl(count);
+    if (int rc = download_rows(w, first, count, 1, w->deact.p, rec.data())) return rc;
+    if (int rc = download_rows(w, first, count, 1, w->flags.p, fl.data())) return rc;
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t type = fl[i] & bge::kTypeMask; // download_rows zero-fills entities without a slot
+        const uint32_t r = (fl[i] & bge::kDrowsy) ? rec[i] : 0u;
+        uint8_t s = BGE_ACTIVATION_NONE;
+        float t = 0.0f;
+        if (type == 1u) s = BGE_ISLAND_SLEEPING;           // addRigidBody puts static objects to sleep
+        else if (type == 3u) s = BGE_DISABLE_DEACTIVATION; // PhysicsSystem.cpp:457
+        else if (type == 2u) {
+            if (r == bge::kDeactSleeping) s = BGE_ISLAND_SLEEPING;
+            else if (r == bge::kDeactWants) s = BGE_WANTS_DEACTIVATION;
+            else {
+                s = BGE_ACTIVE_TAG;
+                std::memcpy(&t, &r, 4);
+            }
+        }
+        if (state) state[i] = s;
+        if (time) time[i] = t;
+    }
+    return BGE_OK;
+}
+
+int bge_world_set_sleeping(bge_world* w, float linear_threshold, float angular_threshold, float seconds)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!(linear_threshold >= 0.0f) || !(angular_threshold >= 0.0f) || !(seconds >= 0.0f))
+        return fail(BGE_ERR_INVALID, "sleeping thresholds must be >= 0");
+    w->sleep_lin = linear_threshold;
+    w->sleep_ang = angular_threshold;
+    w->sleep_time = seconds;
+    w->drop_graph();
     return BGE_OK;
 }
 

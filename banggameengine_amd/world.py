@@ -134,6 +134,17 @@ class World:
         check(lib().bge_world_download_dirty(self._h, first, count, _p(d)))
         return d.astype(bool)
 
+    def download_activation(self, first=0, count=None):
+        """(state, time): bge_activation per entity (0 none, 1 ACTIVE_TAG, 2 ISLAND_SLEEPING, 3 WANTS_DEACTIVATION,
+        4 DISABLE_DEACTIVATION) and Bullet's m_deactivationTime."""
+        count = self.n - first if count is None else count
+        st, tm = np.empty(count, np.uint8), np.empty(count, np.float32)
+        check(lib().bge_world_download_activation(self._h, first, count, _p(st), _p(tm)))
+        return st, tm
+
+    def set_sleeping(self, linear=0.8, angular=1.0, seconds=2.0):
+        check(lib().bge_world_set_sleeping(self._h, linear, angular, seconds))
+
     def dirty_count(self) -> int:
         v = C.c_uint64(0)
         check(lib().bge_world_dirty_count(self._h, C.byref(v)))

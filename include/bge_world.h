@@ -45,6 +45,15 @@ enum bge_status {
 
 /* RigidBodyType (src/ecs/PhysicsComponents.h:20-25) + "entity has no rigid body" */
 enum bge_body_type { BGE_BODY_STATIC = 0, BGE_BODY_DYNAMIC = 1, BGE_BODY_KINEMATIC = 2, BGE_BODY_NONE = 255 };
+/* Bullet's activation states (btCollisionObject.h), as the reference's bodies carry them:
+ * Dynamic bodies are created ACTIVE_TAG, Kinematic ones DISABLE_DEACTIVATION (src/physics/PhysicsSystem.cpp:454-463). */
+enum bge_activation {
+    BGE_ACTIVATION_NONE = 0,
+    BGE_ACTIVE_TAG = 1,
+    BGE_ISLAND_SLEEPING = 2,
+    BGE_WANTS_DEACTIVATION = 3,
+    BGE_DISABLE_DEACTIVATION = 4
+};
 /* ColliderShape (src/ecs/PhysicsComponents.h:7-11) */
 enum bge_shape { BGE_SHAPE_BOX = 0, BGE_SHAPE_CAPSULE = 1 };
 
@@ -183,6 +192,16 @@ BGE_API int bge_world_download_pose_indexed(bge_world* world, uint64_t count, co
 BGE_API int bge_world_download_bodies(bge_world* world, uint64_t first, uint64_t count, float* linvel3,
                                       float* angvel3, float* quat4, float* aabb6);
 BGE_API int bge_world_download_dirty(bge_world* world, uint64_t first, uint64_t count, uint8_t* dirty);
+/* Deactivation ("sleeping") of free bodies, inside stepSimulation (src/physics/PhysicsSystem.cpp:863): a Dynamic body
+ * whose |v| stays below 0.8 and |w| below 1.0 for more than 2 s goes WANTS_DEACTIVATION at the end of that step and
+ * ISLAND_SLEEPING in the next one (a free body is an island of its own); asleep it takes no gravity, is not integrated,
+ * and its velocities are zeroed every step.  Only body (re)creation wakes it (the reference never calls activate()).
+ * state[i] receives a bge_activation; time[i] btCollisionObject::m_deactivationTime while the body is ACTIVE_TAG and 0
+ * otherwise (Bullet keeps a stale value there that nothing reads).  Either pointer may be NULL. */
+BGE_API int bge_world_download_activation(bge_world* world, uint64_t first, uint64_t count, uint8_t* state, float* time);
+/* Thresholds of the above (Bullet's defaults 0.8, 1.0, 2.0 — the reference never changes them).
+ * seconds == 0 disables sleeping (Bullet: gDeactivationTime == 0). */
+BGE_API int bge_world_set_sleeping(bge_world* world, float linear_threshold, float angular_threshold, float seconds);
 /* Scene::CountDirtyTransforms (src/ecs/Scene.cpp:435-446): a device-side wave-reduced count. */
 BGE_API int bge_world_dirty_count(bge_world* world, uint64_t* out);
 /* Overlapping pairs of the last BROADPHASE tick as (a, b) entity indices, a < b, unordered list.

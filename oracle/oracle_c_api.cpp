@@ -169,6 +169,19 @@ void orc_set_physics_options(void* h, float gravityY, int orientMode, int comput
     S(h)->physics.computeAabbs = computeAabbs != 0;
 }
 void orc_transform_update(void* h) { RefTransformSystemUpdate(S(h)->scene); }
+// per-index activation state (0 = no body) and deactivation time of the bodies
+void orc_bulk_get_activation(void* h, uint64_t n, int32_t* state, float* time)
+{
+    auto& rts = S(h)->physics.Runtimes();
+    for (uint64_t i = 0; i < n; ++i) {
+        auto it = rts.find(static_cast<EntityId>(i + 1));
+        const bool ok = it != rts.end() && it->second.hasBody;
+        if (state) state[i] = ok ? it->second.activation : 0;
+        if (time) time[i] = ok ? it->second.deactivationTime : 0.0f;
+    }
+}
+void orc_set_deactivation(void* h, int enabled) { S(h)->physics.deactivation = enabled != 0; }
+
 void orc_physics_update(void* h, double dt) { S(h)->physics.Update(S(h)->scene, dt); }
 uint64_t orc_count_dirty(void* h) { return S(h)->scene.CountDirtyTransforms(); }
 uint64_t orc_transform_count(void* h) { return S(h)->scene.GetTransformCount(); }

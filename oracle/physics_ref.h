@@ -1,8 +1,8 @@
 // oracle/physics_ref.h — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
 //
 // CPU restatement of the rigid-body slice of the reference's PhysicsSystem::Update
-// for FREE bodies (no contacts, no constraints, no ground plane, no sleeping — the
-// scope of SURVEY.md §8 a-10..a-13).  Structure follows the reference's per-tick
+// for FREE bodies (no contacts, no constraints, no ground plane — the scope of SURVEY.md §8
+// a-10..a-13 — plus Bullet's deactivation ("sleeping") of a free body, part of §8(f) rank 4).  Structure follows the reference's per-tick
 // loops over a per-entity runtime hash map so that timing it is a fair "reference
 // CPU path" (it omits Bullet's own broadphase-tree / island / solver bookkeeping, so
 // it is FASTER than the real reference would be — a conservative baseline).
@@ -26,6 +26,18 @@
 //   solver writeback:        v += (totalForce * invMass) * dt          (externalForceImpulse)
 //   integrateTransforms:     x += v * dt; orientation by exponential map
 //   clearForces
+// Deactivation (btCollisionObject activation states; btRigidBody::updateDeactivation / wantsSleeping,
+// btDiscreteDynamicsWorld::updateActivationState, btSimulationIslandManager::buildIslands).  The reference
+// creates Dynamic bodies ACTIVE_TAG and Kinematic ones DISABLE_DEACTIVATION (PhysicsSystem.cpp:454-463), never calls
+// activate() and leaves the thresholds at Bullet's defaults (linear 0.8, angular 1.0, gDeactivationTime 2 s).
+// A free body is an island of its own, so per sub-step:
+//   applyGravity             only if isActive() (state != ISLAND_SLEEPING)
+//   buildIslands             a lone WANTS_DEACTIVATION body is an all-sleeping island -> ISLAND_SLEEPING
+//   solver, integrateTransforms   skipped for a sleeping island / inactive body
+//   updateActivationState    not asleep: |v|^2 < 0.8^2 and |w|^2 < 1^2 ? time += dt : (time = 0, active);
+//                            time > 2 -> WANTS_DEACTIVATION;  asleep: velocities are zeroed every step.
+// Nothing in the free-body scope wakes a sleeping body except re-creation (RigidBody/Collider dirty); a teleport
+// (SyncKinematicBodiesToPhysics) moves it but leaves it asleep, exactly as setWorldTransform does.
 // With dt == fixedStep (src/core/Application.cpp:326, PhysicsSystem.h:77) that is exactly one
 // sub-step per tick; the caller passes that dt.
 //
@@ -52,6 +64,8 @@
 namespace orc {
 
 enum OrientMode : int { kOrientIdeal = 0, kOrientQuat = 1, kOrientBasis = 2 };
+// btCollisionObject.h activation states
+enum Activation : int { kActiveTag = 1, kIslandSleeping = 2, kWantsDeactivation = 3, kDisableDeactivation = 4 };
 
 struct RefBodyRuntime {
     bool hasShape = false;
@@ -67,6 +81,8 @@ struct RefBodyRuntime {
     bt::Vec3 angvel{0, 0, 0};
     float invMass = 0.0f;
     bool freshPose = true; // orientation was (re)posed and not yet written back
+    int activation = 1;           // btCollisionObject::m_activationState1 (ACTIVE_TAG 1 ... DISABLE_DEACTIVATION 4)
+    float deactivationTime = 0.0f; // btCollisionObject::m_deactivationTime
     float aabbMin[3] = {0, 0, 0};
     float aabbMax[3] = {0, 0, 0};
 };
@@ -104,6 +120,9 @@ public:
     float gravityY = -9.81f; // assets/config/physics.json:2, PhysicsSystem.h:87
     int orientMode = kOrientIdeal;
     bool computeAabbs = false;
+    bool deactivation = true; // !gDisableDeactivation
+    float linearSleepingThreshold = 0.8f, angularSleepingThreshold = 1.0f; // btRigidBodyConstructionInfo defaults
+    float deactivationTimeLimit = 2.0f;                                     // gDeactivationTime
 
     std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
     std::unordered_map<EntityId, RefTriggerRuntime>& TriggerRuntimes() { return triggerRuntime_; }
@@ -197,6 +216,12 @@ private:
             rt.angvel = bt::Vec3{0, 0, 0};
             rt.hasBody = true;
             body.dirty = false;
+            // new btRigidBody: ACTIVE_TAG (:462) / DISABLE_DEACTIVATION for Kinematic (:457); addRigidBody puts a
+            // static object to ISLAND_SLEEPING
+            rt.activation = body.type == RefBodyType::Kinematic ? kDisableDeactivation
+                            : body.type == RefBodyType::Static  ? kIslandSleeping
+                                                                : kActiveTag;
+            rt.deactivationTime = 0.0f;
         }
         rt.type = body.type;
         rt.layer = desiredLayer;
@@ -249,6 +274,16 @@ private:
             }
             if (!dynamic) continue;
 
+            // buildIslands: a free body is a one-body island; "all sleeping" unless ACTIVE_TAG / DISABLE_DEACTIVATION
+            if (rt.activation == kWantsDeactivation) rt.activation = kIslandSleeping;
+            if (rt.activation == kIslandSleeping) {
+                // no gravity (it was asleep when applyGravity ran, or its force is dropped by clearForces), not solved,
+                // not integrated; updateActivationState zeroes the velocities of a sleeping body every step
+                rt.linvel = bt::Vec3{0, 0, 0};
+                rt.angvel = bt::Vec3{0, 0, 0};
+                continue;
+            }
+
             // applyGravity + solver write-back of the external force impulse
             const float massInv = 1.0f / rt.invMass;
             const bt::Vec3 force{g.x * massInv, g.y * massInv, g.z * massInv};
@@ -263,6 +298,21 @@ private:
                 rt.orn = bt::IntegrateOrientation(CurrentOrn(rt), rt.angvel, dt);
                 rt.basis = bt::MatFromQuat(rt.orn);
                 rt.freshPose = true;
+            }
+
+            // updateActivationState: updateDeactivation + wantsSleeping (state is ACTIVE_TAG here)
+            if (rt.activation != kDisableDeactivation) {
+                const float lin2 = rt.linvel.x * rt.linvel.x + rt.linvel.y * rt.linvel.y + rt.linvel.z * rt.linvel.z;
+                const float ang2 = rt.angvel.x * rt.angvel.x + rt.angvel.y * rt.angvel.y + rt.angvel.z * rt.angvel.z;
+                if (lin2 < linearSleepingThreshold * linearSleepingThreshold &&
+                    ang2 < angularSleepingThreshold * angularSleepingThreshold) {
+                    rt.deactivationTime = rt.deactivationTime + dt;
+                } else {
+                    rt.deactivationTime = 0.0f;
+                }
+                // wantsSleeping: never while gDisableDeactivation or gDeactivationTime == 0
+                if (deactivation && deactivationTimeLimit != 0.0f && rt.deactivationTime > deactivationTimeLimit)
+                    rt.activation = kWantsDeactivation;
             }
         }
     }

@@ -342,6 +342,17 @@ class RefScene:
         lib().orc_bulk_get_bodies(self.h, C.c_uint64(n), _vp(o), _vp(q), _vp(v), _vp(w), _vp(bb), _vp(ex))
         return dict(origin=o, quat=q, linvel=v, angvel=w, aabb=bb, exists=ex.astype(bool))
 
+    def bulk_activation(self):
+        """(state, time): Bullet activation state per entity index (0 = no body, 1 ACTIVE_TAG, 2 ISLAND_SLEEPING,
+        3 WANTS_DEACTIVATION, 4 DISABLE_DEACTIVATION) and m_deactivationTime."""
+        n = self.n
+        st, tm = np.empty(n, np.int32), np.empty(n, np.float32)
+        lib().orc_bulk_get_activation(self.h, C.c_uint64(n), _vp(st), _vp(tm))
+        return st, tm
+
+    def set_deactivation(self, enabled):
+        lib().orc_set_deactivation(self.h, C.c_int(1 if enabled else 0))
+
     def pairs(self, method="sweep", cap=None):
         cap = cap or max(1024, 64 * self.n)
         out = np.empty((cap, 2), np.uint32)

@@ -563,3 +563,92 @@ def test_long_run_stays_bit_identical():
     assert_bits_equal(got[3]["quat"][has_body], rb["quat"][has_body], "quaternion")
     assert_bits_equal(got[3]["linvel"][has_body], rb["linvel"][has_body], "velocity")
     assert_bits_equal(got[0], ref.bulk_world()[0], "world")
+
+
+def test_free_bodies_fall_asleep_like_the_oracle():
+    """Bullet's deactivation of free bodies (§8(f) rank 4, the sleeping part): zero gravity, a mix of slow, fast and
+    slowly spinning bodies (plus statics / kinematics / plain transforms), compared every few ticks across the 2 s limit:
+    activation state, deactivation timer, pose, velocities and world matrices, all bit for bit."""
+    n = 3000
+    wl = synth.config("flat10k", n=n)
+    rng = np.random.default_rng(11)
+    wl.body_type[:] = rng.choice([1, 1, 1, 1, 0, 2, 255], n).astype(np.uint8)
+    speed = rng.choice([0.0, 0.2, 0.7, 0.79, 0.81, 1.5], n).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    vel = (d * speed[:, None]).astype(np.float32)
+    angvel = np.zeros((n, 3), np.float32)
+    spin = rng.random(n) < 0.3
+    angvel[spin] = (rng.normal(size=(int(spin.sum()), 3)) * 0.6).astype(np.float32)  # |w| straddles 1.0
+    vel[wl.body_type != 1] = 0  # only Dynamic bodies carry velocity through the C ABI
+    angvel[wl.body_type != 1] = 0
+    g0 = (0.0, 0.0, 0.0)
+
+    ref = build_oracle(wl)
+    ref.SetPhysicsOptions(0.0, po.ORIENT_IDEAL, True)
+    with B.World() as w:
+        w.load(wl)
+
+        def frame(k):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, gravity=g0, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+
+        def compare(k):
+            st, tm = w.download_activation()
+            rst, rtm = ref.bulk_activation()
+            assert np.array_equal(st, rst.astype(np.uint8)), (k, np.argwhere(st != rst)[:5].tolist())
+            # the timer is reported while a body is ACTIVE_TAG; Bullet keeps a stale value afterwards that nothing reads
+            assert_bits_equal(tm, np.where(rst == 1, rtm, 0).astype(np.float32), f"deactivation time @ {k}")
+            pos, eul = w.download_pose()
+            assert_bits_equal(pos, ref.bulk_pose()[0], f"position @ {k}")
+            assert_bits_equal(eul, ref.bulk_pose()[1], f"rotationEuler @ {k}")
+            gb, rb = w.download_bodies(), ref.bulk_bodies()
+            ex = rb["exists"]
+            assert_bits_equal(gb["linvel"][ex], rb["linvel"][ex], f"velocity @ {k}")
+            assert_bits_equal(gb["angvel"][ex], rb["angvel"][ex], f"angular velocity @ {k}")
+            assert_bits_equal(gb["aabb"][ex], rb["aabb"][ex], f"aabb @ {k}")
+            assert_bits_equal(w.download_world(), ref.bulk_world()[0], f"world @ {k}")
+            return st
+
+        frame(0)
+        ref.bulk_set_velocity(vel, angvel)
+        w.set_velocities(vel, angvel)
+        seen = set()
+        for k in range(1, 262):
+            frame(k)
+            if k % 40 == 0 or k >= 236:
+                seen |= set(np.unique(compare(k)).tolist())
+        assert {0, 1, 2, 3, 4} <= seen  # none, active, asleep, wants-deactivation (ticks 239/240), kinematic
+        st = compare(261)
+        dyn = wl.body_type == 1
+        slow = dyn & (speed < 0.8) & (np.linalg.norm(angvel, axis=1) < 0.99)
+        fast = dyn & (speed > 0.8)
+        assert (st[slow] == 2).all() and (st[fast] == 1).all()
+
+        # a sleeping body: teleport keeps it asleep, a velocity is wiped by the next step, re-creation wakes it
+        asleep = np.flatnonzero((st == 2) & dyn)[:3]
+        a, b, c = (int(x) for x in asleep)
+        p = np.array([[1.0, 2.0, 3.0]], np.float32)
+        w.upload_trs(pos=p, first=a)
+        ref.bulk_set_trs(a, pos=p)
+        one = np.array([[3.0, 0.0, 0.0]], np.float32)
+        w.set_velocities(one, np.zeros((1, 3), np.float32), first=b)
+        ref.SetVelocity(b + 1, one[0])
+        w.upload_bodies(np.array([1], np.uint8), first=c)
+        ref.MarkBodyDirty(c + 1)
+        g = (0.0, -9.81, 0.0)
+        ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, True)
+        for k in range(262, 266):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, gravity=g, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+            st = compare(k)
+        assert st[a] == 2 and st[b] == 2 and st[c] == 1
+
+        # sleeping switched off (gDeactivationTime == 0): nothing new falls asleep, timers keep running
+        w.set_sleeping(0.8, 1.0, 0.0)
+        w.upload_bodies(wl.body_type)
+        w.tick(dt=DT, gravity=g0, ticks=300)
+        st, tm = w.download_activation()
+        assert not (st[dyn] == 2).any() and tm[dyn].max() > 2.0

@@ -59,3 +59,114 @@ def test_box_margin_arithmetic():
     # tiny box: safe margin 0.1*min(he) replaces 0.04 (btConvexInternalShape::setSafeMargin)
     he = po.box_aabb_half_extents([0.01, 0.2, 0.2])
     assert np.allclose(he, [0.01, 0.2, 0.2], atol=1e-6)
+
+
+# ---------------------------------------------------------------- deactivation ("sleeping") of free bodies
+def _step(ref):
+    """One frame as Application::Update runs it: physics, then TransformSystem::Update (which clears Transform::dirty —
+    without it the teleport rule would re-pose the body and zero its velocity every tick)."""
+    ref.PhysicsSystemUpdate(DT)
+    ref.TransformSystemUpdate()
+
+
+def _one_body(gravity_y, vel, angvel=(0, 0, 0)):
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(gravity_y, po.ORIENT_IDEAL, False)
+    e = ref.CreateEntity()
+    ref.AddTransform(e, pos=(0, 10, 0))
+    ref.AddCollider(e)
+    ref.AddRigidBody(e, body_type=po.BODY_DYNAMIC, mass=1.0)
+    ref.n = 1
+    _step(ref)  # creates the body (zero velocity)
+    ref.SetVelocity(e, vel, angvel)
+    return ref, e
+
+
+DT = float(np.float32(0.0083333333))
+
+
+def _ticks_until_time_exceeds(limit=2.0):
+    """m_deactivationTime += timeStep in binary32, first k with time > limit."""
+    t, k = np.float32(0), 0
+    while not t > np.float32(limit):
+        t = np.float32(t + np.float32(DT))
+        k += 1
+    return k
+
+
+def test_slow_free_body_falls_asleep_like_bullet():
+    """Zero gravity, |v| = 0.5 < 0.8: the timer runs, exceeds 2 s -> WANTS_DEACTIVATION at the end of that step,
+    ISLAND_SLEEPING (not integrated, velocities zeroed) from the next step on."""
+    ref, e = _one_body(0.0, (0.5, 0, 0))
+    k_wants = _ticks_until_time_exceeds() - 1  # the creating tick in _one_body (zero velocity) already counted
+    assert k_wants in (239, 240)
+    xs = []
+    for k in range(1, k_wants + 6):
+        _step(ref)
+        st, tm = ref.bulk_activation()
+        o = ref.GetBody(e)
+        xs.append(o["origin"][0])
+        if k < k_wants:
+            assert st[0] == 1 and tm[0] > 0, k
+        elif k == k_wants:
+            assert st[0] == 3 and np.all(o["linvel"] == [0.5, 0, 0])  # still moving during the step it decides to sleep
+        else:
+            assert st[0] == 2 and np.all(o["linvel"] == 0), k
+    # integrated on every step up to and including k_wants, frozen afterwards
+    assert xs[k_wants - 1] > xs[k_wants - 2]
+    assert all(x == xs[k_wants - 1] for x in xs[k_wants:])
+    # Transform::dirty is still set every tick (SyncRigidBodiesFromPhysics marks every Dynamic body, asleep or not)
+    ref.PhysicsSystemUpdate(DT)
+    assert ref.GetTransform(e)["dirty"]
+
+
+def test_fast_or_spinning_body_never_sleeps_and_timer_resets():
+    ref, e = _one_body(0.0, (0.9, 0, 0))
+    for _ in range(300):
+        _step(ref)
+    st, tm = ref.bulk_activation()
+    assert st[0] == 1 and tm[0] == 0
+    # slow linear but fast angular velocity (|w| >= 1): awake
+    ref, e = _one_body(0.0, (0.1, 0, 0), (0, 1.0, 0))
+    for _ in range(300):
+        _step(ref)
+    assert ref.bulk_activation()[0][0] == 1
+    # the timer restarts when the body speeds up
+    ref, e = _one_body(0.0, (0.1, 0, 0))
+    for _ in range(100):
+        _step(ref)
+    assert ref.bulk_activation()[1][0] > 0.8
+    ref.SetVelocity(e, (2, 0, 0))
+    _step(ref)
+    assert ref.bulk_activation()[1][0] == 0
+
+
+def test_gravity_workloads_never_sleep():
+    """Under g = -9.81 a body is slower than 0.8 for at most 0.16 s: the synthetic workloads are unaffected."""
+    wl = synth.config("flat10k", n=512)
+    ref = run_oracle(build_oracle(wl), wl, 300)
+    st, tm = ref.bulk_activation()
+    assert (st == 1).all() and (tm == 0).all()
+
+
+def test_sleeping_body_stays_asleep_when_teleported_wakes_when_recreated():
+    ref, e = _one_body(0.0, (0.0, 0, 0))
+    for _ in range(_ticks_until_time_exceeds() + 2):
+        _step(ref)
+    assert ref.bulk_activation()[0][0] == 2
+    ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, False)  # gravity does not touch a sleeping body
+    ref.SetTRS(e, pos=(5, 5, 5))                          # teleport: setWorldTransform, no activate()
+    _step(ref)
+    assert ref.bulk_activation()[0][0] == 2
+    assert np.all(ref.GetBody(e)["origin"] == [5, 5, 5])
+    ref.MarkBodyDirty(e)                                  # re-created: a new btRigidBody is ACTIVE_TAG
+    _step(ref)
+    assert ref.bulk_activation()[0][0] == 1
+    assert ref.GetBody(e)["origin"][1] < 5
+    # sleeping disabled (gDisableDeactivation): timer runs, state stays active
+    ref, e = _one_body(0.0, (0, 0, 0))
+    ref.set_deactivation(False)
+    for _ in range(300):
+        _step(ref)
+    st, tm = ref.bulk_activation()
+    assert st[0] == 1 and tm[0] > 2
