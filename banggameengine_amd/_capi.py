@@ -57,6 +57,14 @@ SYMBOLS = {
     "bge_world_download_activation": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
     "bge_world_set_sleeping": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float]),
     "bge_world_dirty_count": (C.c_int, [_vp, C.POINTER(_u64)]),
+    "bge_world_set_global_ids": (C.c_int, [_vp, _u64, _u64, _vp]),
+    "bge_world_aabb_bounds": (C.c_int, [_vp, _vp, _vp, C.POINTER(_u64)]),
+    "bge_world_axis_histogram": (C.c_int, [_vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32, _vp]),
+    "bge_balanced_cuts": (C.c_int, [_vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32, _vp]),
+    "bge_world_bp_route": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "bge_world_bp_pack": (C.c_int, [_vp, _vp]),
+    "bge_world_bp_find": (C.c_int, [_vp, _vp, _u64, C.c_uint32, C.c_float, C.c_float]),
+    "bge_world_bp_exchange": (C.c_int, [_vp, C.c_uint32]),
     "bge_world_pairs": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "bge_world_upload_triggers": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bge_world_trigger_events": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),

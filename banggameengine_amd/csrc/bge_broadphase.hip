@@ -448,7 +448,18 @@ struct PairSink {
     unsigned long long* shard_count; // [kShards][8]
     uint2* pairs;                    // staging: kShards slices of shard_cap pairs
     uint64_t shard_cap;
+    // Slab window of the sharded broadphase (PairWindow): a pair is reported only where the lower end of its overlap
+    // interval along `axis`, max(min_a, min_b), falls into [win_lo, win_hi).  (-inf, +inf) = report everything.
+    uint32_t axis;
+    float win_lo, win_hi;
 };
+
+__device__ __forceinline__ float axis_of(const float4& v, uint32_t axis) { return axis == 0u ? v.x : (axis == 1u ? v.y : v.z); }
+__device__ __forceinline__ bool in_window(const PairSink& s, const float4& alo, const float4& blo)
+{
+    const float m = fmaxf(axis_of(alo, s.axis), axis_of(blo, s.axis));
+    return m >= s.win_lo && m < s.win_hi;
+}
 
 // Wave-compacted append with per-wave staging in LDS.  Each call ballots the hits of the wave, packs them
 // behind the wave's staging cursor (an SGPR-uniform count), and whenever 64 pairs are staged writes them out
@@ -531,6 +542,9 @@ __device__ __forceinline__ bool filter_rec(const float4& a2, const float4& b2)
     return !both_static && (__float_as_uint(a2.x) & __float_as_uint(b2.y)) != 0u && (__float_as_uint(b2.x) & __float_as_uint(a2.y)) != 0u;
 }
 
+// WINDOW: apply the slab window of the sharded broadphase (a second instantiation keeps the single-GPU search free of it:
+// the extra sink fields cost ~5 % there, measured)
+template <bool WINDOW>
 __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ sorted, PairSink sink)
 {
@@ -606,11 +620,11 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
                         const float4 alo = cand[k0], ahi = cand[k0 + 1u];
                         const float4 blo = cand[k1], bhi = cand[k1 + 1u];
                         if (overlap(lo, hi, alo, ahi)) {
-                            hit0 = filter_rec(fi, cand[k0 + 2u]);
+                            hit0 = filter_rec(fi, cand[k0 + 2u]) && (!WINDOW || in_window(sink, lo, alo));
                             e0j = __float_as_uint(alo.w);
                         }
                         if (two && overlap(lo, hi, blo, bhi)) {
-                            hit1 = filter_rec(fi, cand[k1 + 2u]);
+                            hit1 = filter_rec(fi, cand[k1 + 2u]) && (!WINDOW || in_window(sink, lo, blo));
                             e1j = __float_as_uint(blo.w);
                         }
                         jj += 2u;
@@ -658,7 +672,7 @@ __global__ void __launch_bounds__(256) k_bp_large(uint64_t n_slots, const Accum*
             const float4 llo = make_float4(b[0], b[1], b[2], 0), lhi = make_float4(b[3], b[4], b[5], 0);
             // large-vs-small: reported from the small body's side; large-vs-large: from the lower slot's side
             bool hit = body && s != L && (!s_large || s < L) && overlap(lo, hi, llo, lhi);
-            if (hit) hit = filter_ok(flags, group, mask, static_cast<uint32_t>(s), L);
+            if (hit) hit = filter_ok(flags, group, mask, static_cast<uint32_t>(s), L) && in_window(sink, lo, llo);
             emit_pairs(sink, st, hit, hit ? entity_of_slot[s] : 0u, hit ? entity_of_slot[L] : 0u);
         }
     }
@@ -761,7 +775,7 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
     return BGE_OK;
 }
 
-int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const uint32_t* entity_of_slot)
+int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const uint32_t* entity_of_slot, const PairWindow* window)
 {
     if (n > n_slots_) {
         error_ = "broadphase not configured for this many slots";
@@ -776,7 +790,8 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     uint32_t* large_list = static_cast<uint32_t*>(large_list_);
     float4* sorted = static_cast<float4*>(sorted_aabb_);
     const uint64_t shard_cap = shard_capacity(capacity_);
-    const PairSink sink{&acc->shard_count[0][0], static_cast<uint2*>(scan_stage_), shard_cap};
+    const PairSink sink{&acc->shard_count[0][0], static_cast<uint2*>(scan_stage_), shard_cap,
+                        window ? window->axis : 0u, window ? window->lo : -INFINITY, window ? window->hi : INFINITY};
     ran_ = true;
     if (n == 0) {
         BP_TRY(hipMemsetAsync(counters_, 0, sizeof(Accum), stream));
@@ -800,7 +815,11 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     hipLaunchKernelGGL(k_bp_scatter, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, cell_start, body_cell,
                        body_rank, w.group, w.mask, entity_of_slot, sorted);
     // persistent grid sized to residency: 18 KiB of LDS per workgroup -> 8 per CU on 256 CUs
-    hipLaunchKernelGGL(k_bp_pairs, dim3(std::min<uint32_t>(slot_blocks, 8 * 256)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
+    if (window) {
+        hipLaunchKernelGGL(k_bp_pairs<true>, dim3(std::min<uint32_t>(slot_blocks, 8 * 256)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
+    } else {
+        hipLaunchKernelGGL(k_bp_pairs<false>, dim3(std::min<uint32_t>(slot_blocks, 8 * 256)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
+    }
     hipLaunchKernelGGL(k_bp_large, dim3(std::min<uint32_t>(slot_blocks, 4096)), dim3(256), 0, stream, n, acc, large_list,
                        body_cell, w.aabb, w.flags, w.group, w.mask, entity_of_slot, sink);
     hipLaunchKernelGGL(k_bp_compact, dim3(kShards * kCompactParts), dim3(256), 0, stream, acc, static_cast<const uint2*>(scan_stage_),

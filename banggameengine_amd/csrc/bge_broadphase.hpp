@@ -10,12 +10,19 @@
 
 namespace bge {
 
+// Slab window of the sharded broadphase: report a pair only where max(min_a[axis], min_b[axis]) is in [lo, hi).
+struct PairWindow {
+    uint32_t axis;
+    float lo, hi;
+};
+
 class Broadphase {
 public:
     // n_slots: upper bound of bodies; pair_capacity: pairs kept per tick
     int configure(uint64_t n_slots, uint64_t pair_capacity);
     // Collect the overlapping pairs of the AABBs the tick kernel just wrote.
-    int run(hipStream_t stream, const WorldView& w, uint64_t n_slots_ticked, const uint32_t* entity_of_slot);
+    int run(hipStream_t stream, const WorldView& w, uint64_t n_slots_ticked, const uint32_t* entity_of_slot,
+            const PairWindow* window = nullptr);
     int download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uint64_t* total);
     void release();
     const char* error() const { return error_.c_str(); }

@@ -25,6 +25,11 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -46,7 +51,13 @@ Rccl& rccl()
         x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
-        if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.CommDestroy || !x.GetErrorString) {
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(x.handle, "ncclAllReduce"));
+        x.Send = reinterpret_cast<decltype(x.Send)>(dlsym(x.handle, "ncclSend"));
+        x.Recv = reinterpret_cast<decltype(x.Recv)>(dlsym(x.handle, "ncclRecv"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.handle, "ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.handle, "ncclGroupEnd"));
+        if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.CommDestroy || !x.GetErrorString || !x.AllReduce || !x.Send ||
+            !x.Recv || !x.GroupStart || !x.GroupEnd) {
             x.why = "librccl is missing an expected symbol";
             x.handle = nullptr;
         }
@@ -149,6 +160,55 @@ int RootComm::wait(hipStream_t compute)
     for (int b = 0; b < kRing; ++b) {
         if (in_flight_[b]) COMM_HIP(hipStreamWaitEvent(compute, gathered_[b], 0));
     }
+    return BGE_OK;
+}
+
+int RootComm::all_reduce_max(hipStream_t stream, float* device_values, size_t n)
+{
+    if (!comm_) return fail(BGE_ERR_STATE, "communicator not initialised");
+    COMM_NCCL(rccl().AllReduce(device_values, device_values, n, ncclFloat32, ncclMax, static_cast<ncclComm_t>(comm_), stream));
+    return BGE_OK;
+}
+
+int RootComm::all_reduce_sum_u64(hipStream_t stream, uint64_t* device_values, size_t n)
+{
+    if (!comm_) return fail(BGE_ERR_STATE, "communicator not initialised");
+    COMM_NCCL(rccl().AllReduce(device_values, device_values, n, ncclUint64, ncclSum, static_cast<ncclComm_t>(comm_), stream));
+    return BGE_OK;
+}
+
+int RootComm::all_gather_bytes(hipStream_t stream, const void* send_device, void* recv_device, size_t bytes_per_rank)
+{
+    if (!comm_) return fail(BGE_ERR_STATE, "communicator not initialised");
+    COMM_NCCL(rccl().AllGather(send_device, recv_device, bytes_per_rank, ncclUint8, static_cast<ncclComm_t>(comm_), stream));
+    return BGE_OK;
+}
+
+int RootComm::all_to_all_v(hipStream_t stream, const void* send_device, const uint64_t* send_counts, void* recv_device,
+                           const uint64_t* recv_counts, size_t elem_bytes)
+{
+    if (!comm_) return fail(BGE_ERR_STATE, "communicator not initialised");
+    if (elem_bytes % 4) return fail(BGE_ERR_INVALID, "element size must be a multiple of 4 bytes");
+    const size_t words = elem_bytes / 4;
+    const char* s = static_cast<const char*>(send_device);
+    char* r = static_cast<char*>(recv_device);
+    COMM_NCCL(rccl().GroupStart());
+    size_t so = 0, ro = 0;
+    ncclResult_t first_error = ncclSuccess;
+    for (int p = 0; p < nranks_; ++p) {
+        if (send_counts[p]) {
+            const ncclResult_t e = rccl().Send(s + so * elem_bytes, send_counts[p] * words, ncclUint32, p, static_cast<ncclComm_t>(comm_), stream);
+            if (e != ncclSuccess && first_error == ncclSuccess) first_error = e;
+        }
+        if (recv_counts[p]) {
+            const ncclResult_t e = rccl().Recv(r + ro * elem_bytes, recv_counts[p] * words, ncclUint32, p, static_cast<ncclComm_t>(comm_), stream);
+            if (e != ncclSuccess && first_error == ncclSuccess) first_error = e;
+        }
+        so += send_counts[p];
+        ro += recv_counts[p];
+    }
+    COMM_NCCL(rccl().GroupEnd()); // always close the group, even after a failed call inside it
+    if (first_error != ncclSuccess) return fail(BGE_ERR_HIP, std::string("ncclSend/ncclRecv: ") + rccl().GetErrorString(first_error));
     return BGE_OK;
 }
 

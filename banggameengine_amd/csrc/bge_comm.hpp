@@ -27,6 +27,16 @@ public:
     // Enqueue the all-gather of this frame's send buffer on the side stream (after everything queued on `compute`).
     int gather(hipStream_t compute, void** table_device);
     int wait(hipStream_t compute);
+    int rank() const { return rank_; }
+    // Small helpers of the sharded broadphase (bge_route.hip), all enqueued on `stream`:
+    int all_reduce_max(hipStream_t stream, float* device_values, size_t n);
+    int all_reduce_sum_u64(hipStream_t stream, uint64_t* device_values, size_t n);
+    int all_gather_bytes(hipStream_t stream, const void* send_device, void* recv_device, size_t bytes_per_rank);
+    // Variable-size exchange: counts are in elements of elem_bytes (a multiple of 4); peer p's block starts at the sum of
+    // the counts before it.  One ncclSend + ncclRecv per peer inside one group: every pair of ranks talks over its own
+    // xGMI link, there is no ring.
+    int all_to_all_v(hipStream_t stream, const void* send_device, const uint64_t* send_counts, void* recv_device,
+                     const uint64_t* recv_counts, size_t elem_bytes);
     void destroy();
     const char* error() const { return error_.c_str(); }
 

@@ -55,7 +55,7 @@ struct TickParams {
     float* root_out; // when non-null: roots also write their world matrix to root_out[root_index] (send buffer of the all-gather)
 };
 
-// flags: bit0 physics, bit1 transforms, bit2 aabb, bit4 normal matrices (bge_tick_flags)
+// flags: bit0 physics, bit1 transforms, bit2 / bit5 aabb, bit4 normal matrices (bge_tick_flags)
 hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams& p, uint32_t n_tiles, uint32_t flags);
 
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "bge_broadphase.hpp"
+#include "bge_route.hpp"
 #include "bge_comm.hpp"
 #include "bge_flatten.hpp"
 #include "bge_kernels.hpp"
@@ -130,6 +131,13 @@ struct bge_world {
     std::vector<float> palette_inv_mass;            // class -> inv_mass (class 0 = 0: Static / Kinematic)
     std::unordered_map<uint32_t, uint32_t> palette_class; // inv_mass bits -> class
     bge::Broadphase broadphase;
+    // sharded broadphase (bge_route.hip): records routed to spatial slabs, pair search over what was received
+    bge::ShardRouter router;
+    bge::Broadphase slab_broadphase;
+    bool pairs_from_slab = false;          // bge_world_pairs reads the slab search (global ids) instead of the local one
+    std::vector<uint32_t> global_id_host;  // per entity index; empty = identity
+    DevBuf global_of_slot, bp_send, bp_recv, bp_small, bp_hist;
+    bool global_of_slot_stale = true;
     bge::RootComm comm;
     bge::WorldView view{};
 
@@ -214,6 +222,9 @@ struct bge_world {
             b->release();
         }
         broadphase.release();
+        slab_broadphase.release();
+        router.release();
+        for (DevBuf* b : {&global_of_slot, &bp_send, &bp_recv, &bp_small, &bp_hist}) b->release();
         comm.destroy();
         drop_graph();
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
@@ -648,6 +659,8 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     w->has_topology = true;
     w->maybe_dirty = true;
     w->triggers_device_stale = true; // slots moved
+    w->global_of_slot_stale = true;
+    w->pairs_from_slab = false;
     return BGE_OK;
 }
 
@@ -809,8 +822,8 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     if ((flags & (BGE_TICK_PHYSICS | BGE_TICK_TRANSFORMS)) == 0) return fail(BGE_ERR_INVALID, "tick flags select nothing");
-    if ((flags & BGE_TICK_BROADPHASE) && !(flags & BGE_TICK_PHYSICS)) {
-        return fail(BGE_ERR_INVALID, "BGE_TICK_BROADPHASE needs BGE_TICK_PHYSICS (the AABBs come from the physics step)");
+    if ((flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS)) && !(flags & BGE_TICK_PHYSICS)) {
+        return fail(BGE_ERR_INVALID, "BGE_TICK_BROADPHASE / BGE_TICK_AABBS need BGE_TICK_PHYSICS (the AABBs come from the physics step)");
     }
     if ((flags & BGE_TICK_PHYSICS) && !gravity) return fail(BGE_ERR_INVALID, "gravity is NULL");
     if ((flags & BGE_TICK_NORMAL_MATRICES) && !(flags & BGE_TICK_TRANSFORMS)) {
@@ -841,7 +854,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
     uint32_t first_eager = 0;
     const bool use_graph = std::getenv("BGE_USE_GRAPH") != nullptr;
     if (use_graph && !w->graph_disabled && phys && ticks >= 2 * bge_world::kGraphTicks && w->profiling != 2 &&
-        !(flags & (BGE_TICK_BROADPHASE | BGE_TICK_GATHER_ROOTS)) && w->flat.n_tiles_ticked <= bge_world::kGraphMaxTiles &&
+        !(flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS | BGE_TICK_GATHER_ROOTS)) && w->flat.n_tiles_ticked <= bge_world::kGraphMaxTiles &&
         w->flat.n_tiles_ticked > 0) {
         const bool same = w->graph_exec && w->graph_flags == flags && w->graph_dt == dt && w->graph_g[0] == gravity[0] &&
                           w->graph_g[1] == gravity[1] && w->graph_g[2] == gravity[2];
@@ -960,6 +973,7 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
                                    w->entity_of_slot.as<uint32_t>());
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
+            w->pairs_from_slab = false;
             if (with_triggers) {
                 HIP_TRY(hipMemsetAsync(w->trig_count.p, 0, 4, w->stream));
                 HIP_TRY(bge::launch_trigger_pairs(w->stream, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
@@ -1178,9 +1192,194 @@ int bge_world_pairs(bge_world* w, uint32_t* pairs2, uint64_t cap, uint64_t* tota
     if (!w || !total) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     DeviceGuard guard(w->device);
-    const int rc = w->broadphase.download(w->stream, pairs2, cap, total);
-    if (rc != BGE_OK) return fail(rc, "pair download failed: %s", w->broadphase.error());
+    bge::Broadphase& bp = w->pairs_from_slab ? w->slab_broadphase : w->broadphase;
+    const int rc = bp.download(w->stream, pairs2, cap, total);
+    if (rc != BGE_OK) return fail(rc, "pair download failed: %s", bp.error());
     return BGE_OK;
+}
+
+// ---------------------------------------------------------------- sharded broadphase (bge_route.hip)
+namespace {
+uint64_t ticked_slots(const bge_world* w) { return static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile; }
+
+int refresh_global_of_slot(bge_world* w)
+{
+    if (!w->global_of_slot_stale && w->global_of_slot.p) return BGE_OK;
+    const uint64_t S = std::max<uint64_t>(w->flat.n_slots, 1);
+    std::vector<uint32_t> g(S, bge::kNone);
+    for (uint64_t s = 0; s < w->flat.n_slots; ++s) {
+        const uint32_t e = w->flat.entity_of_slot[s];
+        if (e != bge::kNone) g[s] = e < w->global_id_host.size() ? w->global_id_host[e] : e;
+    }
+    HIP_TRY(w->global_of_slot.ensure(S * 4));
+    HIP_TRY(hipMemcpyAsync(w->global_of_slot.p, g.data(), S * 4, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->global_of_slot_stale = false;
+    return BGE_OK;
+}
+} // namespace
+
+int bge_world_set_global_ids(bge_world* w, uint64_t first, uint64_t count, const uint32_t* ids)
+{
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count && !ids) return fail(BGE_ERR_INVALID, "ids is NULL");
+    if (w->global_id_host.size() < w->flat.n_entities) {
+        const size_t old = w->global_id_host.size();
+        w->global_id_host.resize(w->flat.n_entities);
+        for (size_t i = old; i < w->global_id_host.size(); ++i) w->global_id_host[i] = static_cast<uint32_t>(i);
+    }
+    for (uint64_t i = 0; i < count; ++i) w->global_id_host[first + i] = ids[i];
+    w->global_of_slot_stale = true;
+    return BGE_OK;
+}
+
+int bge_world_aabb_bounds(bge_world* w, float mn[3], float mx[3], uint64_t* n_bodies)
+{
+    if (!w || !mn || !mx) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    DeviceGuard guard(w->device);
+    const int rc = w->router.bounds(w->stream, w->view, ticked_slots(w), mn, mx, n_bodies);
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    return BGE_OK;
+}
+
+int bge_world_axis_histogram(bge_world* w, uint32_t axis, float lo, float hi, uint32_t bins, uint64_t* hist)
+{
+    if (!w || !hist) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    DeviceGuard guard(w->device);
+    const int rc = w->router.histogram(w->stream, w->view, ticked_slots(w), axis, lo, hi, bins, hist);
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    return BGE_OK;
+}
+
+int bge_balanced_cuts(const uint64_t* hist, uint32_t bins, float lo, float hi, uint32_t nranks, float* cuts)
+{
+    if (!hist || !cuts || bins == 0 || nranks == 0) return fail(BGE_ERR_INVALID, "bad argument");
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < bins; ++b) total += hist[b];
+    const double width = (static_cast<double>(hi) - static_cast<double>(lo)) / bins;
+    cuts[0] = lo;
+    cuts[nranks] = hi;
+    uint64_t cum = 0;
+    uint32_t b = 0;
+    for (uint32_t k = 1; k < nranks; ++k) {
+        // smallest bin whose inclusive prefix reaches k/nranks of the bodies; the cut is that bin's upper edge
+        const uint64_t target = (total * k + nranks - 1) / nranks;
+        while (b < bins && cum + hist[b] < target) cum += hist[b++];
+        const uint32_t edge = b < bins ? b + 1 : bins;
+        cuts[k] = (hi >= lo) ? static_cast<float>(static_cast<double>(lo) + width * edge) : lo;
+        if (k > 1 && cuts[k] < cuts[k - 1]) cuts[k] = cuts[k - 1];
+    }
+    return BGE_OK;
+}
+
+int bge_world_bp_route(bge_world* w, uint32_t axis, uint32_t nranks, const float* cuts, uint64_t* counts)
+{
+    if (!w || !counts) return fail(BGE_ERR_INVALID, "NULL argument");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    if (nranks > 1 && !cuts) return fail(BGE_ERR_INVALID, "cuts is NULL");
+    DeviceGuard guard(w->device);
+    const float none[2] = {0.0f, 0.0f};
+    const int rc = w->router.count(w->stream, w->view, ticked_slots(w), axis, nranks, cuts ? cuts : none, counts);
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    return BGE_OK;
+}
+
+int bge_world_bp_pack(bge_world* w, void* send_device)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    DeviceGuard guard(w->device);
+    if (int rc = refresh_global_of_slot(w)) return rc;
+    const int rc = w->router.pack(w->stream, w->view, ticked_slots(w), w->global_of_slot.as<uint32_t>(), send_device);
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    return BGE_OK;
+}
+
+int bge_world_bp_find(bge_world* w, const void* records_device, uint64_t n_records, uint32_t axis, float window_lo, float window_hi)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (n_records && !records_device) return fail(BGE_ERR_INVALID, "records_device is NULL");
+    if (axis > 2) return fail(BGE_ERR_INVALID, "axis %u", axis);
+    if (n_records > 0x7fff0000ull) return fail(BGE_ERR_INVALID, "%llu records exceed the 32-bit record index", (unsigned long long)n_records);
+    DeviceGuard guard(w->device);
+    bge::WorldView view{};
+    const uint32_t* ids = nullptr;
+    int rc = w->router.unpack(w->stream, records_device, n_records, &view, &ids);
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * n_records, 4096);
+    rc = w->slab_broadphase.configure(std::max<uint64_t>(n_records, bge::kTile), cap);
+    if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->slab_broadphase.error());
+    const bge::PairWindow win{axis, window_lo, window_hi};
+    rc = w->slab_broadphase.run(w->stream, view, n_records, ids, &win);
+    if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->slab_broadphase.error());
+    w->pairs_from_slab = true;
+    return BGE_OK;
+}
+
+// The whole exchange over the world's RCCL communicator: common bounds (one all-reduce), uniform cuts along `axis`,
+// counts (one all-gather), records (one grouped send/recv per peer), slab search.
+int bge_world_bp_exchange(bge_world* w, uint32_t axis)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    if (!w->comm.ready()) return fail(BGE_ERR_STATE, "bge_world_comm_init has not been called");
+    if (axis > 2) return fail(BGE_ERR_INVALID, "axis %u", axis);
+    const uint32_t N = static_cast<uint32_t>(w->comm.nranks());
+    const uint32_t me = static_cast<uint32_t>(w->comm.rank());
+    if (N > bge::kMaxSlabs) return fail(BGE_ERR_UNSUPPORTED, "at most %u ranks", bge::kMaxSlabs);
+    DeviceGuard guard(w->device);
+    float mn[3], mx[3];
+    int rc = w->router.bounds(w->stream, w->view, ticked_slots(w), mn, mx, nullptr);
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    // max-reduce of (-min, max) along the axis
+    HIP_TRY(w->bp_small.ensure(8 * static_cast<size_t>(N) * (N + 1) + 64));
+    float ext[2] = {-mn[axis], mx[axis]};
+    HIP_TRY(hipMemcpyAsync(w->bp_small.p, ext, sizeof ext, hipMemcpyHostToDevice, w->stream));
+    if (w->comm.all_reduce_max(w->stream, w->bp_small.as<float>(), 2) != BGE_OK) return fail(BGE_ERR_HIP, "%s", w->comm.error());
+    HIP_TRY(hipMemcpyAsync(ext, w->bp_small.p, sizeof ext, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    // balanced cuts: all-reduced histogram of the min corners -> quantiles; every rank evaluates the same code on the
+    // same reduced data, so the cuts are identical everywhere
+    const float lo = -ext[0], hi = ext[1];
+    std::vector<float> cuts(N + 1, 0.0f);
+    if (hi >= lo) {
+        std::vector<uint64_t> hist(bge::kMaxHistBins, 0);
+        rc = w->router.histogram(w->stream, w->view, ticked_slots(w), axis, lo, hi, bge::kMaxHistBins, hist.data());
+        if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+        HIP_TRY(w->bp_hist.ensure(bge::kMaxHistBins * 8));
+        HIP_TRY(hipMemcpyAsync(w->bp_hist.p, hist.data(), bge::kMaxHistBins * 8, hipMemcpyHostToDevice, w->stream));
+        if (w->comm.all_reduce_sum_u64(w->stream, w->bp_hist.as<uint64_t>(), bge::kMaxHistBins) != BGE_OK)
+            return fail(BGE_ERR_HIP, "%s", w->comm.error());
+        HIP_TRY(hipMemcpyAsync(hist.data(), w->bp_hist.p, bge::kMaxHistBins * 8, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        if (int rc2 = bge_balanced_cuts(hist.data(), bge::kMaxHistBins, lo, hi, N, cuts.data())) return rc2;
+    }
+    std::vector<uint64_t> send_counts(N, 0), table(static_cast<size_t>(N) * N, 0), recv_counts(N, 0);
+    rc = w->router.count(w->stream, w->view, ticked_slots(w), axis, N, cuts.data(), send_counts.data());
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    uint64_t* dev_counts = reinterpret_cast<uint64_t*>(w->bp_small.as<char>() + 64);
+    HIP_TRY(hipMemcpyAsync(dev_counts, send_counts.data(), 8ull * N, hipMemcpyHostToDevice, w->stream));
+    if (w->comm.all_gather_bytes(w->stream, dev_counts, dev_counts + N, 8ull * N) != BGE_OK) return fail(BGE_ERR_HIP, "%s", w->comm.error());
+    HIP_TRY(hipMemcpyAsync(table.data(), dev_counts + N, 8ull * N * N, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    uint64_t n_send = 0, n_recv = 0;
+    for (uint32_t p = 0; p < N; ++p) {
+        recv_counts[p] = table[static_cast<size_t>(p) * N + me]; // what rank p routes to my slab
+        n_send += send_counts[p];
+        n_recv += recv_counts[p];
+    }
+    HIP_TRY(w->bp_send.ensure(std::max<uint64_t>(n_send, 1) * bge::kRecordBytes));
+    HIP_TRY(w->bp_recv.ensure(std::max<uint64_t>(n_recv, 1) * bge::kRecordBytes));
+    if (int rc2 = refresh_global_of_slot(w)) return rc2;
+    rc = w->router.pack(w->stream, w->view, ticked_slots(w), w->global_of_slot.as<uint32_t>(), w->bp_send.p);
+    if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
+    if (w->comm.all_to_all_v(w->stream, w->bp_send.p, send_counts.data(), w->bp_recv.p, recv_counts.data(), bge::kRecordBytes) != BGE_OK)
+        return fail(BGE_ERR_HIP, "%s", w->comm.error());
+    const float wlo = me == 0 ? -INFINITY : cuts[me];
+    const float whi = me + 1 == N ? INFINITY : cuts[me + 1];
+    return bge_world_bp_find(w, w->bp_recv.p, n_recv, axis, wlo, whi);
 }
 
 int bge_world_upload_triggers(bge_world* w, uint64_t count, const uint32_t* entity_index, const uint8_t* shape, const float* size3,

@@ -11,7 +11,7 @@ from ._capi import WorldDesc, WorldInfo, check, lib
 NO_PARENT = 0xFFFFFFFF
 BODY_STATIC, BODY_DYNAMIC, BODY_KINEMATIC, BODY_NONE = 0, 1, 2, 255
 SHAPE_BOX, SHAPE_CAPSULE = 0, 1
-TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL, TICK_GATHER_ROOTS, TICK_NORMAL_MATRICES = 1, 2, 4, 3, 8, 16
+TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL, TICK_GATHER_ROOTS, TICK_NORMAL_MATRICES, TICK_AABBS = 1, 2, 4, 3, 8, 16, 32
 ARRAY_WORLD, ARRAY_ROOT_WORLDS, ARRAY_SLOT_OF_ENTITY, ARRAY_POSITION, ARRAY_PAIRS = 0, 1, 2, 3, 4
 
 # fixed step and gravity of the reference (assets/config/physics.json:2-3)
@@ -145,6 +145,38 @@ class World:
     def set_sleeping(self, linear=0.8, angular=1.0, seconds=2.0):
         check(lib().bge_world_set_sleeping(self._h, linear, angular, seconds))
 
+    # -- sharded broadphase (global pair set across worlds / ranks)
+    def set_global_ids(self, ids, first=0):
+        ids = _arr(ids, np.uint32)
+        check(lib().bge_world_set_global_ids(self._h, first, len(ids), _p(ids)))
+
+    def aabb_bounds(self):
+        mn, mx = np.empty(3, np.float32), np.empty(3, np.float32)
+        n = C.c_uint64(0)
+        check(lib().bge_world_aabb_bounds(self._h, _p(mn), _p(mx), C.byref(n)))
+        return mn, mx, int(n.value)
+
+    def axis_histogram(self, axis, lo, hi, bins=4096):
+        hist = np.zeros(bins, np.uint64)
+        check(lib().bge_world_axis_histogram(self._h, axis, lo, hi, bins, _p(hist)))
+        return hist
+
+    def bp_route(self, axis, cuts):
+        """cuts: nranks + 1 slab boundaries (the outer two are ignored).  Returns records per destination slab."""
+        cuts = _arr(cuts, np.float32)
+        counts = np.zeros(len(cuts) - 1, np.uint64)
+        check(lib().bge_world_bp_route(self._h, axis, len(cuts) - 1, _p(cuts), _p(counts)))
+        return counts
+
+    def bp_pack(self, send_device_ptr):
+        check(lib().bge_world_bp_pack(self._h, C.c_void_p(send_device_ptr)))
+
+    def bp_find(self, records_device_ptr, n_records, axis, window_lo, window_hi):
+        check(lib().bge_world_bp_find(self._h, C.c_void_p(records_device_ptr), n_records, axis, window_lo, window_hi))
+
+    def bp_exchange(self, axis=2):
+        check(lib().bge_world_bp_exchange(self._h, axis))
+
     def dirty_count(self) -> int:
         v = C.c_uint64(0)
         check(lib().bge_world_dirty_count(self._h, C.byref(v)))
@@ -237,6 +269,14 @@ class World:
         if with_bodies:
             self.upload_bodies(wl.body_type)
         return self
+
+
+def balanced_cuts(hist, lo, hi, nranks):
+    """Host-only: slab boundaries at the k/nranks quantiles of an (all-reduced) axis histogram."""
+    hist = _arr(hist, np.uint64)
+    cuts = np.zeros(nranks + 1, np.float32)
+    check(lib().bge_balanced_cuts(_p(hist), len(hist), lo, hi, nranks, _p(cuts)))
+    return cuts
 
 
 def flatten_topology(parent, has_transform=None):

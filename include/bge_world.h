@@ -64,8 +64,10 @@ enum bge_tick_flags {
     BGE_TICK_BROADPHASE = 4u, /* AABB update + overlapping pairs (Bullet updateAabbs/calculateOverlappingPairs) */
     BGE_TICK_ALL = 3u,        /* Application::Update's physics + transform steps (src/core/Application.cpp:256,284) */
     BGE_TICK_GATHER_ROOTS = 8u, /* after the tick: bge_world_gather_roots (needs bge_world_comm_init) */
-    BGE_TICK_NORMAL_MATRICES = 16u /* with TRANSFORMS: also write transpose(inverse(world)) per entity, the normalMtx
+    BGE_TICK_NORMAL_MATRICES = 16u, /* with TRANSFORMS: also write transpose(inverse(world)) per entity, the normalMtx
                                       Renderer::BeginFrame computes on the CPU per mesh (src/render/Renderer.cpp:633-636) */
+    BGE_TICK_AABBS = 32u      /* with PHYSICS: update the AABBs (Bullet updateAabbs) without the local pair search —
+                                 the sharded broadphase (bge_world_bp_*) searches them across ranks instead */
 };
 
 enum bge_device_array {
@@ -264,6 +266,41 @@ BGE_API int bge_world_comm_wait(bge_world* world);
 /* Copy the most recently gathered table to the host (waits for it): nranks x rows_per_rank x 16 floats. */
 BGE_API int bge_world_download_gathered(bge_world* world, float* out, uint64_t floats);
 BGE_API int bge_world_comm_destroy(bge_world* world);
+
+/*
+ * Sharded broadphase: the GLOBAL pair set of a scene whose bodies live on several GPUs.
+ * The reference has one Bullet world, hence one pair cache over all bodies (src/physics/PhysicsSystem.cpp:124, 863);
+ * bge_partition_subtrees shards by subtree, so a per-world BGE_TICK_BROADPHASE only sees the pairs inside one shard.
+ * For the pair search the bodies are re-partitioned into slabs along one axis, one slab per rank
+ * (slab s = [cuts[s], cuts[s+1]), cuts[0] = -inf, cuts[nranks] = +inf, interior cuts non-decreasing):
+ *   bge_world_set_global_ids   id reported for each local entity index (default: the index itself)
+ *   bge_world_aabb_bounds      min / max corner over the body AABBs of the last BGE_TICK_AABBS / BGE_TICK_BROADPHASE
+ *                              tick, so that ranks can agree on cuts
+ *   bge_world_bp_route         counts[d] = records this world sends to slab d: one per slab the body's extent touches
+ *   bge_world_bp_pack          the 48-byte records grouped by slab (slab d at record offset sum(counts[0..d))) into
+ *                              device memory the caller exchanges (all-to-all: RCCL, torch.distributed, hipMemcpyPeer)
+ *   bge_world_bp_find          pair search over the records a rank received; a pair is kept only where the lower end
+ *                              of its overlap interval along `axis`, max(min_a, min_b), lies in [window_lo, window_hi)
+ *                              = the rank's own slab, so the union over ranks is the global set without duplicates.
+ *                              Afterwards bge_world_pairs returns these pairs (global ids) until the next
+ *                              BGE_TICK_BROADPHASE tick.
+ *   bge_world_bp_exchange      all of the above over the world's RCCL communicator (bge_world_comm_init): all-reduced
+ *                              extent and histogram -> balanced cuts, one all-gather of counts, one send/recv per peer.
+ * Record layout (float4 x 3): min.xyz | global id,  max.xyz | 0,  group | mask | static flag | 0.
+ */
+#define BGE_BP_RECORD_BYTES 48
+BGE_API int bge_world_set_global_ids(bge_world* world, uint64_t first, uint64_t count, const uint32_t* ids);
+BGE_API int bge_world_aabb_bounds(bge_world* world, float min3[3], float max3[3], uint64_t* n_bodies);
+/* hist[b] = bodies whose AABB min corner along `axis` falls into bin b of `bins` (<= 4096) equal bins over [lo, hi]
+ * (out-of-range values land in the first / last bin).  Summed over ranks it yields balanced cuts: */
+BGE_API int bge_world_axis_histogram(bge_world* world, uint32_t axis, float lo, float hi, uint32_t bins, uint64_t* hist);
+/* Host only: cuts[0..nranks] with cuts[k] = upper edge of the first bin at which k/nranks of the bodies are reached. */
+BGE_API int bge_balanced_cuts(const uint64_t* hist, uint32_t bins, float lo, float hi, uint32_t nranks, float* cuts);
+BGE_API int bge_world_bp_route(bge_world* world, uint32_t axis, uint32_t nranks, const float* cuts, uint64_t* counts);
+BGE_API int bge_world_bp_pack(bge_world* world, void* send_device);
+BGE_API int bge_world_bp_find(bge_world* world, const void* records_device, uint64_t n_records, uint32_t axis,
+                              float window_lo, float window_hi);
+BGE_API int bge_world_bp_exchange(bge_world* world, uint32_t axis);
 BGE_API int bge_world_get_info(bge_world* world, bge_world_info* info);
 
 /*

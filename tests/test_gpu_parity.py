@@ -652,3 +652,88 @@ def test_free_bodies_fall_asleep_like_the_oracle():
         w.tick(dt=DT, gravity=g0, ticks=300)
         st, tm = w.download_activation()
         assert not (st[dyn] == 2).any() and tm[dyn].max() > 2.0
+
+
+def _sharded_scene(n=30_000, side=34.0):
+    """Small subtrees with bodies on their roots (so bge_partition_subtrees decides the ownership), a ground box that
+    spans every slab, statics / kinematics and layer masks."""
+    rng = np.random.default_rng(8)
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    for i in range(1, n):
+        if rng.random() < 0.5:
+            parent[i] = rng.integers(max(0, i - 6), i)
+    wl = synth.Workload("cube", synth.FLAT, n, 77, pos_box=synth.CUBE)
+    wl.parent = parent
+    wl.pos = (wl.pos * np.float32(side / 262.0)).astype(np.float32)
+    roots = parent == 0xFFFFFFFF
+    wl.body_type = np.where(roots, rng.choice([0, 1, 1, 1, 2], n), 255).astype(np.uint8)
+    layer = rng.choice([1, 2, 4], n).astype(np.uint32)
+    mask = rng.choice([0xFFFFFFFF, 3, 6], n).astype(np.uint32)
+    size = np.full((n, 3), 0.5, np.float32)
+    size[0] = (60.0, 1.0, 60.0)
+    wl.body_type[0] = 0
+    return wl, dict(size=size, layer=layer, mask=mask)
+
+
+@pytest.mark.parametrize("nshards,axis", [(3, 2), (2, 0), (5, 1)])
+def test_slab_broadphase_across_shards_gives_the_global_pair_set(nshards, axis):
+    """§8(e) "not sharded" / §8(f) rank 4: bodies live in `nshards` worlds (subtree shards, interleaved in space); the
+    slab exchange must reproduce the pair set of the ONE unsharded world — the oracle's — with no duplicates.
+    All worlds share this GPU; the exchange is the device-to-device rehearsal of the all-to-all."""
+    from banggameengine_amd import sharding
+    wl, kw = _sharded_scene()
+    ref = run_oracle(build_oracle(wl, aabbs=True, **kw), wl, 2)
+    want = ref.pairs("sweep")
+    rank_of, load, shards = sharding.shard_scene(wl.parent, nshards)
+    worlds = []
+    try:
+        for ids, local_parent in shards:
+            w = B.World(pair_capacity=64 * len(ids))
+            w.set_topology(local_parent)
+            w.upload_trs(wl.pos[ids], wl.euler[ids], wl.scale[ids])
+            w.upload_bodies(wl.body_type[ids], **{k: v[ids] for k, v in kw.items()})
+            w.set_global_ids(ids)
+            for k in range(2):
+                w.tick(dt=DT, flags=B.TICK_ALL | B.TICK_AABBS)
+                if k == 0:
+                    w.set_velocities(wl.vel[ids])
+            worlds.append(w)
+        counts, cuts = sharding.slab_broadphase_local(worlds, axis=axis)
+        per_world = [w.pairs(cap=64 * wl.n) for w in worlds]
+        local_only = 0
+        for w in worlds:   # for comparison: what the per-shard broadphase alone would have found
+            w.tick(dt=0.0, flags=B.TICK_PHYSICS | B.TICK_BROADPHASE)
+            local_only += w.pair_count()
+    finally:
+        for w in worlds:
+            w.close()
+    got = np.concatenate(per_world)
+    key = got[:, 0].astype(np.uint64) << np.uint64(32) | got[:, 1]
+    assert len(np.unique(key)) == len(key), "a pair was reported by two slabs"
+    assert (got[:, 0] < got[:, 1]).all()
+    assert len(want) > 5000 and np.array_equal(got[np.argsort(key)], want)
+    assert local_only < 0.7 * len(want)            # the shards alone miss the cross-shard pairs
+    n_bodies = int((wl.body_type != 255).sum())
+    assert n_bodies <= counts.sum() < 1.5 * n_bodies + nshards   # one record per body + ghosts at slab borders
+    assert all(len(p) > 0 for p in per_world)
+
+
+def test_native_slab_exchange_single_rank_rehearsal():
+    """bge_world_bp_exchange over a 1-rank RCCL communicator (all-reduce, all-gather, grouped send/recv to self):
+    must equal the local broadphase, reported with the global ids."""
+    wl, kw = _sharded_scene(n=8000, side=22.0)
+    gids = (np.arange(wl.n, dtype=np.uint32) * 3 + 7).astype(np.uint32)
+    with B.World(pair_capacity=64 * wl.n) as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, **kw)
+        w.set_global_ids(gids)
+        w.comm_init(1, 0, B.World.comm_unique_id(), 16)
+        run_world(w, wl, 2, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+        local = w.pairs(cap=64 * wl.n)
+        w.bp_exchange(axis=1)
+        got = w.pairs(cap=64 * wl.n)
+        w.comm_destroy()
+    want = np.sort(gids[local], axis=1)
+    want = want[np.lexsort((want[:, 1], want[:, 0]))]
+    assert len(local) > 1000 and np.array_equal(got, want)
