@@ -67,6 +67,8 @@ struct Accum {
     float part_max[kBoundsBlocks][3];
     uint32_t part_count[kBoundsBlocks];
     uint32_t extent_hist[kExtentBins]; // bodies per extent bin (bin = float exponent + 2 mantissa bits)
+    uint32_t scan_ticket;              // tile tickets of k_scan_lookback (dispatch order)
+    uint32_t scan_error;               // a look-back gave up (never observed; keeps a logic error from hanging the GPU)
 };
 
 constexpr uint32_t kLargeCell = 0xffffffffu;
@@ -96,6 +98,7 @@ __global__ void k_bp_reset(Accum* acc)
         acc->n_large = 0;
         acc->n_pairs = 0;
         acc->n_pairs_kept = 0;
+        acc->scan_ticket = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < kShards) acc->shard_count[threadIdx.x][0] = 0;
 }
@@ -309,23 +312,23 @@ __global__ void __launch_bounds__(64) k_bp_params(Accum* acc, uint32_t max_cells
     acc->grid = g;
 }
 
-__device__ __forceinline__ uint32_t cell_of(const GridParams& g, const float* mn)
+__device__ __forceinline__ uint32_t cell_axis(const GridParams& g, float v, int a)
 {
     // +1: the padding cell; clamped so that garbage (NaN / out of range) stays inside the table
-    uint32_t c[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        double t = floor((static_cast<double>(mn[a]) - static_cast<double>(g.origin[a])) * g.inv_cell);
-        t = fmin(fmax(t, 0.0), 4.0e9);
-        c[a] = static_cast<uint32_t>(t) + 1u;
-    }
+    double t = floor((static_cast<double>(v) - static_cast<double>(g.origin[a])) * g.inv_cell);
+    t = fmin(fmax(t, 0.0), 4.0e9);
+    return static_cast<uint32_t>(t) + 1u;
+}
+__device__ __forceinline__ uint32_t cell_of(const GridParams& g, float x, float y, float z)
+{
     const uint32_t dy = g.dim_xy / g.dim_x;
     const uint32_t dz = g.n_cells / g.dim_xy;
-    c[0] = min(c[0], g.dim_x - 2u);
-    c[1] = min(c[1], dy - 2u);
-    c[2] = min(c[2], dz - 2u);
-    return c[0] + g.dim_x * c[1] + g.dim_xy * c[2];
+    const uint32_t cx = min(cell_axis(g, x, 0), g.dim_x - 2u);
+    const uint32_t cy = min(cell_axis(g, y, 1), dy - 2u);
+    const uint32_t cz = min(cell_axis(g, z, 2), dz - 2u);
+    return cx + g.dim_x * cy + g.dim_xy * cz;
 }
+__device__ __forceinline__ uint32_t cell_of(const GridParams& g, const float* mn) { return cell_of(g, mn[0], mn[1], mn[2]); }
 
 __global__ void __launch_bounds__(256) k_bp_count(uint64_t n_slots, const uint32_t* __restrict__ flags,
                                                   const float* __restrict__ aabb, Accum* acc,
@@ -350,6 +353,90 @@ __global__ void __launch_bounds__(256) k_bp_count(uint64_t n_slots, const uint32
 
 // ---- exclusive scan of cell_count[0..n) into cell_start[0..n], n = padded to kScanBlock multiples by the caller
 constexpr uint32_t kScanBlock = 2048; // 256 threads x 8
+
+// Single-pass scan: one read and one write of the table instead of the three kernels below (76 us -> see DESIGN.md 4.3).
+// The table has at most ~1000 tiles of 8192 cells, so there is no look-back CHAIN: every tile publishes its own sum and
+// then adds up the sums of ALL earlier tiles itself (256 threads x <= 4 status words, one round trip), O(tiles^2 / 2)
+// 8-byte reads in total — 4 MB for 1024 tiles.
+//   * a workgroup takes its tile number from a ticket counter, so a tile only ever waits for tiles whose workgroups
+//     were dispatched before it (no deadlock whatever the dispatch order or residency);
+//   * per tile ONE 64-bit status word (epoch << 32 | sum), written and read with agent-scope atomics only: coherent
+//     across the 8 XCDs' L2s, and the payload travels in the flag word itself — no fence, nothing that could be stale;
+//   * the epoch (one per run) makes words of earlier runs read as "not there yet": the status array is never cleared;
+//   * tiles entirely beyond `limit` (= cells in use + 2, known only on the device) publish a zero and touch no memory.
+constexpr uint32_t kScanTile = 8192; // 256 threads x 32
+__global__ void __launch_bounds__(256) k_scan_lookback(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       unsigned long long* __restrict__ status, Accum* acc, uint32_t n,
+                                                       uint32_t epoch)
+{
+    __shared__ uint32_t wave_tot[4], wave_back[4];
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(&acc->scan_ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t limit = min(n, acc->grid.n_cells + 2u);
+    const bool live = tile * kScanTile < limit; // the buffers are padded to whole tiles and zero beyond the cells in use
+    const uint32_t base = tile * kScanTile + threadIdx.x * 32;
+    uint4 v[8];
+    uint32_t sum = 0;
+    if (live) {
+        const uint4* src = reinterpret_cast<const uint4*>(in + base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = src[k];
+            sum += v[k].x + v[k].y + v[k].z + v[k].w;
+        }
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if ((threadIdx.x & 63u) >= static_cast<uint32_t>(off)) incl += t;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane == 63u) wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __hip_atomic_store(&status[tile], (static_cast<unsigned long long>(epoch) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // sum of all earlier tiles
+    uint32_t back = 0;
+    for (uint32_t j = threadIdx.x; j < tile; j += 256u) {
+        unsigned long long w = 0;
+        uint32_t spins = 0;
+        while (true) {
+            w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w >> 32) == epoch) break;
+            if (++spins > (1u << 24)) { // ~seconds: a logic error must not hang the GPU
+                acc->scan_error = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        back += static_cast<uint32_t>(w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) back += __shfl_xor(back, off, 64);
+    if (lane == 0) wave_back[wave] = back;
+    __syncthreads();
+    if (!live) return;
+    uint32_t run = wave_back[0] + wave_back[1] + wave_back[2] + wave_back[3];
+    for (uint32_t k = 0; k < wave; ++k) run += wave_tot[k];
+    run += incl - sum;
+    uint4* dst = reinterpret_cast<uint4*>(out + base);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint4 o;
+        o.x = run;
+        o.y = o.x + v[k].x;
+        o.z = o.y + v[k].y;
+        o.w = o.z + v[k].z;
+        run = o.w + v[k].w;
+        dst[k] = o;
+    }
+}
 
 __global__ void __launch_bounds__(256) k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                      uint32_t* __restrict__ block_sums, uint32_t n)
@@ -422,12 +509,18 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
     }
 }
 
-// Sorted record, 48 bytes: everything the pair test and the emission need, so that a hit costs no further
-// (uncoalesced, dependent) global loads:  r0 = min.xyz | entity   r1 = max.xyz | cell   r2 = group | mask | static | slot
+// Sorted record: everything the pair test and the emission need, so that a hit costs no further (uncoalesced,
+// dependent) global loads.
+//   full, 48 bytes:     r0 = min.xyz | entity   r1 = max.xyz | cell    r2 = group | mask | static | slot
+//   COMPACT, 32 bytes:  r0 = min.xyz | entity   r1 = max.xyz | class   (class -> group, mask, static through the world's
+//                       filter palette; the cell is recomputed from min.xyz).  One aligned 32-byte sector per record:
+//                       the scatter's random writes and the pair search's L2 -> LDS staging both move 1/3 fewer bytes.
+template <bool COMPACT>
 __global__ void __launch_bounds__(256) k_bp_scatter(uint64_t n_slots, const uint32_t* __restrict__ flags,
                                                     const float* __restrict__ aabb, const uint32_t* __restrict__ cell_start,
                                                     const uint32_t* __restrict__ body_cell, const uint32_t* __restrict__ body_rank,
                                                     const uint32_t* __restrict__ group, const uint32_t* __restrict__ mask,
+                                                    const uint32_t* __restrict__ class_of_slot,
                                                     const uint32_t* __restrict__ entity_of_slot, float4* __restrict__ sorted)
 {
     const uint64_t s = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -438,10 +531,15 @@ __global__ void __launch_bounds__(256) k_bp_scatter(uint64_t n_slots, const uint
     if (c == kLargeCell) return;
     const uint32_t pos = cell_start[c] + body_rank[s];
     const float* b = aabb + 6 * s;
-    sorted[3ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(entity_of_slot[s]));
-    sorted[3ull * pos + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(c));
-    sorted[3ull * pos + 2] = make_float4(__uint_as_float(group[s]), __uint_as_float(mask[s]),
-                                         __uint_as_float((f & kTypeMask) == 1u ? 1u : 0u), __uint_as_float(static_cast<uint32_t>(s)));
+    if (COMPACT) {
+        sorted[2ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(entity_of_slot[s]));
+        sorted[2ull * pos + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(class_of_slot[s]));
+    } else {
+        sorted[3ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(entity_of_slot[s]));
+        sorted[3ull * pos + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(c));
+        sorted[3ull * pos + 2] = make_float4(__uint_as_float(group[s]), __uint_as_float(mask[s]),
+                                             __uint_as_float((f & kTypeMask) == 1u ? 1u : 0u), __uint_as_float(static_cast<uint32_t>(s)));
+    }
 }
 
 struct PairSink {
@@ -544,15 +642,24 @@ __device__ __forceinline__ bool filter_rec(const float4& a2, const float4& b2)
 
 // WINDOW: apply the slab window of the sharded broadphase (a second instantiation keeps the single-GPU search free of it:
 // the extra sink fields cost ~5 % there, measured)
-template <bool WINDOW>
-__global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
-                                                  const float4* __restrict__ sorted, PairSink sink)
+__device__ __forceinline__ bool filter_tab(const uint4& a, const uint4& b)
 {
-    __shared__ float4 cand[3 * kChunk];
+    return !(a.z != 0u && b.z != 0u) && (a.x & b.y) != 0u && (b.x & a.y) != 0u;
+}
+
+template <bool WINDOW, bool COMPACT>
+__global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
+                                                  const float4* __restrict__ sorted, const uint4* __restrict__ filter_table,
+                                                  PairSink sink)
+{
+    constexpr uint32_t RS = COMPACT ? 2u : 3u; // float4 per record
+    __shared__ float4 cand[RS * kChunk];
     __shared__ uint2 stage_lds[4][kStage];
+    __shared__ uint4 s_tab[COMPACT ? 256 : 1]; // (group, mask, static, 0) per filter class
     __shared__ uint32_t s_cell_first, s_cell_last;
 
     const GridParams g = acc->grid;
+    if (COMPACT) s_tab[threadIdx.x] = filter_table[threadIdx.x]; // visible after the first barrier below
     const uint32_t n_sorted = g.n_bodies - acc->n_large;
     const uint32_t n_blocks = (n_sorted + 255u) / 256u;
     WaveStage st{stage_lds[threadIdx.x >> 6], 0u};
@@ -564,10 +671,14 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
         float4 lo = make_float4(0, 0, 0, 0), hi = lo, fi = lo;
         uint32_t cell = 0;
         if (active) {
-            lo = sorted[3ull * i];
-            hi = sorted[3ull * i + 1];
-            fi = sorted[3ull * i + 2];
-            cell = __float_as_uint(hi.w);
+            lo = sorted[static_cast<uint64_t>(RS) * i];
+            hi = sorted[static_cast<uint64_t>(RS) * i + 1];
+            if (COMPACT) {
+                cell = cell_of(g, lo.x, lo.y, lo.z); // the same function of the same bits as in k_bp_count
+            } else {
+                fi = sorted[3ull * i + 2];
+                cell = __float_as_uint(hi.w);
+            }
         }
         const uint32_t entity_i = __float_as_uint(lo.w);
         const uint32_t last_tid = min(255u, n_sorted - 1u - blk * 256u);
@@ -576,6 +687,8 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
         if (tid == last_tid) s_cell_last = cell;
         __syncthreads();
         const uint32_t cell_first = s_cell_first, cell_last = s_cell_last;
+        uint4 own = make_uint4(0, 0, 0, 0);
+        if (COMPACT && active) own = s_tab[__float_as_uint(hi.w) & 255u];
 
 #pragma unroll 1
         for (int row = 0; row < 5; ++row) {
@@ -606,7 +719,7 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
                 const uint32_t jj0 = max(j, base);
                 const uint32_t e0 = min(end, top);
                 if (!__syncthreads_or(jj0 < e0)) continue;
-                for (uint32_t k = tid; k < 3u * (top - base); k += 256u) cand[k] = sorted[3ull * base + k];
+                for (uint32_t k = tid; k < RS * (top - base); k += 256u) cand[k] = sorted[static_cast<uint64_t>(RS) * base + k];
                 __syncthreads();
                 uint32_t jj = jj0;
                 while (__any(jj < e0)) {
@@ -614,17 +727,19 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
                     bool hit0 = false, hit1 = false;
                     uint32_t e0j = 0, e1j = 0;
                     if (jj < e0) {
-                        const uint32_t k0 = 3u * (jj - base);
+                        const uint32_t k0 = RS * (jj - base);
                         const bool two = jj + 1u < e0;
-                        const uint32_t k1 = two ? k0 + 3u : k0;
+                        const uint32_t k1 = two ? k0 + RS : k0;
                         const float4 alo = cand[k0], ahi = cand[k0 + 1u];
                         const float4 blo = cand[k1], bhi = cand[k1 + 1u];
                         if (overlap(lo, hi, alo, ahi)) {
-                            hit0 = filter_rec(fi, cand[k0 + 2u]) && (!WINDOW || in_window(sink, lo, alo));
+                            hit0 = (COMPACT ? filter_tab(own, s_tab[__float_as_uint(ahi.w) & 255u]) : filter_rec(fi, cand[k0 + RS - 1u])) &&
+                                   (!WINDOW || in_window(sink, lo, alo));
                             e0j = __float_as_uint(alo.w);
                         }
                         if (two && overlap(lo, hi, blo, bhi)) {
-                            hit1 = filter_rec(fi, cand[k1 + 2u]) && (!WINDOW || in_window(sink, lo, blo));
+                            hit1 = (COMPACT ? filter_tab(own, s_tab[__float_as_uint(bhi.w) & 255u]) : filter_rec(fi, cand[k1 + RS - 1u])) &&
+                                   (!WINDOW || in_window(sink, lo, blo));
                             e1j = __float_as_uint(blo.w);
                         }
                         jj += 2u;
@@ -635,6 +750,136 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
                     }
                 }
                 // (the __syncthreads_or at the top of the next iteration protects cand before it is overwritten)
+            }
+        }
+    }
+    if (st.fill) stage_flush(sink, st, st.fill);
+}
+
+// Pair search, wave-granular.  Same algorithm as k_bp_pairs, but the unit of work is ONE WAVE owning 64 consecutive
+// sorted bodies: the candidate chunks are staged in a wave-private LDS region and handed between the lanes of the wave
+// with wave_sync() (a wave's DS operations execute in order), so the kernel has no workgroup barrier at all.  The
+// workgroup version above spent its time waiting — two __syncthreads per staged chunk behind dependent cell_start and
+// record loads — not moving bytes: shrinking the records from 48 to 32 bytes left its 355 us untouched.
+#ifndef BGE_WAVE_CHUNK
+#define BGE_WAVE_CHUNK 96
+#endif
+constexpr uint32_t kWaveChunk = BGE_WAVE_CHUNK; // records per staged chunk and wave (a row's union range is ~70 records at 0.7 bodies per cell)
+// workgroups per CU the LDS footprint allows (wave chunk regions + 6 KiB pair staging + 2 KiB filter table)
+constexpr uint32_t kWaveResidentCompact = (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + 6144u + 2048u + 96u) > 8u ? 8u : (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + 6144u + 2048u + 96u);
+constexpr uint32_t kWaveResidentFull = (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + 6144u + 64u) > 8u ? 8u : (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + 6144u + 64u);
+template <bool WINDOW, bool COMPACT>
+__global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveResidentFull) k_bp_pairs_wave(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, const uint4* __restrict__ filter_table,
+                                                       PairSink sink)
+{
+    constexpr uint32_t RS = COMPACT ? 2u : 3u; // float4 per record
+    __shared__ float4 cand_all[4][RS * kWaveChunk];
+    __shared__ uint2 stage_lds[4][kStage];
+    __shared__ uint2 s_tab[COMPACT ? 256 : 1];      // (group, mask) per filter class
+    __shared__ uint32_t s_static[COMPACT ? 8 : 1];  // static bit per filter class
+
+    const GridParams g = acc->grid;
+    if (COMPACT) {
+        const uint4 e = filter_table[threadIdx.x];
+        s_tab[threadIdx.x] = make_uint2(e.x, e.y);
+        const unsigned long long sm = __ballot(e.z != 0u);
+        if ((threadIdx.x & 63u) == 0u) {
+            s_static[2u * (threadIdx.x >> 6)] = static_cast<uint32_t>(sm);
+            s_static[2u * (threadIdx.x >> 6) + 1u] = static_cast<uint32_t>(sm >> 32);
+        }
+        __syncthreads(); // the only workgroup barrier: the filter table is shared
+    }
+    const uint32_t n_sorted = g.n_bodies - acc->n_large;
+    const uint32_t n_blocks = (n_sorted + 63u) / 64u;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    float4* cand = cand_all[wave];
+    WaveStage st{stage_lds[wave], 0u};
+
+    for (uint32_t blk = blockIdx.x * 4u + wave; blk < n_blocks; blk += gridDim.x * 4u) {
+        const uint32_t i = blk * 64u + lane;
+        const bool active = i < n_sorted;
+        float4 lo = make_float4(0, 0, 0, 0), hi = lo, fi = lo;
+        uint32_t cell = 0;
+        if (active) {
+            lo = sorted[static_cast<uint64_t>(RS) * i];
+            hi = sorted[static_cast<uint64_t>(RS) * i + 1];
+            if (COMPACT) {
+                cell = cell_of(g, lo.x, lo.y, lo.z);
+            } else {
+                fi = sorted[3ull * i + 2];
+                cell = __float_as_uint(hi.w);
+            }
+        }
+        const uint32_t entity_i = __float_as_uint(lo.w);
+        const uint32_t last_lane = min(63u, n_sorted - 1u - blk * 64u);
+        const uint32_t cell_first = __shfl(cell, 0, 64), cell_last = __shfl(cell, static_cast<int>(last_lane), 64);
+        uint4 own = make_uint4(0, 0, 0, 0);
+        auto class_entry = [&](uint32_t cls) {
+            const uint2 gm = s_tab[cls & 255u];
+            return make_uint4(gm.x, gm.y, (s_static[(cls & 255u) >> 5] >> (cls & 31u)) & 1u, 0u);
+        };
+        if (COMPACT && active) own = class_entry(__float_as_uint(hi.w));
+
+#pragma unroll 1
+        for (int row = 0; row < 5; ++row) {
+            // this lane's candidate range [j, end) and the wave's union [r_lo, r_hi)
+            uint32_t j = 0, end = 0, r_lo, r_hi;
+            if (row == 0) {
+                // own cell's later records + the cell to the right
+                if (active) {
+                    j = i + 1;
+                    end = cell_start[cell + 2];
+                }
+                r_lo = blk * 64u + 1u;
+                r_hi = cell_start[cell_last + 2];
+            } else {
+                const int dy = (row == 1) ? 1 : (row - 3); // rows 2,3,4 -> dy = -1,0,1 at dz = 1
+                const int dz = (row == 1) ? 0 : 1;
+                const uint32_t off = static_cast<uint32_t>(dy * static_cast<int>(g.dim_x)) + static_cast<uint32_t>(dz) * g.dim_xy;
+                if (active) {
+                    j = cell_start[cell + off - 1];
+                    end = cell_start[cell + off + 2];
+                }
+                r_lo = cell_start[cell_first + off - 1];
+                r_hi = cell_start[cell_last + off + 2];
+            }
+            for (uint32_t base = r_lo; base < r_hi; base += kWaveChunk) {
+                const uint32_t top = min(base + kWaveChunk, r_hi);
+                const uint32_t jj0 = max(j, base);
+                const uint32_t e0 = min(end, top);
+                if (!__any(jj0 < e0)) continue;
+                wave_sync(); // the previous chunk has been consumed
+                for (uint32_t k = lane; k < RS * (top - base); k += 64u) cand[k] = sorted[static_cast<uint64_t>(RS) * base + k];
+                wave_sync();
+                uint32_t jj = jj0;
+                while (__any(jj < e0)) {
+                    // two candidates per trip: both LDS fetches are in flight together
+                    bool hit0 = false, hit1 = false;
+                    uint32_t e0j = 0, e1j = 0;
+                    if (jj < e0) {
+                        const uint32_t k0 = RS * (jj - base);
+                        const bool two = jj + 1u < e0;
+                        const uint32_t k1 = two ? k0 + RS : k0;
+                        const float4 alo = cand[k0], ahi = cand[k0 + 1u];
+                        const float4 blo = cand[k1], bhi = cand[k1 + 1u];
+                        if (overlap(lo, hi, alo, ahi)) {
+                            hit0 = (COMPACT ? filter_tab(own, class_entry(__float_as_uint(ahi.w))) : filter_rec(fi, cand[k0 + RS - 1u])) &&
+                                   (!WINDOW || in_window(sink, lo, alo));
+                            e0j = __float_as_uint(alo.w);
+                        }
+                        if (two && overlap(lo, hi, blo, bhi)) {
+                            hit1 = (COMPACT ? filter_tab(own, class_entry(__float_as_uint(bhi.w))) : filter_rec(fi, cand[k1 + RS - 1u])) &&
+                                   (!WINDOW || in_window(sink, lo, blo));
+                            e1j = __float_as_uint(blo.w);
+                        }
+                        jj += 2u;
+                    }
+                    if (__any(hit0 || hit1)) {
+                        emit_pairs(sink, st, hit0, entity_i, e0j);
+                        emit_pairs(sink, st, hit1, entity_i, e1j);
+                    }
+                }
             }
         }
     }
@@ -729,7 +974,7 @@ int Broadphase::fail(int code, const char* what, hipError_t e)
 
 void Broadphase::release()
 {
-    for (void** p : {&pairs_, &scan_stage_, &counters_, &cell_count_, &cell_start_, &scan_tmp_, &sorted_slot_, &sorted_aabb_, &body_cell_,
+    for (void** p : {&pairs_, &scan_stage_, &counters_, &cell_count_, &cell_start_, &scan_tmp_, &scan_status_, &sorted_slot_, &sorted_aabb_, &body_cell_,
                      &large_list_}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -764,19 +1009,28 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
     BP_TRY(hipMalloc(&pairs_, std::max<uint64_t>(capacity_, 1) * 8));
     BP_TRY(hipMalloc(&scan_stage_, shard_capacity(capacity_) * kShards * 8)); // sharded staging of the pair list
     BP_TRY(hipMalloc(&counters_, sizeof(Accum)));
-    BP_TRY(hipMalloc(&cell_count_, (static_cast<size_t>(table_size_) + kScanBlock) * 4));
-    BP_TRY(hipMalloc(&cell_start_, (static_cast<size_t>(table_size_) + kScanBlock) * 4));
+    BP_TRY(hipMalloc(&cell_count_, (static_cast<size_t>(table_size_) + 2 * kScanTile) * 4)); // whole scan tiles, zero-padded
+    BP_TRY(hipMalloc(&cell_start_, (static_cast<size_t>(table_size_) + 2 * kScanTile) * 4));
     BP_TRY(hipMalloc(&scan_tmp_, (static_cast<size_t>(table_size_) / kScanBlock + 2) * 4));
+    BP_TRY(hipMalloc(&scan_status_, (static_cast<size_t>(table_size_) / kScanBlock + 2) * 8));
+    BP_TRY(hipMemset(scan_status_, 0, (static_cast<size_t>(table_size_) / kScanBlock + 2) * 8));
+    scan_epoch_ = 0;
+    if (const char* e = std::getenv("BGE_BP_SCAN")) three_kernel_scan_ = std::atoi(e) == 3; // A/B: BGE_BP_SCAN=3 keeps the three-kernel scan
+    if (const char* e = std::getenv("BGE_BP_PAIRS")) block_pairs_ = std::string(e) == "block";  // A/B: workgroup-granular pair search
+    if (const char* e = std::getenv("BGE_BP_RECORDS")) full_records_ = std::atoi(e) == 48;  // A/B: BGE_BP_RECORDS=48 keeps full records
     BP_TRY(hipMalloc(&sorted_slot_, std::max<uint64_t>(n_slots, 1) * 4));  // body rank inside its cell
     BP_TRY(hipMalloc(&sorted_aabb_, std::max<uint64_t>(n_slots, 1) * 48));
     BP_TRY(hipMalloc(&body_cell_, std::max<uint64_t>(n_slots, 1) * 4));
     BP_TRY(hipMalloc(&large_list_, std::max<uint64_t>(n_slots, 1) * 4));
     BP_TRY(hipMemset(counters_, 0, sizeof(Accum)));
+    compacted_ = false;
     return BGE_OK;
 }
 
-int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const uint32_t* entity_of_slot, const PairWindow* window)
+int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const uint32_t* entity_of_slot, const PairWindow* window,
+                    const FilterPalette* palette)
 {
+    const bool compact_records = palette && palette->class_of_slot && palette->table && !window && !full_records_;
     if (n > n_slots_) {
         error_ = "broadphase not configured for this many slots";
         return BGE_ERR_STATE;
@@ -806,25 +1060,64 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     const uint32_t bounds_blocks = std::min<uint32_t>(slot_blocks, kBoundsBlocks);
     hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
     hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(64), 0, stream, acc, table_size_, bounds_blocks);
-    BP_TRY(hipMemsetAsync(cell_count, 0, (static_cast<size_t>(table_size_) + kScanBlock) * 4, stream));
+    BP_TRY(hipMemsetAsync(cell_count, 0, (static_cast<size_t>(table_size_) + 2 * kScanTile) * 4, stream));
     hipLaunchKernelGGL(k_bp_count, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc, cell_count, body_cell,
                        body_rank, large_list);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(scan_blocks), dim3(256), 0, stream, cell_count, cell_start, block_sums, scan_n);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, block_sums, scan_blocks);
-    hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, stream, cell_start, block_sums, scan_n);
-    hipLaunchKernelGGL(k_bp_scatter, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, cell_start, body_cell,
-                       body_rank, w.group, w.mask, entity_of_slot, sorted);
-    // persistent grid sized to residency: 18 KiB of LDS per workgroup -> 8 per CU on 256 CUs
-    if (window) {
-        hipLaunchKernelGGL(k_bp_pairs<true>, dim3(std::min<uint32_t>(slot_blocks, 8 * 256)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
+    if (three_kernel_scan_) {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(scan_blocks), dim3(256), 0, stream, cell_count, cell_start, block_sums, scan_n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, block_sums, scan_blocks);
+        hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, stream, cell_start, block_sums, scan_n);
     } else {
-        hipLaunchKernelGGL(k_bp_pairs<false>, dim3(std::min<uint32_t>(slot_blocks, 8 * 256)), dim3(256), 0, stream, acc, cell_start, sorted, sink);
+        scan_epoch_ = (scan_epoch_ + 1u) & 0x3fffffffu;
+        if (scan_epoch_ == 0u) scan_epoch_ = 1u; // 0 is what a never-written status word holds
+        hipLaunchKernelGGL(k_scan_lookback, dim3(blocks_for(scan_n, kScanTile)), dim3(256), 0, stream, cell_count, cell_start,
+                           static_cast<unsigned long long*>(scan_status_), acc, scan_n, scan_epoch_);
+    }
+    if (compact_records) {
+        hipLaunchKernelGGL(k_bp_scatter<true>, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, cell_start, body_cell,
+                           body_rank, w.group, w.mask, palette->class_of_slot, entity_of_slot, sorted);
+    } else {
+        hipLaunchKernelGGL(k_bp_scatter<false>, dim3(slot_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, cell_start, body_cell,
+                           body_rank, w.group, w.mask, static_cast<const uint32_t*>(nullptr), entity_of_slot, sorted);
+    }
+    // persistent grid sized to residency: 18 KiB of LDS per workgroup -> 8 per CU on 256 CUs
+    const dim3 pair_grid(std::min<uint32_t>(slot_blocks, 8 * 256));
+    const uint4* no_table = nullptr;
+    if (!block_pairs_) {
+        // wave-granular search, persistent grid sized to residency (LDS: 26 KiB per workgroup with 32-byte records, 30 KiB
+        // with full ones).  A software-pipelined variant (all five rows' cell_start loads up front, the next row's chunk
+        // prefetched into registers during the tests) was measured SLOWER: 324 us against 308 us — it needs 95 VGPRs.
+        const dim3 wgrid(std::min<uint32_t>(blocks_for(n, 256), (compact_records ? kWaveResidentCompact : kWaveResidentFull) * 256));
+        if (window) {
+            hipLaunchKernelGGL((k_bp_pairs_wave<true, false>), wgrid, dim3(256), 0, stream, acc, cell_start, sorted, no_table, sink);
+        } else if (compact_records) {
+            hipLaunchKernelGGL((k_bp_pairs_wave<false, true>), wgrid, dim3(256), 0, stream, acc, cell_start, sorted, palette->table, sink);
+        } else {
+            hipLaunchKernelGGL((k_bp_pairs_wave<false, false>), wgrid, dim3(256), 0, stream, acc, cell_start, sorted, no_table, sink);
+        }
+    } else if (window) {
+        hipLaunchKernelGGL((k_bp_pairs<true, false>), pair_grid, dim3(256), 0, stream, acc, cell_start, sorted, no_table, sink);
+    } else if (compact_records) {
+        hipLaunchKernelGGL((k_bp_pairs<false, true>), pair_grid, dim3(256), 0, stream, acc, cell_start, sorted, palette->table, sink);
+    } else {
+        hipLaunchKernelGGL((k_bp_pairs<false, false>), pair_grid, dim3(256), 0, stream, acc, cell_start, sorted, no_table, sink);
     }
     hipLaunchKernelGGL(k_bp_large, dim3(std::min<uint32_t>(slot_blocks, 4096)), dim3(256), 0, stream, n, acc, large_list,
                        body_cell, w.aabb, w.flags, w.group, w.mask, entity_of_slot, sink);
-    hipLaunchKernelGGL(k_bp_compact, dim3(kShards * kCompactParts), dim3(256), 0, stream, acc, static_cast<const uint2*>(scan_stage_),
-                       shard_cap, static_cast<uint2*>(pairs_), capacity_);
+    // The pairs now sit in 64 shard slices; the compact list is built on demand (compact()): a tick whose pairs nobody
+    // downloads does not pay the 49 us copy (4 M bodies, 12.6 M pairs).
+    compacted_ = false;
     BP_TRY(hipGetLastError());
+    return BGE_OK;
+}
+
+int Broadphase::compact(hipStream_t stream)
+{
+    if (!ran_ || compacted_) return BGE_OK;
+    hipLaunchKernelGGL(k_bp_compact, dim3(kShards * kCompactParts), dim3(256), 0, stream, static_cast<Accum*>(counters_),
+                       static_cast<const uint2*>(scan_stage_), shard_capacity(capacity_), static_cast<uint2*>(pairs_), capacity_);
+    BP_TRY(hipGetLastError());
+    compacted_ = true;
     return BGE_OK;
 }
 
@@ -832,13 +1125,24 @@ int Broadphase::download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uin
 {
     *total = 0;
     if (!ran_) return BGE_OK;
-    unsigned long long n = 0;
     const Accum* acc = static_cast<const Accum*>(counters_);
-    unsigned long long both[2] = {0, 0};
-    BP_TRY(hipMemcpyAsync(both, &acc->n_pairs, sizeof both, hipMemcpyDeviceToHost, stream));
+    unsigned long long counts[kShards][8];
+    uint32_t scan_error = 0;
+    BP_TRY(hipMemcpyAsync(counts, acc->shard_count, sizeof counts, hipMemcpyDeviceToHost, stream));
+    BP_TRY(hipMemcpyAsync(&scan_error, &acc->scan_error, 4, hipMemcpyDeviceToHost, stream));
     BP_TRY(hipStreamSynchronize(stream));
-    n = both[0];
-    *total = n; // found; both[1] of them are present in the compact list
+    if (scan_error) {
+        error_ = "internal error: the cell scan's look-back timed out";
+        return BGE_ERR_HIP;
+    }
+    const uint64_t shard_cap = shard_capacity(capacity_);
+    unsigned long long both[2] = {0, 0}; // found on the device; kept in the shard slices (and hence in the compact list)
+    for (uint32_t s = 0; s < kShards; ++s) {
+        both[0] += counts[s][0];
+        both[1] += std::min<unsigned long long>(counts[s][0], shard_cap);
+    }
+    both[1] = std::min<unsigned long long>(both[1], capacity_);
+    *total = both[0];
     if (pairs2 && both[1] < both[0]) {
         error_ = std::to_string(both[0]) + " pairs found but the device kept " + std::to_string(both[1]) +
                  " (pair_capacity " + std::to_string(capacity_) + ", split over " + std::to_string(kShards) +
@@ -847,6 +1151,7 @@ int Broadphase::download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uin
     }
     const uint64_t take = std::min<uint64_t>(std::min<uint64_t>(both[1], cap), capacity_);
     if (take && pairs2) {
+        if (int rc = compact(stream)) return rc;
         BP_TRY(hipMemcpyAsync(pairs2, pairs_, take * 8, hipMemcpyDeviceToHost, stream));
         BP_TRY(hipStreamSynchronize(stream));
     }

@@ -16,14 +16,22 @@ struct PairWindow {
     float lo, hi;
 };
 
+// Collision-filter palette of the world (null pointers: full 48-byte records carrying group and mask).
+struct FilterPalette {
+    const uint32_t* class_of_slot; // [slots]
+    const uint4* table;            // [256] (group, mask, static, 0)
+};
+
 class Broadphase {
 public:
     // n_slots: upper bound of bodies; pair_capacity: pairs kept per tick
     int configure(uint64_t n_slots, uint64_t pair_capacity);
     // Collect the overlapping pairs of the AABBs the tick kernel just wrote.
     int run(hipStream_t stream, const WorldView& w, uint64_t n_slots_ticked, const uint32_t* entity_of_slot,
-            const PairWindow* window = nullptr);
+            const PairWindow* window = nullptr, const FilterPalette* palette = nullptr);
     int download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uint64_t* total);
+    // The search leaves the pairs in 64 shard slices; this builds the compact list (idempotent until the next run).
+    int compact(hipStream_t stream);
     void release();
     const char* error() const { return error_.c_str(); }
     void* pairs_device() const { return pairs_; }
@@ -41,11 +49,17 @@ private:
     void* cell_count_ = nullptr; // uint32[table_size + 1]
     void* cell_start_ = nullptr; // uint32[table_size + 1]
     void* scan_tmp_ = nullptr;
+    void* scan_status_ = nullptr; // uint64[tiles] status words of the single-pass scan
+    uint32_t scan_epoch_ = 0;
+    bool three_kernel_scan_ = false;
+    bool full_records_ = false;
+    bool block_pairs_ = false;
     void* sorted_slot_ = nullptr; // uint32[n_slots]
     void* sorted_aabb_ = nullptr; // float4[n_slots][3] sorted records
     void* body_cell_ = nullptr;   // int32[n_slots][4]
     void* large_list_ = nullptr;  // uint32[n_slots]
     bool ran_ = false;
+    bool compacted_ = false;
 };
 
 } // namespace bge

@@ -418,12 +418,13 @@ __global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, co
                                  uint64_t first, uint64_t count,
                                  const uint32_t* __restrict__ type_bits, const float* __restrict__ inv_mass,
                                  const float* __restrict__ half_extent3, const uint32_t* __restrict__ group,
-                                 const uint32_t* __restrict__ mask, WorldView w)
+                                 const uint32_t* __restrict__ mask, const uint32_t* __restrict__ filter_class, WorldView w)
 {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
     const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
+    w.filter_class[slot] = filter_class[i];
     uint32_t f = w.flags[slot];
     f &= ~(kTypeMask | kBDirty | kSpin | kMassMask | kDrowsy); // a (re)created body is ACTIVE_TAG with its timer at zero
     f |= type_bits[i]; // body type, kBDirty and the mass class
@@ -483,6 +484,7 @@ __global__ void k_init_slots(uint64_t n_slots, const uint32_t* __restrict__ stru
     w.half_extent[3 * s] = w.half_extent[3 * s + 1] = w.half_extent[3 * s + 2] = 0.5f;
     w.group[s] = 1u;
     w.mask[s] = 0xffffffffu;
+    w.filter_class[s] = 0u;
     // mtxIdentity(local), mtxIdentity(world)
     for (int k = 0; k < 16; ++k) w.world[16 * s + k] = (k % 5 == 0) ? 1.0f : 0.0f;
     for (int k = 0; k < 6; ++k) w.aabb[6 * s + k] = 0.0f;
@@ -643,11 +645,12 @@ hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity
 
 hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                  const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
-                                 const uint32_t* group, const uint32_t* mask, const WorldView& w, const uint32_t* index)
+                                 const uint32_t* group, const uint32_t* mask, const uint32_t* filter_class, const WorldView& w,
+                                 const uint32_t* index)
 {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_bodies, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, index, first, count,
-                       type_bits, inv_mass, half_extent3, group, mask, w);
+                       type_bits, inv_mass, half_extent3, group, mask, filter_class, w);
     return hipGetLastError();
 }
 

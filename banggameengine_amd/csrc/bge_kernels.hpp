@@ -30,6 +30,7 @@ struct WorldView {
     float* half_extent;       // [slots][3]  AABB half extents of the collider in its own frame
     uint32_t* group;          // [slots]     collision filter group (layer)
     uint32_t* mask;           // [slots]
+    uint32_t* filter_class;   // [slots]     index of the body's (group, mask, static) triple in the world's filter palette
     float* aabb;              // [slots][6]  min xyz, max xyz fed to the broadphase
     float* normal;            // [slots][16] transpose(inverse(world)); allocated on first use
     const uint32_t* root_index; // [slots]   position of a root in the root table (read by roots only, when packing)
@@ -65,7 +66,7 @@ hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity
                               uint32_t width, const void* src, void* stage, const uint32_t* index = nullptr);
 hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                  const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
-                                 const uint32_t* group, const uint32_t* mask, const WorldView& w,
+                                 const uint32_t* group, const uint32_t* mask, const uint32_t* filter_class, const WorldView& w,
                                  const uint32_t* index = nullptr);
 hipError_t launch_scatter_velocities(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                      const float* lin, const float* ang, const WorldView& w);

@@ -119,7 +119,31 @@ struct bge_world {
     // device arrays
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
-    DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact;
+    DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table;
+    // Collision-filter palette: scenes use a handful of (layer, mask, static) combinations, so the broadphase's sorted
+    // records carry an 8-bit class instead of two 32-bit words (32-byte records instead of 48).  Class 0 = (1, ~0, not
+    // static), the component defaults; with more than 255 combinations the broadphase falls back to full records.
+    struct FilterKey {
+        uint32_t group, mask, is_static;
+        bool operator==(const FilterKey& o) const { return group == o.group && mask == o.mask && is_static == o.is_static; }
+    };
+    std::vector<FilterKey> filter_palette{FilterKey{1u, 0xffffffffu, 0u}};
+    bool filter_overflow = false;
+    bool filter_table_stale = true;
+    uint32_t filter_class_of(uint32_t group, uint32_t mask, bool is_static)
+    {
+        const FilterKey k{group, mask, is_static ? 1u : 0u};
+        for (size_t c = 0; c < filter_palette.size(); ++c) {
+            if (filter_palette[c] == k) return static_cast<uint32_t>(c);
+        }
+        if (filter_palette.size() >= 255) {
+            filter_overflow = true;
+            return 0;
+        }
+        filter_palette.push_back(k);
+        filter_table_stale = true;
+        return static_cast<uint32_t>(filter_palette.size() - 1);
+    }
     // Bullet's defaults (btRigidBodyConstructionInfo: 0.8 / 1.0; gDeactivationTime 2 s) — the reference never changes them
     float sleep_lin = 0.8f, sleep_ang = 1.0f, sleep_time = 2.0f;
     void fill_sleep(bge::TickParams& p) const
@@ -210,6 +234,7 @@ struct bge_world {
         view.aabb = aabb.as<float>();
         view.mass_palette = mass_palette.as<float2>();
         view.deact = deact.as<uint32_t>();
+        view.filter_class = filter_class.as<uint32_t>();
         view.root_index = root_index.as<uint32_t>();
         view.normal = normal.as<float>();
     }
@@ -217,7 +242,7 @@ struct bge_world {
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &deact, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count}) {
             b->release();
         }
@@ -507,7 +532,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     if (n_keep) {
         for (auto [buf, width] : std::initializer_list<std::pair<DevBuf*, uint32_t>>{
                  {&w->pos, 3}, {&w->euler, 3}, {&w->scale, 3}, {&w->world, 16}, {&w->vel, 3}, {&w->angvel, 3},
-                 {&w->quat, 4}, {&w->inv_mass, 1}, {&w->deact, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6}}) {
+                 {&w->quat, 4}, {&w->inv_mass, 1}, {&w->deact, 1}, {&w->filter_class, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6}}) {
             carries.push_back(Carry{buf, width, DevBuf{}});
         }
         for (Carry& c : carries) {
@@ -588,6 +613,8 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     HIP_TRY(w->quat.ensure(S * 16));
     HIP_TRY(w->inv_mass.ensure(S * 4));
     HIP_TRY(w->deact.ensure(S * 4));
+    HIP_TRY(w->filter_class.ensure(S * 4));
+    HIP_TRY(w->filter_table.ensure(256 * 16));
     HIP_TRY(w->half_extent.ensure(S * 12));
     HIP_TRY(w->group.ensure(S * 4));
     HIP_TRY(w->mask.ensure(S * 4));
@@ -749,12 +776,13 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
         w->palette_inv_mass.push_back(0.0f);
         w->palette_class[0u] = 0;
     }
-    std::vector<uint32_t> words(count * 7);
+    std::vector<uint32_t> words(count * 8);
     uint32_t* type_bits = words.data();
     float* inv_mass = reinterpret_cast<float*>(words.data() + count);
     float* he = reinterpret_cast<float*>(words.data() + 2 * count);
     uint32_t* group = words.data() + 5 * count;
     uint32_t* msk = words.data() + 6 * count;
+    uint32_t* fclass = words.data() + 7 * count;
     for (uint64_t i = 0; i < count; ++i) {
         const uint8_t t = type[i];
         if (t != BGE_BODY_NONE && t > BGE_BODY_KINEMATIC) return fail(BGE_ERR_INVALID, "type[%llu] = %u", (unsigned long long)i, t);
@@ -778,6 +806,7 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
         const uint32_t l = layer ? layer[i] : 1u;
         group[i] = l ? l : 1u;
         msk[i] = mask ? mask[i] : 0xffffffffu;
+        fclass[i] = t == BGE_BODY_NONE ? 0u : w->filter_class_of(group[i], msk[i], t == BGE_BODY_STATIC);
     }
     if (palette_changed) {
         std::vector<float2> pal(256, float2{0.0f, 0.0f});
@@ -794,7 +823,7 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
     const uint32_t* d = w->stage.as<uint32_t>();
     HIP_TRY(bge::launch_scatter_bodies(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, d,
                                        reinterpret_cast<const float*>(d + count), reinterpret_cast<const float*>(d + 2 * count),
-                                       d + 5 * count, d + 6 * count, w->view, di));
+                                       d + 5 * count, d + 6 * count, d + 7 * count, w->view, di));
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->maybe_dirty = true;
     return BGE_OK;
@@ -970,8 +999,21 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
             const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * w->flat.n_entities, 4096);
             int rc = w->broadphase.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
             if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->broadphase.error());
+            if (w->filter_table_stale && !w->filter_overflow) {
+                std::vector<uint32_t> tab(256 * 4, 0u);
+                for (size_t c = 0; c < w->filter_palette.size(); ++c) {
+                    tab[4 * c] = w->filter_palette[c].group;
+                    tab[4 * c + 1] = w->filter_palette[c].mask;
+                    tab[4 * c + 2] = w->filter_palette[c].is_static;
+                }
+                HIP_TRY(hipMemcpyAsync(w->filter_table.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, w->stream));
+                HIP_TRY(hipStreamSynchronize(w->stream)); // `tab` is a local
+                w->filter_table_stale = false;
+            }
+            const bge::FilterPalette palette{w->filter_overflow ? nullptr : w->filter_class.as<uint32_t>(),
+                                             w->filter_overflow ? nullptr : w->filter_table.as<uint4>()};
             rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
-                                   w->entity_of_slot.as<uint32_t>());
+                                   w->entity_of_slot.as<uint32_t>(), nullptr, &palette);
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
             w->pairs_from_slab = false;
             if (with_triggers) {
@@ -1466,7 +1508,14 @@ int bge_world_device_array(bge_world* w, int which, void** device_ptr, uint64_t*
     case BGE_ARRAY_ROOT_WORLDS: p = w->root_worlds.p; n = w->flat.root_slots.size(); break;
     case BGE_ARRAY_SLOT_OF_ENTITY: p = w->slot_of_entity.p; n = w->flat.n_entities; break;
     case BGE_ARRAY_POSITION: p = w->pos.p; n = w->flat.n_slots; break;
-    case BGE_ARRAY_PAIRS: p = w->broadphase.pairs_device(); n = w->broadphase.capacity(); break;
+    case BGE_ARRAY_PAIRS: {
+        bge::Broadphase& bp = w->pairs_from_slab ? w->slab_broadphase : w->broadphase;
+        DeviceGuard guard(w->device);
+        if (bp.compact(w->stream) != BGE_OK) return fail(BGE_ERR_HIP, "%s", bp.error());
+        p = bp.pairs_device();
+        n = bp.capacity();
+        break;
+    }
     case BGE_ARRAY_NORMAL: p = w->normal.p; n = w->normal.p ? w->flat.n_slots : 0; break;
     default: return fail(BGE_ERR_INVALID, "unknown device array %d", which);
     }
