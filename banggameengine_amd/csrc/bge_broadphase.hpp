@@ -53,6 +53,10 @@ private:
     uint32_t scan_epoch_ = 0;
     bool three_kernel_scan_ = false;
     bool full_records_ = false;
+    // two-level LDS counting sort (k_sort_*)
+    bool lds_sort_ = false;
+    uint32_t sort_shift_ = 12, sort_buckets_ = 0;
+    void *sort_matrix_ = nullptr, *sort_offsets_ = nullptr, *sort_status_ = nullptr, *coarse_ = nullptr;
     bool block_pairs_ = false;
     void* sorted_slot_ = nullptr; // uint32[n_slots]
     void* sorted_aabb_ = nullptr; // float4[n_slots][3] sorted records
