@@ -57,6 +57,8 @@ SYMBOLS = {
     "bge_world_download_activation": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
     "bge_world_set_sleeping": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float]),
     "bge_world_dirty_count": (C.c_int, [_vp, C.POINTER(_u64)]),
+    "bge_host_alloc": (C.c_int, [_u64, C.POINTER(_vp)]),
+    "bge_host_free": (C.c_int, [_vp]),
     "bge_world_set_global_ids": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_aabb_bounds": (C.c_int, [_vp, _vp, _vp, C.POINTER(_u64)]),
     "bge_world_axis_histogram": (C.c_int, [_vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32, _vp]),

@@ -134,6 +134,7 @@ void flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_tra
     if (flat) {
         out = Flattened{};
         out.n_entities = out.n_transforms = n;
+        out.identity = true;
         out.n_tiles_ticked = out.n_tiles_total = static_cast<uint32_t>((n + kTile - 1) / kTile);
         out.n_slots = static_cast<uint64_t>(out.n_tiles_total) * kTile;
         out.slot_of_entity.resize(n);

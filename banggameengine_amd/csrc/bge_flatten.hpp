@@ -63,6 +63,7 @@ struct Flattened {
     uint32_t n_tiles_ticked = 0; // tiles [0, n_tiles_ticked) are launched; the rest is limbo storage
     uint32_t n_tiles_total = 0;
     uint64_t n_limbo = 0;
+    bool identity = false;       // slot == entity index for every entity (flat scenes): copies need no gather / scatter
     uint32_t max_depth = 0; // deepest node (global depth, root = 0)
     std::vector<uint32_t> slot_of_entity;   // [n_entities] or kNone
     std::vector<uint32_t> entity_of_slot;   // [n_slots] or kNone

@@ -50,7 +50,7 @@ struct TriggerView {
 struct TickParams {
     float dt;
     float gx, gy, gz;
-    float sleep_lin2, sleep_ang2, sleep_time; // Bullet's sleeping thresholds (squared) and gDeactivationTime; time 0 = never sleep
+    float sleep_lin, sleep_lin2, sleep_ang2, sleep_time; // Bullet's sleeping thresholds (linear also squared, angular squared) and gDeactivationTime; time 0 = never sleep
     uint32_t tile_begin;
     uint32_t nt_out; // non-temporal stores for world / normal matrices (working set larger than the Infinity Cache)
     float* root_out; // when non-null: roots also write their world matrix to root_out[root_index] (send buffer of the all-gather)

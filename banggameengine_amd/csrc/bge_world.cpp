@@ -148,6 +148,7 @@ struct bge_world {
     float sleep_lin = 0.8f, sleep_ang = 1.0f, sleep_time = 2.0f;
     void fill_sleep(bge::TickParams& p) const
     {
+        p.sleep_lin = sleep_lin;
         p.sleep_lin2 = sleep_lin * sleep_lin;
         p.sleep_ang2 = sleep_ang * sleep_ang;
         p.sleep_time = sleep_time;
@@ -334,6 +335,12 @@ int download_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, 
                   const uint32_t* dev_index = nullptr)
 {
     const size_t bytes = static_cast<size_t>(count) * width * 4;
+    if (w->flat.identity && !dev_index) {
+        // flat scene: slot == entity index, the rows are already contiguous in entity order
+        HIP_TRY(hipMemcpyAsync(host, static_cast<const char*>(src) + first * width * 4, bytes, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        return BGE_OK;
+    }
     HIP_TRY(w->stage.ensure(bytes));
     HIP_TRY(bge::launch_gather_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, width, src, w->stage.p, dev_index));
     HIP_TRY(hipMemcpyAsync(host, w->stage.p, bytes, hipMemcpyDeviceToHost, w->stream));
@@ -1198,6 +1205,27 @@ int bge_world_set_sleeping(bge_world* w, float linear_threshold, float angular_t
     w->sleep_ang = angular_threshold;
     w->sleep_time = seconds;
     w->drop_graph();
+    return BGE_OK;
+}
+
+// Page-locked host memory: transfers to and from it run at the full PCIe rate (~55 GB/s against ~10 GB/s pageable).
+int bge_host_alloc(uint64_t bytes, void** out)
+{
+    if (!out) return fail(BGE_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? BGE_ERR_OOM : BGE_ERR_HIP, "hipHostMalloc(%llu): %s", (unsigned long long)bytes,
+                                     hipGetErrorString(e));
+    *out = p;
+    return BGE_OK;
+}
+
+int bge_host_free(void* p)
+{
+    if (!p) return BGE_OK;
+    const hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) return fail(BGE_ERR_HIP, "hipHostFree: %s", hipGetErrorString(e));
     return BGE_OK;
 }
 

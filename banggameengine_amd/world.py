@@ -104,9 +104,9 @@ class World:
         return float(ms.value), int(n.value)
 
     # -- results
-    def download_world(self, first=0, count=None):
+    def download_world(self, first=0, count=None, out=None):
         count = self.n - first if count is None else count
-        out = np.empty((count, 16), np.float32)
+        out = np.empty((count, 16), np.float32) if out is None else out
         check(lib().bge_world_download_world(self._h, first, count, _p(out)))
         return out
 
@@ -269,6 +269,25 @@ class World:
         if with_bodies:
             self.upload_bodies(wl.body_type)
         return self
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (bge_host_alloc); keep the object alive as long as the array is used."""
+
+    def __init__(self, shape, dtype=np.float32):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = C.c_void_p()
+        check(lib().bge_host_alloc(n, C.byref(self._p)))
+        buf = (C.c_char * max(n, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._p:
+                lib().bge_host_free(self._p)
+                self._p = C.c_void_p()
+        except Exception:
+            pass
 
 
 def balanced_cuts(hist, lo, hi, nranks):

@@ -183,6 +183,11 @@ BGE_API int bge_world_sync(bge_world* world);
 BGE_API int bge_world_profile_enable(bge_world* world, int enable);
 BGE_API int bge_world_profile_read(bge_world* world, double* tick_kernel_ms, uint64_t* ticks);
 
+/* Page-locked host buffers for the upload / download entry points: copies to and from them run at the PCIe rate
+ * (pageable memory: roughly a fifth of it).  Optional — every entry point accepts any host pointer. */
+BGE_API int bge_host_alloc(uint64_t bytes, void** out);
+BGE_API int bge_host_free(void* p);
+
 /* Results.  `Transform::world` after TransformSystem::Update; position/rotationEuler after PhysicsSystem::Update. */
 BGE_API int bge_world_download_world(bge_world* world, uint64_t first, uint64_t count, float* out16);
 BGE_API int bge_world_download_pose(bge_world* world, uint64_t first, uint64_t count, float* pos3, float* euler3);

@@ -737,3 +737,24 @@ def test_native_slab_exchange_single_rank_rehearsal():
     want = np.sort(gids[local], axis=1)
     want = want[np.lexsort((want[:, 1], want[:, 0]))]
     assert len(local) > 1000 and np.array_equal(got, want)
+
+
+def test_pinned_host_buffers_and_identity_layout_downloads():
+    """bge_host_alloc'ed (page-locked) destination buffers and the gather-free copy of flat scenes (slot == entity index)
+    return the same bytes as the staged path (a hierarchy forces the gather)."""
+    from banggameengine_amd.world import PinnedArray
+    for name, n in (("flat10k", 5000), ("chains4", 4000)):
+        wl = synth.config(name, n=n)
+        with B.World() as w:
+            run_world(w.load(wl), wl, 3)
+            plain = w.download_world()
+            pinned = PinnedArray((n, 16))
+            w.download_world(out=pinned.array)
+            part = w.download_world(first=100, count=700)
+            idx = w.download_world_indexed(np.arange(n - 1, -1, -1, dtype=np.uint32)) if hasattr(w, "download_world_indexed") else None
+        ref = run_oracle(build_oracle(wl), wl, 3)
+        assert_bits_equal(plain, ref.bulk_world()[0], name)
+        assert_bits_equal(pinned.array, plain, name + " pinned")
+        assert_bits_equal(part, plain[100:800], name + " sub-range")
+        if idx is not None:
+            assert_bits_equal(idx, plain[::-1], name + " indexed")

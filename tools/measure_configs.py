@@ -65,6 +65,13 @@ def gpu_rate(name, n, steps, extra=None):
             w.tick(dt=FIXED_DT, flags=flags)
             w.download_world()
         out["rate_with_d2h"] = wl.n * k / (time.perf_counter() - t0)
+        from banggameengine_amd.world import PinnedArray
+        pinned = PinnedArray((wl.n, 16))
+        t0 = time.perf_counter()
+        for _ in range(k):
+            w.tick(dt=FIXED_DT, flags=flags)
+            w.download_world(out=pinned.array)
+        out["rate_with_d2h_pinned"] = wl.n * k / (time.perf_counter() - t0)
         t0 = time.perf_counter()
         for _ in range(k):
             w.upload_trs(wl.pos, wl.euler, wl.scale)
@@ -110,7 +117,8 @@ def main():
               + (f"{r['cpu']['soa_rate']/1e6:.0f} M ({r['cpu']['soa_threads']} thr)" if 'soa_rate' in r['cpu'] else "—") + " |")
     for r in rows:
         if "rate_with_d2h" in r:
-            print(f"\nPCIe-inclusive, {r['label']}: tick + D2H of all world matrices {r['rate_with_d2h']/1e6:.0f} M updates/s; "
+            print(f"\nPCIe-inclusive, {r['label']}: tick + D2H of all world matrices {r['rate_with_d2h']/1e6:.0f} M updates/s "
+                  f"({r['rate_with_d2h_pinned']/1e6:.0f} M into page-locked memory); "
                   f"H2D of all TRS + transform tick {r['rate_with_h2d']/1e6:.0f} M updates/s")
 
 
