@@ -123,9 +123,13 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
         const uint64_t s = first + r * stride;
         uint32_t my_bin = 0;
         bool have_bin = false;
-        if (s < n_slots && is_body(flags[s])) {
-        const float2* b = reinterpret_cast<const float2*>(aabb + 6 * s);
+        // flags and AABB are loaded together (the AABB of a slot without a body is just not used): one memory round trip
+        // per body instead of two dependent ones
+        const uint64_t sc = s < n_slots ? s : 0;
+        const uint32_t fl = flags[sc];
+        const float2* b = reinterpret_cast<const float2*>(aabb + 6 * sc);
         const float2 b0 = b[0], b1 = b[1], b2 = b[2]; // min.x min.y | min.z max.x | max.y max.z
+        if (s < n_slots && is_body(fl)) {
         mn[0] = fminf(mn[0], b0.x);
         mn[1] = fminf(mn[1], b0.y);
         mn[2] = fminf(mn[2], b1.x);
@@ -557,14 +561,19 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_hist(uint64_t n_slots, ui
     __syncthreads();
     const GridParams g = acc->grid;
     const uint64_t begin = blockIdx.x * chunk, end = min(begin + chunk, n_slots);
+#pragma unroll 2
     for (uint64_t s = begin + threadIdx.x; s < end; s += kSortThreads) {
-        if (!is_body(flags[s])) continue;
-        const float* b = aabb + 6 * s;
+        // flags and AABB in one round trip (see k_bp_bounds)
+        const uint32_t fl = flags[s];
+        const float2* bp = reinterpret_cast<const float2*>(aabb + 6 * s);
+        const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+        if (!is_body(fl)) continue;
+        const float b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
         if (body_is_large(g, b)) {
             large_list[atomicAdd(&acc->n_large, 1u)] = static_cast<uint32_t>(s);
             continue;
         }
-        atomicAdd(&hist[cell_of(g, b) >> shift], 1u);
+        atomicAdd(&hist[cell_of(g, b[0], b[1], b[2]) >> shift], 1u);
     }
     __syncthreads();
     // bucket-major matrix: entry (bucket, workgroup)
@@ -584,18 +593,22 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_coarse(uint64_t n_slots, 
     __syncthreads();
     const GridParams g = acc->grid;
     const uint64_t begin = blockIdx.x * chunk, end = min(begin + chunk, n_slots);
+#pragma unroll 2
     for (uint64_t s = begin + threadIdx.x; s < end; s += kSortThreads) {
         const uint32_t f = flags[s];
+        const float2* bp = reinterpret_cast<const float2*>(aabb + 6 * s);
+        const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+        const uint32_t ent = entity_of_slot[s];
         if (!is_body(f)) continue;
-        const float* b = aabb + 6 * s;
+        const float b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
         if (body_is_large(g, b)) continue;
-        const uint32_t c = cell_of(g, b);
+        const uint32_t c = cell_of(g, b[0], b[1], b[2]);
         const uint64_t pos = atomicAdd(&cursor[c >> shift], 1u);
         if (COMPACT) {
-            coarse[2ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(entity_of_slot[s]));
+            coarse[2ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(ent));
             coarse[2ull * pos + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(class_of_slot[s]));
         } else {
-            coarse[3ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(entity_of_slot[s]));
+            coarse[3ull * pos] = make_float4(b[0], b[1], b[2], __uint_as_float(ent));
             coarse[3ull * pos + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(c));
             coarse[3ull * pos + 2] = make_float4(__uint_as_float(group[s]), __uint_as_float(mask[s]),
                                                  __uint_as_float((f & kTypeMask) == 1u ? 1u : 0u), __uint_as_float(static_cast<uint32_t>(s)));

@@ -758,3 +758,79 @@ def test_pinned_host_buffers_and_identity_layout_downloads():
         assert_bits_equal(part, plain[100:800], name + " sub-range")
         if idx is not None:
             assert_bits_equal(idx, plain[::-1], name + " indexed")
+
+
+@pytest.mark.parametrize("env", [
+    {},                                                     # LDS sort, 32-byte records, wave-granular search
+    {"BGE_BP_SORT": "atomic"},                              # the global-atomic counting sort (tables beyond 32 M cells)
+    {"BGE_BP_SORT": "atomic", "BGE_BP_SCAN": "3"},          # ... with the three-kernel scan
+    {"BGE_BP_RECORDS": "48"},                               # full records (more than 255 filter classes; slab search)
+    {"BGE_BP_PAIRS": "block"},                              # workgroup-granular pair search
+    {"BGE_BP_PAIRS": "block", "BGE_BP_RECORDS": "48", "BGE_BP_SORT": "atomic"},
+])
+def test_every_broadphase_code_path_gives_the_same_pairs(env, monkeypatch):
+    """The fallbacks of the broadphase (selected by scene size / palette overflow in production, by environment
+    variables here) against the oracle's pair set: statics, kinematics, layers, masks, capsules, a ground box."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 6000
+    wl = _cube(n, 30.0, seed=99)
+    rng = np.random.default_rng(5)
+    wl.body_type = rng.choice([0, 1, 1, 1, 2], n).astype(np.uint8)
+    layer = rng.choice([0, 1, 2, 4], n).astype(np.uint32)
+    mask = rng.choice([0xFFFFFFFF, 1, 2, 6], n).astype(np.uint32)
+    size = np.full((n, 3), 0.5, np.float32)
+    size[0] = (50.0, 1.0, 50.0)
+    shape = np.zeros(n, np.uint8)
+    shape[2:200] = 1
+    wl.body_type[0] = 0
+    kw = dict(size=size, shape=shape, layer=layer, mask=mask)
+    ref = run_oracle(build_oracle(wl, aabbs=True, **kw), wl, 2)
+    with B.World(pair_capacity=64 * n) as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, **kw)
+        run_world(w, wl, 2, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+        got = w.pairs(cap=64 * n)
+    assert np.array_equal(got, ref.pairs("sweep"))
+
+
+def test_more_than_255_filter_classes_fall_back_to_full_records():
+    n = 4000
+    wl = _cube(n, 24.0, seed=3)
+    rng = np.random.default_rng(9)
+    layer = (1 + (np.arange(n) % 400)).astype(np.uint32)           # 400 distinct layers x 2 masks -> palette overflow
+    mask = rng.choice([0xFFFFFFFF, 0x0000FFFF], n).astype(np.uint32)
+    ref = run_oracle(build_oracle(wl, aabbs=True, layer=layer, mask=mask), wl, 2)
+    with B.World(pair_capacity=64 * n) as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, layer=layer, mask=mask)
+        run_world(w, wl, 2, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+        got = w.pairs(cap=64 * n)
+    want = ref.pairs("sweep")
+    assert len(want) > 500 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("layout", ["sparse", "two-clusters", "one-bucket"])
+def test_broadphase_on_skewed_scenes(layout):
+    """The LDS sort's coarse buckets under skew: a huge, almost empty extent; two dense clusters far apart (most buckets
+    empty, two crowded); everything inside one bucket."""
+    n = 12_000
+    wl = _cube(n, 1.0, seed=17)                   # unit cube of offsets, spread below
+    u = wl.pos.copy()
+    if layout == "sparse":
+        wl.pos = (u * np.float32(3000.0)).astype(np.float32)
+    elif layout == "two-clusters":
+        wl.pos = (u * np.float32(22.0)).astype(np.float32)
+        wl.pos[n // 2:] += np.float32(5000.0)
+    else:
+        wl.pos = (u * np.float32(26.0)).astype(np.float32)
+    ref = run_oracle(build_oracle(wl, aabbs=True), wl, 2)
+    with B.World(pair_capacity=64 * n) as w:
+        run_world(w.load(wl), wl, 2, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+        got = w.pairs(cap=64 * n)
+    want = ref.pairs("sweep")
+    if layout != "sparse":
+        assert len(want) > 3000
+    assert np.array_equal(got, want)
