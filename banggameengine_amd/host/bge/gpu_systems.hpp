@@ -87,13 +87,13 @@ public:
             auto it = index_of_.find(id);
             if (it != index_of_.end()) index_list_.push_back(it->second);
         }
-        stage_.resize(index_list_.size() * 16);
+        if (!down_.resize(index_list_.size() * 16 + 1)) return Log("bge_host_alloc");
         if (!index_list_.empty() &&
-            bge_world_download_world_indexed(world_, index_list_.size(), index_list_.data(), stage_.data()) != BGE_OK) {
+            bge_world_download_world_indexed(world_, index_list_.size(), index_list_.data(), down_.data()) != BGE_OK) {
             return Log("bge_world_download_world_indexed");
         }
         for (size_t k = 0; k < index_list_.size(); ++k) {
-            if (auto* t = scene.GetTransform(ids_[index_list_[k]])) std::memcpy(t->world, &stage_[16 * k], 64);
+            if (auto* t = scene.GetTransform(ids_[index_list_[k]])) std::memcpy(t->world, &down_[16 * k], 64);
         }
         return true;
     }
@@ -115,14 +115,14 @@ public:
             }
             return true;
         }
-        stage_.resize(n * 16);
-        if (n && bge_world_download_world(world_, 0, n, stage_.data()) != BGE_OK) return Log("bge_world_download_world");
+        if (!down_.resize(n * 16 + 1)) return Log("bge_host_alloc");
+        if (n && bge_world_download_world(world_, 0, n, down_.data()) != BGE_OK) return Log("bge_world_download_world");
         limbo_.resize(n);
         if (n && bge_world_download_dirty(world_, 0, n, limbo_.data()) != BGE_OK) return Log("bge_world_download_dirty");
         for (auto& kv : scene.GetTransforms()) {
             const uint32_t i = index_of_[kv.first];
             if (limbo_[i]) continue; // inside a parent cycle: the reference never reaches it, it stays dirty
-            std::memcpy(kv.second.world, &stage_[16 * static_cast<size_t>(i)], 64);
+            std::memcpy(kv.second.world, &down_[16 * static_cast<size_t>(i)], 64);
             kv.second.dirty = false;
             written_[i] = 0;
         }
@@ -152,19 +152,19 @@ public:
             if (static_cast<int>(kv.second.type) == 1) index_list_.push_back(it->second);
         }
         const size_t m = index_list_.size();
-        stage_.resize(m * 6);
-        if (m && bge_world_download_pose_indexed(world_, m, index_list_.data(), stage_.data(), stage_.data() + 3 * m) != BGE_OK) {
+        if (!down_.resize(m * 6 + 1)) return Log("bge_host_alloc");
+        if (m && bge_world_download_pose_indexed(world_, m, index_list_.data(), down_.data(), down_.data() + 3 * m) != BGE_OK) {
             return Log("bge_world_download_pose_indexed");
         }
         for (size_t k = 0; k < m; ++k) {
             const uint32_t i = index_list_[k];
             auto* t = scene.GetTransform(ids_[i]);
             if (!t) continue;
-            std::memcpy(static_cast<void*>(&t->position), &stage_[3 * k], 12);
-            std::memcpy(static_cast<void*>(&t->rotationEuler), &stage_[3 * m + 3 * k], 12);
+            std::memcpy(static_cast<void*>(&t->position), &down_[3 * k], 12);
+            std::memcpy(static_cast<void*>(&t->rotationEuler), &down_[3 * m + 3 * k], 12);
             t->MarkDirty();
-            std::memcpy(&last_pose_[6 * static_cast<size_t>(i)], &stage_[3 * k], 12);
-            std::memcpy(&last_pose_[6 * static_cast<size_t>(i) + 3], &stage_[3 * m + 3 * k], 12);
+            std::memcpy(&last_pose_[6 * static_cast<size_t>(i)], &down_[3 * k], 12);
+            std::memcpy(&last_pose_[6 * static_cast<size_t>(i) + 3], &down_[3 * m + 3 * k], 12);
             written_[i] = 1;
         }
         return true;
@@ -430,6 +430,33 @@ private:
     std::vector<BodyState> body_;
     std::vector<float> last_pose_;              // position + euler the physics write-back stored (6 floats per index)
     std::vector<float> stage_, repack_;
+    // Destination of the downloads: page-locked (bge_host_alloc), so the copies run at the PCIe rate instead of the
+    // pageable ~10 GB/s; grow-only.
+    struct PinnedFloats {
+        float* p = nullptr;
+        size_t cap = 0;
+        ~PinnedFloats() { bge_host_free(p); }
+        PinnedFloats() = default;
+        PinnedFloats(const PinnedFloats&) = delete;
+        PinnedFloats& operator=(const PinnedFloats&) = delete;
+        float* resize(size_t n)
+        {
+            if (n > cap) {
+                bge_host_free(p);
+                p = nullptr;
+                cap = 0;
+                void* q = nullptr;
+                const size_t want = n + n / 4;
+                if (bge_host_alloc(want * sizeof(float), &q) == BGE_OK) {
+                    p = static_cast<float*>(q);
+                    cap = want;
+                }
+            }
+            return p;
+        }
+        float& operator[](size_t i) { return p[i]; }
+        float* data() { return p; }
+    } down_;
     std::vector<uint8_t> b_type_, b_shape_;
     std::vector<float> b_mass_, b_size_;
     std::vector<uint32_t> b_layer_, b_mask_;
