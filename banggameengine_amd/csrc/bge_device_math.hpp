@@ -119,8 +119,11 @@ __device__ __forceinline__ void bx_mtx_srt(float (&m)[16], const F3& s, const F3
 }
 
 // out = a * b, each element ((a0*b[j] + a1*b[4+j]) + a2*b[8+j]) + a3*b[12+j]   (bx::vec4MulMtx)
+// Two output columns per instruction (v_pk_mul_f32 / v_pk_add_f32): 56 packed operations instead of 112 scalar ones,
+// the same IEEE rounding per component and operation and the same association, so the bits do not change.
 __device__ __forceinline__ void bx_mtx_mul(float (&o)[16], const float (&a)[16], const float (&b)[16])
 {
+#ifdef BGE_EXPERIMENT_SCALAR_MTXMUL /* timing-only A/B build */
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -129,6 +132,21 @@ __device__ __forceinline__ void bx_mtx_mul(float (&o)[16], const float (&a)[16],
                            + a[4 * i + 3] * b[12 + j];
         }
     }
+#else
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 b0 = {b[2 * h], b[2 * h + 1]}, b1 = {b[4 + 2 * h], b[5 + 2 * h]};
+        const f32x2 b2 = {b[8 + 2 * h], b[9 + 2 * h]}, b3 = {b[12 + 2 * h], b[13 + 2 * h]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 a0 = {a[4 * i], a[4 * i]}, a1 = {a[4 * i + 1], a[4 * i + 1]};
+            const f32x2 a2 = {a[4 * i + 2], a[4 * i + 2]}, a3 = {a[4 * i + 3], a[4 * i + 3]};
+            const f32x2 r = ((a0 * b0 + a1 * b1) + a2 * b2) + a3 * b3;
+            o[4 * i + 2 * h] = r.x;
+            o[4 * i + 2 * h + 1] = r.y;
+        }
+    }
+#endif
 }
 
 // normalMtx = transpose(inverse(world)) as Renderer::BeginFrame computes it per mesh entity
