@@ -93,8 +93,18 @@ private:
             return false;
         }
         const char c = s_[p_];
-        if (c == '{') return object(v);
-        if (c == '[') return array(v);
+        if (c == '{' || c == '[') {
+            // bounded nesting: the parser is recursive, and a file of 100 000 '[' must be an error, not a stack overflow
+            // (found by tests/cpp/sanitize_host.cpp); the reference's scenes nest 4 levels deep
+            if (depth_ >= kMaxDepth) {
+                msg_ = "nesting deeper than " + std::to_string(kMaxDepth);
+                return false;
+            }
+            ++depth_;
+            const bool ok = c == '{' ? object(v) : array(v);
+            --depth_;
+            return ok;
+        }
         if (c == '"') {
             v.kind = Value::String;
             return string(v.str);
@@ -255,6 +265,8 @@ private:
 
     const std::string& s_;
     size_t p_ = 0;
+    static constexpr int kMaxDepth = 128;
+    int depth_ = 0;
     std::string msg_;
 };
 
