@@ -155,14 +155,25 @@ def main():
         rows_per_rank = int(rows.item())
         native = args.collective == "rccl"
         if native:
+            ok = 1
             try:
                 uid = [B.World.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
                 world.comm_init(n_gpus, rank, uid[0], rows_per_rank)
+            except Exception as e:  # transport choice only: the torch path moves the same bytes
+                print(f"[bench] rank {rank}: native RCCL init failed ({e})", file=sys.stderr)
+                ok = 0
+            # the choice of transport must be the same on every rank, or the first collective deadlocks
+            agreed = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 1:
                 collective = (f"ncclAllGather (RCCL, native in libbge_world) of {rows_per_rank} x 64 B root world matrices "
                               "per rank per step, side stream, double-buffered")
-            except Exception as e:  # transport choice only: the torch path moves the same bytes
-                print(f"[bench] native RCCL init failed ({e}); using torch.distributed", file=sys.stderr)
+            else:
+                if ok:
+                    world.comm_destroy()
+                if rank == 0:
+                    print("[bench] using torch.distributed for the root gather on every rank", file=sys.stderr)
                 native = False
         if not native:
             from banggameengine_amd.sharding import RootTable

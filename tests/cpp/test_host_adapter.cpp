@@ -254,6 +254,28 @@ int main()
         w.CompareAll("back in coherent mode");
     }
 
-    if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, 10 ticks, %zu trigger events)\n", w.gpu.GetTransformCount(), w.events_seen);
+    // sleeping through the adapter: no gravity, freshly re-created bodies stand still, Bullet's deactivation puts them to
+    // sleep after 2 s (240 ticks); a teleport moves a sleeper without waking it; host `dirty` flags stay coherent throughout
+    {
+        w.gpuPhysics.SetGravity(0.0f);
+        w.refPhysics.gravityY = 0.0f;
+        for (auto& kv : w.ref.GetRigidBodies()) kv.second.dirty = true;
+        for (auto& kv : w.gpu.GetRigidBodies()) kv.second.dirty = true;
+        for (int k = 0; k < 246; ++k) {
+            if (k == 243) {
+                float p[3] = {3.0f, 4.0f, 5.0f};
+                w.Move(ids[2000], p, true);
+            }
+            w.Tick();
+        }
+        size_t asleep = 0;
+        for (auto& kv : w.refPhysics.Runtimes()) asleep += kv.second.activation == orc::kIslandSleeping && kv.second.invMass != 0.0f;
+        CHECK(asleep > 100, "only %zu bodies fell asleep in the oracle", asleep);
+        w.gpuPhysics.SetGravity(-9.81f);
+        w.refPhysics.gravityY = -9.81f;
+        for (int k = 0; k < 3; ++k) w.Tick(); // gravity does not touch sleepers
+    }
+
+    if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, 259 ticks, %zu trigger events)\n", w.gpu.GetTransformCount(), w.events_seen);
     return g_failures ? 1 : 0;
 }
