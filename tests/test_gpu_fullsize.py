@@ -44,3 +44,40 @@ def test_full_size_bitwise(name, n, ticks):
     want_world = npo.resolve_world(wl.parent, pos, euler, wl.scale)
     assert_bits_equal(world, want_world, "world")
     del world, want_world
+
+
+def test_slab_broadphase_full_size_equals_single_world():
+    """configs[3]'s 4 M bodies split over 4 worlds (entity i -> shard i % 4: interleaved in space): the union of the slabs'
+    pair lists must be exactly the single world's pair list — 12.6 M pairs, no duplicates."""
+    from banggameengine_amd import sharding
+    n, nshards = 4_000_000, 4
+    wl = synth.config("cube4m", n=n)
+    with B.World() as w:
+        run_world(w.load(wl), wl, 3, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+        total = w.pair_count()
+        want = w.pairs(cap=total)
+    worlds = []
+    try:
+        for r in range(nshards):
+            ids = np.arange(r, n, nshards, dtype=np.uint32)
+            s = B.World(pair_capacity=16 * len(ids))
+            s.set_topology(np.full(len(ids), 0xFFFFFFFF, np.uint32))
+            s.upload_trs(wl.pos[ids], wl.euler[ids], wl.scale[ids])
+            s.upload_bodies(wl.body_type[ids])
+            s.set_global_ids(ids)
+            for k in range(3):
+                s.tick(dt=DT, flags=B.TICK_ALL | B.TICK_AABBS)
+                if k == 0:
+                    s.set_velocities(wl.vel[ids])
+            worlds.append(s)
+        counts, cuts = sharding.slab_broadphase_local(worlds, axis=2)
+        got = np.concatenate([s.pairs(cap=max(s.pair_count(), 1)) for s in worlds])
+    finally:
+        for s in worlds:
+            s.close()
+    assert len(got) == total and total > 10_000_000
+    key = got[:, 0].astype(np.uint64) << np.uint64(32) | got[:, 1]
+    key.sort()
+    assert (np.diff(key) != 0).all()
+    assert np.array_equal(key, want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1])
+    assert n <= counts.sum() < 1.05 * n
