@@ -78,6 +78,7 @@ SYMBOLS = {
     "bge_world_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _u64]),
     "bge_world_gather_roots": (C.c_int, [_vp, C.POINTER(_vp)]),
     "bge_world_comm_wait": (C.c_int, [_vp]),
+    "bge_world_comm_set_mode": (C.c_int, [_vp, C.c_int]),
     "bge_world_download_gathered": (C.c_int, [_vp, _vp, _u64]),
     "bge_world_comm_destroy": (C.c_int, [_vp]),
     "bge_flatten_topology": (C.c_int, [_u64, _vp, _vp, _vp, _vp, _vp, C.POINTER(WorldInfo)]),

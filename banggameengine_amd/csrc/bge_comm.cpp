@@ -147,7 +147,22 @@ int RootComm::gather(hipStream_t compute, void** table_device)
     const int b = static_cast<int>(frame_ % kRing);
     COMM_HIP(hipEventRecord(packed_[b], compute));
     COMM_HIP(hipStreamWaitEvent(side_, packed_[b], 0));
-    COMM_NCCL(rccl().AllGather(send_[b], table_[b], rows_ * 16, ncclFloat32, static_cast<ncclComm_t>(comm_), side_));
+    if (mode_ == 1) {
+        // direct schedule over the xGMI mesh: one send and one receive per peer, all inside one group
+        const size_t words = rows_ * 16;
+        COMM_NCCL(rccl().GroupStart());
+        ncclResult_t first_error = ncclSuccess;
+        for (int p = 0; p < nranks_; ++p) {
+            ncclResult_t e = rccl().Send(send_[b], words, ncclFloat32, p, static_cast<ncclComm_t>(comm_), side_);
+            if (e != ncclSuccess && first_error == ncclSuccess) first_error = e;
+            e = rccl().Recv(table_[b] + static_cast<size_t>(p) * words, words, ncclFloat32, p, static_cast<ncclComm_t>(comm_), side_);
+            if (e != ncclSuccess && first_error == ncclSuccess) first_error = e;
+        }
+        COMM_NCCL(rccl().GroupEnd());
+        if (first_error != ncclSuccess) return fail(BGE_ERR_HIP, std::string("ncclSend/ncclRecv: ") + rccl().GetErrorString(first_error));
+    } else {
+        COMM_NCCL(rccl().AllGather(send_[b], table_[b], rows_ * 16, ncclFloat32, static_cast<ncclComm_t>(comm_), side_));
+    }
     COMM_HIP(hipEventRecord(gathered_[b], side_));
     in_flight_[b] = true;
     if (table_device) *table_device = table_[b];

@@ -28,6 +28,12 @@ public:
     int gather(hipStream_t compute, void** table_device);
     int wait(hipStream_t compute);
     int rank() const { return rank_; }
+    // How a frame's root table is gathered: 0 = one ncclAllGather; 1 = DIRECT: one ncclSend + ncclRecv per peer inside one
+    // group, i.e. every rank pushes its block over its own xGMI link to each peer (the node is a full mesh, so no hop
+    // relays another rank's data).  Which one is faster depends on the RCCL build and the message size: bench.py times
+    // both on the node it runs on.
+    void set_mode(int mode) { mode_ = mode; }
+    int mode() const { return mode_; }
     // Small helpers of the sharded broadphase (bge_route.hip), all enqueued on `stream`:
     int all_reduce_max(hipStream_t stream, float* device_values, size_t n);
     int all_reduce_sum_u64(hipStream_t stream, uint64_t* device_values, size_t n);
@@ -53,6 +59,7 @@ private:
     hipEvent_t packed_[kRing] = {};   // compute -> side: roots of the frame are packed
     hipEvent_t gathered_[kRing] = {}; // side -> compute: the gather of that frame is complete
     bool in_flight_[kRing] = {};
+    int mode_ = 0;
 };
 
 } // namespace bge

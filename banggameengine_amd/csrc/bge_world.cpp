@@ -1604,6 +1604,16 @@ int bge_world_download_gathered(bge_world* w, float* out, uint64_t floats)
     return BGE_OK;
 }
 
+int bge_world_comm_set_mode(bge_world* w, int mode)
+{
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (mode != BGE_GATHER_ALLGATHER && mode != BGE_GATHER_DIRECT) return fail(BGE_ERR_INVALID, "unknown gather mode %d", mode);
+    DeviceGuard guard(w->device);
+    if (w->comm.ready() && w->comm.wait(w->stream) != BGE_OK) return fail(BGE_ERR_HIP, "%s", w->comm.error());
+    w->comm.set_mode(mode);
+    return BGE_OK;
+}
+
 int bge_world_comm_wait(bge_world* w)
 {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");

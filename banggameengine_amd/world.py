@@ -249,6 +249,10 @@ class World:
     def comm_wait(self):
         check(lib().bge_world_comm_wait(self._h))
 
+    def comm_set_mode(self, mode: int):
+        """0 = ncclAllGather, 1 = direct send/recv per peer (include/bge_world.h)."""
+        check(lib().bge_world_comm_set_mode(self._h, int(mode)))
+
     def comm_destroy(self):
         check(lib().bge_world_comm_destroy(self._h))
 

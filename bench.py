@@ -44,6 +44,8 @@ def parse_args():
                          "torch: torch.distributed.all_gather_into_tensor")
     ap.add_argument("--no-overlap", action="store_true", help="issue the all-gather on the compute stream instead of "
                                                               "double-buffered on a side stream")
+    ap.add_argument("--gather-mode", choices=["allgather", "direct"], default=None,
+                    help="force the schedule of the native root gather (default: time both before the timed region, keep the faster)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-core CPU leg (a 1-GPU box's CPU share)")
@@ -104,6 +106,12 @@ def load_traffic(workload_name, entities):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the result.  Libraries print there too (RCCL writes its version banner to fd 1
+    # when the first communicator is created), so fd 1 is pointed at stderr for the duration of the run and the JSON line
+    # goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -167,8 +175,8 @@ def main():
             agreed = torch.tensor([ok], dtype=torch.int64, device="cuda")
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             if int(agreed.item()) == 1:
-                collective = (f"ncclAllGather (RCCL, native in libbge_world) of {rows_per_rank} x 64 B root world matrices "
-                              "per rank per step, side stream, double-buffered")
+                collective = (f"native RCCL gather (libbge_world) of {rows_per_rank} x 64 B root world matrices per rank per "
+                              "step, side stream, ring of 8 buffers")
             else:
                 if ok:
                     world.comm_destroy()
@@ -204,6 +212,31 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    gather_trials = None
+    if gather and native and not args.gather_mode:
+        # Which schedule moves the root table faster — one ncclAllGather, or a direct send/recv per peer over the xGMI
+        # mesh — depends on the RCCL build, the rank count and the message size: measure both on THIS node (untimed
+        # tuning, like the warm-up), keep the faster one on every rank (the decision is an all-reduced number).
+        gather_trials = {}
+        for mode in (0, 1):
+            world.comm_set_mode(mode)
+            world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags | B.TICK_GATHER_ROOTS, ticks=8)
+            barrier()
+            t_a = time.perf_counter()
+            world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags | B.TICK_GATHER_ROOTS, ticks=40)
+            barrier()
+            el = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device="cuda")
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            gather_trials[mode] = float(el.item()) / 40 * 1e3
+        best = min(gather_trials, key=gather_trials.get)
+        world.comm_set_mode(best)
+        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags | B.TICK_GATHER_ROOTS, ticks=8)
+        barrier()
+        collective += (f"; schedule {'direct send/recv per peer' if best else 'ncclAllGather'} chosen by trial "
+                       f"(ms per frame: all-gather {gather_trials[0]:.4f}, direct {gather_trials[1]:.4f})")
+    elif gather and native and args.gather_mode:
+        world.comm_set_mode({"allgather": 0, "direct": 1}[args.gather_mode])
+        collective += f"; schedule forced: {args.gather_mode}"
     # Timed region: exactly K steps, no per-step host work.  Without a collective the K tick launches are
     # bracketed by ONE HIP event pair recorded by the library on the launch stream (bge_world_profile_enable(1)),
     # so the roofline figure is the average launch duration inside the timed region, gaps included.
@@ -301,6 +334,7 @@ def main():
                 "tiles": info["n_tiles"], "passes": info["n_passes"], "roots_per_gpu": n_roots,
                 "collective": collective,
                 "gather_check": gather_check,
+                "gather_schedule_trials_ms": gather_trials,
                 "dt": FIXED_DT, "gravity": list(GRAVITY),
                 "bytes_per_update_algorithmic": bytes_per_update,
             },
@@ -320,7 +354,8 @@ def main():
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
             out["cpu_allcore"] = cpu_allcore(wl, args.cpu_seconds / 2, args.cpu_threads)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     if gather and native:
         world.comm_destroy()

@@ -268,6 +268,11 @@ BGE_API int bge_comm_unique_id(void* out128);
 BGE_API int bge_world_comm_init(bge_world* world, int nranks, int rank, const void* id128, uint64_t rows_per_rank);
 BGE_API int bge_world_gather_roots(bge_world* world, void** table_device);
 BGE_API int bge_world_comm_wait(bge_world* world);
+/* How the frame's root table travels: one ncclAllGather (default), or DIRECT — one ncclSend + ncclRecv per peer in one
+ * group, every rank pushing its block to each peer over its own xGMI link (the node is a full mesh).  Same table either
+ * way; call on every rank.  bench.py times both on the node it runs on and keeps the faster one. */
+enum bge_gather_mode { BGE_GATHER_ALLGATHER = 0, BGE_GATHER_DIRECT = 1 };
+BGE_API int bge_world_comm_set_mode(bge_world* world, int mode);
 /* Copy the most recently gathered table to the host (waits for it): nranks x rows_per_rank x 16 floats. */
 BGE_API int bge_world_download_gathered(bge_world* world, float* out, uint64_t floats);
 BGE_API int bge_world_comm_destroy(bge_world* world);

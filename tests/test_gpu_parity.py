@@ -231,8 +231,8 @@ def test_mass_palette_and_per_slot_fallback(distinct):
     assert_bits_equal(got_world, ref.bulk_world()[0], "world")
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_native_root_gather_single_rank(fused):
+@pytest.mark.parametrize("fused,mode", [(True, 0), (False, 0), (True, 1), (False, 1)])
+def test_native_root_gather_single_rank(fused, mode):
     """One-rank rehearsal of the native RCCL path: the gathered table must be this rank's root world matrices, both
     when the roots write the send buffer from inside the tick kernel (BGE_TICK_GATHER_ROOTS) and through the
     separate packing kernel (bge_world_gather_roots)."""
@@ -241,6 +241,7 @@ def test_native_root_gather_single_rank(fused):
     with B.World() as w:
         w.load(wl)
         w.comm_init(1, 0, B.World.comm_unique_id(), len(roots) + 5)   # padded rows stay zero
+        w.comm_set_mode(mode)                                         # 0 ncclAllGather, 1 direct send/recv per peer
         for k in range(3):   # buffers alternate: exercise both
             if fused:
                 w.tick(dt=DT, flags=B.TICK_ALL | B.TICK_GATHER_ROOTS)
