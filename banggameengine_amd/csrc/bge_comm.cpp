@@ -119,9 +119,9 @@ int RootComm::init(int nranks, int rank, const void* id128, uint64_t rows_per_ra
     frame_ = 0;
     COMM_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     for (int b = 0; b < kRing; ++b) {
-        COMM_HIP(hipMalloc(reinterpret_cast<void**>(&send_[b]), rows_ * 64));
-        COMM_HIP(hipMalloc(reinterpret_cast<void**>(&table_[b]), rows_ * 64 * static_cast<size_t>(nranks)));
-        COMM_HIP(hipMemset(send_[b], 0, rows_ * 64));
+        COMM_HIP(hipMalloc(reinterpret_cast<void**>(&send_[b]), rows_ * kRowFloats * 4));
+        COMM_HIP(hipMalloc(reinterpret_cast<void**>(&table_[b]), rows_ * kRowFloats * 4 * static_cast<size_t>(nranks)));
+        COMM_HIP(hipMemset(send_[b], 0, rows_ * kRowFloats * 4));
         COMM_HIP(hipEventCreateWithFlags(&packed_[b], hipEventDisableTiming));
         COMM_HIP(hipEventCreateWithFlags(&gathered_[b], hipEventDisableTiming));
         in_flight_[b] = false;
@@ -149,7 +149,7 @@ int RootComm::gather(hipStream_t compute, void** table_device)
     COMM_HIP(hipStreamWaitEvent(side_, packed_[b], 0));
     if (mode_ == 1) {
         // direct schedule over the xGMI mesh: one send and one receive per peer, all inside one group
-        const size_t words = rows_ * 16;
+        const size_t words = rows_ * kRowFloats;
         COMM_NCCL(rccl().GroupStart());
         ncclResult_t first_error = ncclSuccess;
         for (int p = 0; p < nranks_; ++p) {
@@ -161,7 +161,7 @@ int RootComm::gather(hipStream_t compute, void** table_device)
         COMM_NCCL(rccl().GroupEnd());
         if (first_error != ncclSuccess) return fail(BGE_ERR_HIP, std::string("ncclSend/ncclRecv: ") + rccl().GetErrorString(first_error));
     } else {
-        COMM_NCCL(rccl().AllGather(send_[b], table_[b], rows_ * 16, ncclFloat32, static_cast<ncclComm_t>(comm_), side_));
+        COMM_NCCL(rccl().AllGather(send_[b], table_[b], rows_ * kRowFloats, ncclFloat32, static_cast<ncclComm_t>(comm_), side_));
     }
     COMM_HIP(hipEventRecord(gathered_[b], side_));
     in_flight_[b] = true;

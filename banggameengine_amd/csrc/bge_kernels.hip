@@ -70,9 +70,12 @@ __device__ __forceinline__ void load_world(const float* __restrict__ world, uint
 // consecutive lanes, so the 64-byte rows of a wave form one contiguous run).
 __device__ __forceinline__ void store_root(float* __restrict__ root_out, uint32_t index, const float (&m)[16])
 {
-    float4* dst = reinterpret_cast<float4*>(root_out) + 4ull * index;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dst[r] = make_float4(m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]);
+    // compact row, 48 bytes: a root's world matrix is its local matrix (Transform.cpp:32-35), whose fourth column is
+    // exactly (0, 0, 0, 1) (bx::mtxSRT) — the gather moves the 12 floats that carry information
+    float4* dst = reinterpret_cast<float4*>(root_out) + 3ull * index;
+    dst[0] = make_float4(m[0], m[1], m[2], m[4]);
+    dst[1] = make_float4(m[5], m[6], m[8], m[9]);
+    dst[2] = make_float4(m[10], m[12], m[13], m[14]);
 }
 
 // Stores of results the tick never reads again (world / normal matrices).  Non-temporal when the host asks for it:
@@ -525,7 +528,25 @@ __global__ void k_dirty_bytes(const uint32_t* __restrict__ slot_of_entity, uint6
     out[i] = (slot != kNone && (flags[slot] & kTDirty)) ? 1 : 0;
 }
 
-// Root table for the per-frame all-gather: 4 lanes per root, 16 B each.
+// Compact root rows (12 floats, see store_root): 3 lanes per root, 16 B each.
+__global__ void k_pack_roots_compact(uint64_t n_roots, const uint32_t* __restrict__ root_slots, const float* __restrict__ world,
+                                     float4* __restrict__ dst)
+{
+    const uint64_t t = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t r = t / 3;
+    if (r >= n_roots) return;
+    const uint32_t q = static_cast<uint32_t>(t - 3 * r);
+    const float* m = world + 16ull * root_slots[r];
+    float v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t cidx = 4u * q + k; // position in the compact row -> element of the 4x4 (skip column 3)
+        v[k] = m[cidx + cidx / 3u];
+    }
+    dst[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Full 4x4 rows (the torch.distributed path of sharding.RootTable): 4 lanes per root, 16 B each.
 __global__ void k_pack_roots(uint64_t n_roots, const uint32_t* __restrict__ root_slots, const float4* __restrict__ world,
                              float4* __restrict__ dst)
 {
@@ -715,11 +736,17 @@ hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n
     return hipGetLastError();
 }
 
-hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst)
+hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst,
+                             bool compact)
 {
     if (n_roots == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_roots, grid_for(n_roots * 4, 256), dim3(256), 0, stream, n_roots, root_slots,
-                       reinterpret_cast<const float4*>(world), reinterpret_cast<float4*>(dst));
+    if (compact) {
+        hipLaunchKernelGGL(k_pack_roots_compact, grid_for(n_roots * 3, 256), dim3(256), 0, stream, n_roots, root_slots, world,
+                           reinterpret_cast<float4*>(dst));
+    } else {
+        hipLaunchKernelGGL(k_pack_roots, grid_for(n_roots * 4, 256), dim3(256), 0, stream, n_roots, root_slots,
+                           reinterpret_cast<const float4*>(world), reinterpret_cast<float4*>(dst));
+    }
     return hipGetLastError();
 }
 

@@ -53,7 +53,7 @@ struct TickParams {
     float sleep_lin, sleep_lin2, sleep_ang2, sleep_time; // Bullet's sleeping thresholds (linear also squared, angular squared) and gDeactivationTime; time 0 = never sleep
     uint32_t tile_begin;
     uint32_t nt_out; // non-temporal stores for world / normal matrices (working set larger than the Infinity Cache)
-    float* root_out; // when non-null: roots also write their world matrix to root_out[root_index] (send buffer of the all-gather)
+    float* root_out; // when non-null: roots also write their world matrix (compact, 12 floats) to root_out[root_index] (send buffer of the gather)
 };
 
 // flags: bit0 physics, bit1 transforms, bit2 / bit5 aabb, bit4 normal matrices (bge_tick_flags)
@@ -77,6 +77,8 @@ hipError_t launch_dirty_bytes(hipStream_t stream, const uint32_t* slot_of_entity
 hipError_t launch_trigger_aabb(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, const WorldView& w);
 hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n_triggers, const TriggerView& t, const WorldView& w,
                                 const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap);
-hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst);
+// compact: 12 floats per root (4x3, the constant fourth column dropped) instead of 16
+hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst,
+                             bool compact = false);
 
 } // namespace bge

@@ -1584,7 +1584,8 @@ int bge_world_gather_roots(bge_world* w, void** table_device)
     float* send = nullptr;
     int rc = w->comm.begin_frame(w->stream, &send);
     if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
-    HIP_TRY(bge::launch_pack_roots(w->stream, w->flat.root_slots.size(), w->root_slots.as<uint32_t>(), w->world.as<float>(), send));
+    HIP_TRY(bge::launch_pack_roots(w->stream, w->flat.root_slots.size(), w->root_slots.as<uint32_t>(), w->world.as<float>(), send,
+                                   /*compact=*/true));
     rc = w->comm.gather(w->stream, table_device);
     if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
     return BGE_OK;
@@ -1598,9 +1599,22 @@ int bge_world_download_gathered(bge_world* w, float* out, uint64_t floats)
     if (w->comm.wait(w->stream) != BGE_OK) return fail(BGE_ERR_HIP, "%s", w->comm.error());
     const void* table = w->comm.last_table();
     if (!table) return fail(BGE_ERR_STATE, "nothing has been gathered yet");
-    const uint64_t have = w->comm.rows_per_rank() * 16 * static_cast<uint64_t>(w->comm.nranks());
-    HIP_TRY(hipMemcpyAsync(out, table, std::min(floats, have) * 4, hipMemcpyDeviceToHost, w->stream));
+    // the table holds compact rows (12 floats); the caller gets full 4x4 matrices
+    const uint64_t rows = w->comm.rows_per_rank() * static_cast<uint64_t>(w->comm.nranks());
+    std::vector<float> compact(rows * bge::RootComm::kRowFloats);
+    HIP_TRY(hipMemcpyAsync(compact.data(), table, compact.size() * 4, hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    const uint64_t take = std::min<uint64_t>(floats / 16, rows);
+    for (uint64_t r = 0; r < take; ++r) {
+        const float* c = &compact[r * bge::RootComm::kRowFloats];
+        float* m = out + 16 * r;
+        for (int row = 0; row < 4; ++row) {
+            m[4 * row] = c[3 * row];
+            m[4 * row + 1] = c[3 * row + 1];
+            m[4 * row + 2] = c[3 * row + 2];
+            m[4 * row + 3] = row == 3 ? 1.0f : 0.0f;
+        }
+    }
     return BGE_OK;
 }
 

@@ -11,7 +11,7 @@ HBM before the timed region.  Rank 0 prints one JSON line.
 Workloads (BASELINE.json `configs`):
     N = 1 : "flat1m"    — configs[1]: 1,000,000 entities, flat, every entity a Dynamic body
     N > 1 : "subtree64" — configs[4] (variant 5b): 2,000,000 entities PER GPU in 64-node subtrees whose
-            roots are Dynamic bodies; shards are whole subtrees; all-gather of 31,250 roots x 64 B per rank.
+            roots are Dynamic bodies; shards are whole subtrees; gather of 31,250 root matrices per rank per step.
             ("chains4_shard" = variant 5a, 500,000 roots per rank, is selectable with --workload.)
 """
 from __future__ import annotations
@@ -175,8 +175,8 @@ def main():
             agreed = torch.tensor([ok], dtype=torch.int64, device="cuda")
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             if int(agreed.item()) == 1:
-                collective = (f"native RCCL gather (libbge_world) of {rows_per_rank} x 64 B root world matrices per rank per "
-                              "step, side stream, ring of 8 buffers")
+                collective = (f"native RCCL gather (libbge_world) of {rows_per_rank} root world matrices per rank per step as "
+                              "48-B rows (4x3: a root's fourth column is exactly 0,0,0,1), side stream, ring of 8 buffers")
             else:
                 if ok:
                     world.comm_destroy()

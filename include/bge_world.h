@@ -254,16 +254,20 @@ BGE_API int bge_world_device_array(bge_world* world, int which, void** device_pt
  * of its roots and receives everybody's.
  *   bge_comm_unique_id   rank 0 fills a 128-byte id and distributes it by any means (the bench uses
  *                        torch.distributed's store); wraps ncclGetUniqueId.
- *   bge_world_comm_init  joins the communicator (ncclCommInitRank) and allocates two send/receive buffer
- *                        pairs of `rows_per_rank` x 16 floats (ranks pad to the largest root count) plus a
- *                        side stream for the collective.
- *   bge_world_gather_roots   packs this rank's roots on the world's stream and enqueues ONE ncclAllGather on
- *                        the side stream; buffers alternate per frame, so frame t's gather runs under frame
- *                        t+1's tick.  *table_device (may be NULL) receives the device pointer of the table being
- *                        filled: nranks x rows_per_rank x 16 floats, rank-major.
+ *   bge_world_comm_init  joins the communicator (ncclCommInitRank) and allocates a ring of 8 send/receive buffer
+ *                        pairs of `rows_per_rank` rows (ranks pad to the largest root count) plus a side stream for
+ *                        the collective.  A row on the wire is BGE_ROOT_ROW_FLOATS = 12 floats: the root's world matrix
+ *                        without its fourth column, which is exactly (0, 0, 0, 1) for a root (world = local =
+ *                        bx::mtxSRT, src/ecs/Transform.cpp:32-35) — elements 0,1,2, 4,5,6, 8,9,10, 12,13,14.
+ *   bge_world_gather_roots   packs this rank's roots on the world's stream and enqueues ONE gather on the side
+ *                        stream; buffers rotate per frame, so frame t's gather runs under the following ticks.
+ *                        *table_device (may be NULL) receives the device pointer of the table being filled:
+ *                        nranks x rows_per_rank x 12 floats, rank-major.  bge_world_download_gathered returns full
+ *                        4x4 matrices.
  *   bge_world_comm_wait  makes the world's stream wait for every outstanding gather.
  * librccl.so.1 is loaded at run time (dlopen); BGE_ERR_UNSUPPORTED when it cannot be found.
  */
+#define BGE_ROOT_ROW_FLOATS 12
 BGE_API int bge_comm_unique_id(void* out128);
 BGE_API int bge_world_comm_init(bge_world* world, int nranks, int rank, const void* id128, uint64_t rows_per_rank);
 BGE_API int bge_world_gather_roots(bge_world* world, void** table_device);
