@@ -36,6 +36,7 @@ public:
     const char* error() const { return error_.c_str(); }
     void* pairs_device() const { return pairs_; }
     uint64_t capacity() const { return capacity_; }
+    uint64_t configured_slots() const { return n_slots_; }
 
 private:
     int fail(int code, const char* what, hipError_t e);

@@ -1378,8 +1378,12 @@ int bge_world_bp_find(bge_world* w, const void* records_device, uint64_t n_recor
     const uint32_t* ids = nullptr;
     int rc = w->router.unpack(w->stream, records_device, n_records, &view, &ids);
     if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
-    const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * n_records, 4096);
-    rc = w->slab_broadphase.configure(std::max<uint64_t>(n_records, bge::kTile), cap);
+    // the number of records a slab receives changes from tick to tick: grow with 25 % headroom, never shrink
+    uint64_t want_slots = std::max<uint64_t>(n_records, bge::kTile);
+    if (want_slots > w->slab_broadphase.configured_slots()) want_slots += want_slots / 4;
+    const uint64_t cap = std::max<uint64_t>(w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * want_slots, 4096),
+                                            w->slab_broadphase.capacity());
+    rc = w->slab_broadphase.configure(std::max<uint64_t>(want_slots, w->slab_broadphase.configured_slots()), cap);
     if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->slab_broadphase.error());
     const bge::PairWindow win{axis, window_lo, window_hi};
     rc = w->slab_broadphase.run(w->stream, view, n_records, ids, &win);
