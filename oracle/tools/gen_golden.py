@@ -7,7 +7,7 @@ Provenance (read before trusting a fixture):
                          oracle must reproduce them; this script only verifies that and refuses to run otherwise.
   * demo_scene.json    — inputs are the reference's own assets/scenes/demo.json:48-108 (3 entities: TRS,
                          collider, rigid body — data, not code); expected world matrices come from the oracle.
-  * transform_cases.npz, physics_cases.npz, pairs_case.npz — seeded inputs + oracle outputs ("spec-derived";
+  * transform_cases.npz, physics_cases.npz, pairs_case.npz, sleep_case.npz — seeded inputs + oracle outputs ("spec-derived";
                          the reference has no tests, so nothing of its own pins these — parity unpinned).
 
 Run from the repo root:  python oracle/tools/gen_golden.py
@@ -145,10 +145,47 @@ def pairs_case():
     print("pairs_case:", len(pairs), "pairs for", n, "bodies")
 
 
+def _sleep_scene():
+    """96 Dynamic bodies in zero gravity with speeds around Bullet's sleeping thresholds (0.8 linear, 1.0 angular)."""
+    n = 96
+    wl = synth.config("flat10k", n=n)
+    speed = np.tile(np.array([0.0, 0.3, 0.79, 0.8, 0.81, 1.4], np.float32), n // 6)
+    d = synth.velocity(0x51EE9, 0, n)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    vel = (d * speed[:, None]).astype(np.float32)
+    angvel = np.zeros((n, 3), np.float32)
+    angvel[::4, 1] = np.float32(0.99)
+    angvel[1::8, 2] = np.float32(1.0)
+    return wl, vel, angvel
+
+
+def sleep_case():
+    wl, vel, angvel = _sleep_scene()
+    ref = build_oracle(wl)
+    ref.SetPhysicsOptions(0.0, po.ORIENT_IDEAL, False)
+    out = dict(vel=vel, angvel=angvel, n=np.int64(wl.n))
+    ticks = (238, 239, 240, 241, 260)
+    for k in range(ticks[-1] + 1):
+        ref.PhysicsSystemUpdate(DT)
+        ref.TransformSystemUpdate()
+        if k == 0:
+            ref.bulk_set_velocity(vel, angvel)
+        if k in ticks:
+            st, tm = ref.bulk_activation()
+            out[f"state.{k}"] = st.astype(np.uint8)
+            out[f"time.{k}"] = np.where(st == 1, tm, 0).astype(np.float32)
+            out[f"pos.{k}"] = ref.bulk_pose()[0]
+            out[f"linvel.{k}"] = ref.bulk_bodies()["linvel"]
+    out["ticks"] = np.array(ticks, np.int64)
+    np.savez_compressed(os.path.join(GOLD, "sleep_case.npz"), **out)
+    print("sleep_case: states at tick 260:", np.bincount(out["state.260"], minlength=5).tolist())
+
+
 if __name__ == "__main__":
     check_kat()
     demo_scene()
     transform_cases()
     physics_cases()
     pairs_case()
+    sleep_case()
     print("fixtures written to", GOLD)

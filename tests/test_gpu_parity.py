@@ -836,3 +836,21 @@ def test_broadphase_on_skewed_scenes(layout):
     if layout != "sparse":
         assert len(want) > 3000
     assert np.array_equal(got, want)
+
+
+def test_sleep_fixture_on_the_gpu():
+    z = np.load(os.path.join(GOLD, "sleep_case.npz"))
+    wl = synth.config("flat10k", n=int(z["n"]))
+    ticks = [int(t) for t in z["ticks"]]
+    with B.World() as w:
+        w.load(wl)
+        for k in range(ticks[-1] + 1):
+            w.tick(dt=DT, gravity=(0.0, 0.0, 0.0))
+            if k == 0:
+                w.set_velocities(z["vel"], z["angvel"])
+            if k in ticks:
+                st, tm = w.download_activation()
+                assert np.array_equal(st, z[f"state.{k}"]), k
+                assert_bits_equal(tm, z[f"time.{k}"], f"timer @ {k}")
+                assert_bits_equal(w.download_pose()[0], z[f"pos.{k}"], f"position @ {k}")
+                assert_bits_equal(w.download_bodies()["linvel"], z[f"linvel.{k}"], f"velocity @ {k}")
