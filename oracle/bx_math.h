@@ -14,6 +14,10 @@
 // PARITY STATUS: the reference holds no tests or golden vectors for this path;
 // the known-answer vectors in tests/golden/bx_kat.json come from SURVEY.md §8
 // (a restatement made from the disassembly).  Strictly: "parity unpinned".
+// What does pin it: oracle/tools/check_bx_order.py executes the reference's COMPILED
+// vec4MulMtx, mtxSRT, cos, floor and mtxInverse symbolically (from the committed
+// Transform.obj / SandboxCity.exe, nothing is run) and finds their expression trees
+// identical to the formulas below — operation order, association, constants, branches.
 //
 // Must be compiled with -ffp-contract=off (scalar mulss/addss, no FMA, as the
 // reference's /fp:precise MSVC build).
@@ -147,7 +151,8 @@ inline void mtxMul(float* out, const float* a, const float* b)
 
 // bx::mtxInverse (bx/src/math.cpp): adjugate / determinant, cofactors expanded along the first row of each minor.
 // Used by the reference for the per-mesh normal matrix (src/render/Renderer.cpp:413-416, 633-636).
-// Restated from bx's published source; the committed binaries were not decoded for this one — unpinned.
+// Operation order checked against the compiled function in the reference's SandboxCity.exe
+// (oracle/tools/check_bx_order.py: all 16 outputs identical as expression trees).
 inline void mtxInverse(float* r, const float* a)
 {
     const float xx = a[0], xy = a[1], xz = a[2], xw = a[3];
