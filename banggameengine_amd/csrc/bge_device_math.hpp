@@ -211,10 +211,12 @@ __device__ __forceinline__ Q4 bt_quat_from_transform_euler(const F3& e)
     const float cosRoll = bge_det_cosf(halfRoll);
     const float sinRoll = bge_det_sinf(halfRoll);
     Q4 q;
-    q.x = cosYaw * cosPitch * sinRoll - sinYaw * sinPitch * cosRoll;
-    q.y = cosYaw * sinPitch * cosRoll + sinYaw * cosPitch * sinRoll;
-    q.z = sinYaw * cosPitch * cosRoll - cosYaw * sinPitch * sinRoll;
-    q.w = cosYaw * cosPitch * cosRoll + sinYaw * sinPitch * sinRoll;
+    // product order of bullet3's btQuaternion::setEulerZYX as the reference's build compiled it (roll factor first,
+    // left-associated) — oracle/tools/check_bullet_order.py checks it against PhysicsSystem.obj
+    q.x = sinRoll * cosPitch * cosYaw - cosRoll * sinPitch * sinYaw;
+    q.y = cosRoll * sinPitch * cosYaw + sinRoll * cosPitch * sinYaw;
+    q.z = cosRoll * cosPitch * sinYaw - sinRoll * sinPitch * cosYaw;
+    q.w = cosRoll * cosPitch * cosYaw + sinRoll * sinPitch * sinYaw;
     return q;
 }
 

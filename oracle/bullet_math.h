@@ -14,7 +14,11 @@
 // output, so every function here restates Bullet's PUBLISHED algorithm (file names
 // below are bullet3 paths) for the scalar (non-SSE) code path.
 //
-// PARITY STATUS: "parity unpinned" — spec-derived.
+// PARITY STATUS: "parity unpinned" — spec-derived; EXCEPT the header-inline conversions
+// (setEulerZYX through the reference's ToBtQuaternion, btMatrix3x3::setRotation / getEulerZYX /
+// getRotation), whose compiled bodies sit in the reference's committed PhysicsSystem.obj and were
+// executed symbolically against the formulas below (oracle/tools/check_bullet_order.py: operation
+// order, association, constants, branch structure and the euler.y/x/z -> yaw/pitch/roll mapping).
 //
 // libm: Bullet calls the platform sinf/cosf/asinf/atan2f.  g_libm selects either the
 // platform libm (what Bullet does) or the deterministic routines of
@@ -74,10 +78,12 @@ inline Quat QuatFromEulerZYX(float yawZ, float pitchY, float rollX)
     const float cosRoll = Cos(halfRoll);
     const float sinRoll = Sin(halfRoll);
     Quat q;
-    q.x = cosYaw * cosPitch * sinRoll - sinYaw * sinPitch * cosRoll;
-    q.y = cosYaw * sinPitch * cosRoll + sinYaw * cosPitch * sinRoll;
-    q.z = sinYaw * cosPitch * cosRoll - cosYaw * sinPitch * sinRoll;
-    q.w = cosYaw * cosPitch * cosRoll + sinYaw * sinPitch * sinRoll;
+    // product order of bullet3's btQuaternion::setEulerZYX as the reference's build compiled it (roll factor first,
+    // left-associated) — oracle/tools/check_bullet_order.py checks it against PhysicsSystem.obj
+    q.x = sinRoll * cosPitch * cosYaw - cosRoll * sinPitch * sinYaw;
+    q.y = cosRoll * sinPitch * cosYaw + sinRoll * cosPitch * sinYaw;
+    q.z = cosRoll * cosPitch * sinYaw - sinRoll * sinPitch * cosYaw;
+    q.w = cosRoll * cosPitch * cosYaw + sinRoll * sinPitch * sinYaw;
     return q;
 }
 

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Pin the oracle's Bullet conversions (oracle/bullet_math.h) against the reference's COMPILED code, mechanically.
+
+Bullet is not under /root/reference, but its header-inline functions are compiled INTO the reference's committed
+build/SandboxCity.dir/RelWithDebInfo/PhysicsSystem.obj, with symbols:
+  ?ToBtQuaternion@?A0x...@@...                 the reference's helper with btQuaternion::setEulerZYX inlined
+                                               (src/physics/PhysicsSystem.cpp:40-45)
+  ?setRotation@btMatrix3x3@@...                btMatrix3x3::setRotation(q)             -> bt::MatFromQuat
+  ?getEulerZYX@btMatrix3x3@@...                btMatrix3x3::getEulerZYX(yaw,pitch,roll) -> bt::EulerZYXFromMat
+  ?getRotation@btMatrix3x3@@...                btMatrix3x3::getRotation(q)             -> bt::QuatFromMat (kOrientBasis mode only)
+The object file is read as bytes (COFF parser below), each function's section is disassembled with objdump, relocations
+name the constants (__real@3f000000 ...) and the libm calls (sinf, cosf, asinf, atan2f, sqrtf), and the scalar SSE code is
+executed symbolically exactly as in check_bx_order.py.  Data-dependent branches are enumerated path by path.
+
+This pins the euler <-> quaternion <-> matrix conventions and operation order of SURVEY.md 8 a-11 / a-12.  It does not
+pin the libm VALUES (the reference calls MSVC's sinf/cosf/asinf/atan2f; the oracle and the GPU path use the deterministic
+routines of include/bge_detmath.h, bounded against the platform libm in tests/test_oracle_physics.py), nor the parts of
+Bullet that exist only inside the symbol-less SandboxCity.exe (stepSimulation's integrator, updateAabbs).
+
+Run in the build container only:  python oracle/tools/check_bullet_order.py
+"""
+import os
+import re
+import struct
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from check_bx_order import E, compare, execute, norm  # noqa: E402
+
+OBJ = "/root/reference/build/SandboxCity.dir/RelWithDebInfo/PhysicsSystem.obj"
+
+
+def coff_function(path, wanted):
+    """(instructions, {pc_next: constant tree}, {pc_next: callee}) of the COMDAT function whose symbol contains `wanted`."""
+    b = open(path, "rb").read()
+    _, nsec, _, symoff, nsym, optsz, _ = struct.unpack_from("<HHIIIHH", b, 0)
+    secs, off = [], 20 + optsz
+    for _ in range(nsec):
+        _, _, rsz, raw, reloc, _, nreloc, _, _ = struct.unpack_from("<IIIIIIHHI", b, off + 8)
+        secs.append((rsz, raw, reloc, nreloc))
+        off += 40
+    strtab = symoff + nsym * 18
+
+    def sname(e):
+        if e[:4] == b"\0\0\0\0":
+            o = struct.unpack_from("<I", e, 4)[0]
+            return b[strtab + o: b.index(b"\0", strtab + o)].decode()
+        return e[:8].rstrip(b"\0").decode()
+
+    syms, i = {}, 0
+    while i < nsym:
+        e = b[symoff + i * 18: symoff + i * 18 + 18]
+        _, sec, _, _, naux = struct.unpack_from("<IhHBB", e, 8)
+        syms[i] = (sname(e), sec)
+        i += 1 + naux
+    hits = [(n, s) for n, s in syms.values() if wanted in n and s > 0 and not n.startswith("$")]
+    assert len(hits) == 1, hits
+    rsz, raw, reloc, nreloc = secs[hits[0][1] - 1]
+    code = b[raw: raw + rsz]
+    rel = {}
+    for k in range(nreloc):
+        va, si, _ = struct.unpack_from("<IIH", b, reloc + k * 10)
+        rel[va] = syms[si][0]
+    tmp = "/tmp/_bge_fn.bin"
+    open(tmp, "wb").write(code)
+    text = subprocess.run(["objdump", "-D", "-b", "binary", "-m", "i386:x86-64", "--no-show-raw-insn", tmp],
+                          capture_output=True, text=True, check=True).stdout
+    ins = []
+    for line in text.splitlines():
+        m = re.match(r"\s*([0-9a-f]+):\s+(\S+)\s*(.*)$", line)
+        if m:
+            ins.append((int(m.group(1), 16), m.group(2), m.group(3).split("#")[0].strip()))
+    ins = [x for x in ins if x[1] != "int3"]
+    consts, calls = {}, {}
+    for k, (pc, mn, ops) in enumerate(ins):
+        nxt = ins[k + 1][0] if k + 1 < len(ins) else pc + 16
+        names = [s for va, s in rel.items() if pc < va < nxt]
+        if not names:
+            continue
+        name = names[0]
+        if mn == "call":
+            calls[nxt] = name
+        elif name.startswith("__real@"):
+            consts[nxt] = ("const", struct.unpack("<f", struct.pack("<I", int(name[7:15], 16)))[0])
+        elif name.startswith("__xmm@80000000"):
+            consts[nxt] = ("signmask",)
+        elif name.startswith("__xmm@7fffffff"):
+            consts[nxt] = ("absmask",)
+        elif name.startswith("__security"):
+            consts[nxt] = ("opaque", name)
+        else:
+            raise AssertionError(name)
+    return hits[0][0], ins, consts, calls
+
+
+def C(x):
+    return E(("const", struct.unpack("<f", struct.pack("<f", x))[0]))
+
+
+def fn(name, *args):
+    return E((name,) + tuple(a.t for a in args))
+
+
+# ---------------------------------------------------------------- restatements (structure of oracle/bullet_math.h)
+def quat_from_transform_euler(ex, ey, ez):
+    """bt::QuatFromTransformEuler = QuatFromEulerZYX(yawZ = e.y, pitchY = e.x, rollX = e.z)."""
+    yaw, pitch, roll = ey, ex, ez
+    hy, hp, hr = yaw * 0.5, pitch * 0.5, roll * 0.5
+    cy, sy, cp, sp, cr, sr = fn("cosf", hy), fn("sinf", hy), fn("cosf", hp), fn("sinf", hp), fn("cosf", hr), fn("sinf", hr)
+    return {("q", 0): (sr * cp * cy - cr * sp * sy).t, ("q", 1): (cr * sp * cy + sr * cp * sy).t,
+            ("q", 2): (cr * cp * sy - sr * sp * cy).t, ("q", 3): (cr * cp * cy + sr * sp * sy).t}
+
+
+def mat_from_quat(q):
+    x, y, z, w = q
+    d = x * x + y * y + z * z + w * w
+    s = 2.0 / d
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz = w * xs, w * ys, w * zs
+    xx, xy, xz = x * xs, x * ys, x * zs
+    yy, yz, zz = y * ys, y * zs, z * zs
+    one = C(1.0)
+    m = [[one - (yy + zz), xy - wz, xz + wy], [xy + wz, one - (xx + zz), yz - wx], [xz - wy, yz + wx, one - (xx + yy)]]
+    out = {4 * r + c: m[r][c].t for r in range(3) for c in range(3)}
+    out.update({3: ("const", 0.0), 7: ("const", 0.0), 11: ("const", 0.0)})   # btVector3's fourth float
+    return out
+
+
+def euler_zyx_from_mat(m, path):
+    """bt::EulerZYXFromMat; m[r][c]; returns yaw, pitch, roll."""
+    K_PI = 3.1415926535897932384626433832795029
+    if path in ("gimbal-up", "gimbal-down"):
+        delta = fn("atan2f", m[0][0], m[0][2])
+        if path == "gimbal-up":
+            pitch = C(K_PI / 2.0)             # the compiler folds SIMD_PI / 2 to 0x3fc90fdb
+            roll = pitch + delta
+        else:
+            pitch = C(-K_PI / 2.0)
+            roll = delta - pitch             # -pitch + delta in the source; x - (-y) and y + x are the same float
+        return C(0.0), pitch, roll
+    clamped = E(("min", ("const", 1.0), ("max", ("const", -1.0), m[2][0].t)))   # btAsin clamps to [-1, 1]
+    pitch = -fn("asinf", clamped)
+    c = fn("cosf", pitch)
+    roll = fn("atan2f", E(("div", m[2][1].t, c.t)), E(("div", m[2][2].t, c.t)))
+    yaw = fn("atan2f", E(("div", m[1][0].t, c.t)), E(("div", m[0][0].t, c.t)))
+    return yaw, pitch, roll
+
+
+def main():
+    ok = True
+    # 1. ToBtQuaternion(euler): result through rcx (hidden return pointer), euler through rdx
+    name, ins, consts, calls = coff_function(OBJ, "?ToBtQuaternion@")
+    got = execute(ins, {"%rdx": "e"}, {"%rcx": "q"}, named_consts=consts, named_calls=calls)
+    e = [E(("in", "e", k)) for k in range(3)]
+    want = quat_from_transform_euler(*e)
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    print(f"ToBtQuaternion / btQuaternion::setEulerZYX(euler.y, euler.x, euler.z): {4 - len(bad)} of 4 components identical"
+          + ("" if not bad else f"  <-- MISMATCH {bad}"))
+    ok &= not bad
+
+    # 2. btMatrix3x3::setRotation(q): this = rcx (3 rows of 4 floats), q = rdx
+    name, ins, consts, calls = coff_function(OBJ, "?setRotation@btMatrix3x3@@")
+    got = execute(ins, {"%rdx": "q"}, "%rcx", named_consts=consts, named_calls=calls)
+    want = mat_from_quat([E(("in", "q", k)) for k in range(4)])
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    print(f"btMatrix3x3::setRotation: {len(want) - len(bad)} of {len(want)} stored floats identical" + ("" if not bad else f"  <-- MISMATCH {bad}"))
+    ok &= not bad
+
+    # 3. btMatrix3x3::getEulerZYX(yaw&, pitch&, roll&, solution_number = 1): this = rcx, rdx / r8 / r9 = results
+    name, ins, consts, calls = coff_function(OBJ, "?getEulerZYX@btMatrix3x3@@")
+    jb = [i[0] for i in ins if i[1] == "jb"]          # |m20| >= 1 ?   (taken: the regular case)
+    jbe = [i[0] for i in ins if i[1] == "jbe"]        # m20 > 0 ?      (taken: gimbal locked down)
+    je = [i[0] for i in ins if i[1] == "je"]          # solution_number == 1
+    assert len(jb) == 1 and len(jbe) == 1 and len(je) == 1, (jb, jbe, je)
+    m = [[E(("in", "m", 4 * r + c)) for c in range(3)] for r in range(3)]
+    for path, take in (("regular", jb + je), ("gimbal-up", je), ("gimbal-down", jbe + je)):
+        got = execute(ins, {"%rcx": "m"}, {"%rdx": "yaw", "%r8": "pitch", "%r9": "roll"}, named_consts=consts, named_calls=calls,
+                      take=tuple(take))
+        yaw, pitch, roll = euler_zyx_from_mat(m, path)
+        want = {("yaw", 0): yaw.t, ("pitch", 0): pitch.t, ("roll", 0): roll.t}
+        bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+        print(f"btMatrix3x3::getEulerZYX, {path}: {3 - len(bad)} of 3 angles identical" + ("" if not bad else f"  <-- MISMATCH {bad}"))
+        for k in bad:
+            print("   compiled   :", norm(got.get(k, ("missing",))))
+            print("   restatement:", norm(want[k]))
+        ok &= not bad
+    # 4. btMatrix3x3::getRotation(q), the trace > 0 side (the other side indexes the matrix with run-time i, j, k; it was
+    #    read by hand: i = m00 < m11 ? (m11 < m22 ? 2 : 1) : (m00 < m22 ? 2 : 0), s = sqrt(m[i][i] - m[j][j] - m[k][k] + 1),
+    #    t[i] = s / 2, s = 0.5 / s, t[3] = (m[k][j] - m[j][k]) s, t[j] = (m[j][i] + m[i][j]) s, t[k] = (m[k][i] + m[i][k]) s)
+    name, ins, consts, calls = coff_function(OBJ, "?getRotation@btMatrix3x3@@")
+    ja = [i[0] for i in ins if i[1] == "ja"]
+    got = execute(ins, {"%rcx": "m"}, {"%rdx": "q"}, named_consts=consts, named_calls=calls, take=())   # jbe not taken: trace > 0
+    m = [[E(("in", "m", 4 * r + c)) for c in range(3)] for r in range(3)]
+    trace = m[0][0] + m[1][1] + m[2][2]
+    s = fn("sqrtf", trace + 1.0)
+    s2 = E(("div", ("const", 0.5), s.t))
+    want = {("q", 0): ((m[2][1] - m[1][2]) * s2).t, ("q", 1): ((m[0][2] - m[2][0]) * s2).t,
+            ("q", 2): ((m[1][0] - m[0][1]) * s2).t, ("q", 3): (s * 0.5).t}
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    print(f"btMatrix3x3::getRotation, trace > 0: {4 - len(bad)} of 4 components identical" + ("" if not bad else f"  <-- MISMATCH {bad}"))
+    ok &= not bad
+    print("RESULT:", "the restatement has the compiled code's operation order" if ok else "MISMATCH")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -42,8 +42,10 @@ def norm(e):
     if op == "neg":
         a = norm(e[1])
         return a[1] if a[0] == "neg" else ("neg", a)
-    if op in ("cos", "floor", "trunc"):
+    if op in ("cos", "floor", "trunc", "abs", "cosf", "sinf", "asinf", "sqrtf"):
         return (op, norm(e[1]))
+    if op in ("atan2f", "max", "min"):
+        return (op, norm(e[1]), norm(e[2]))
     a, b = norm(e[1]), norm(e[2])
     if op in ("mul", "div"):
         sign = 0
@@ -242,13 +244,16 @@ def parse(text, start_label=None, multi_ret=False):
 
 
 # ---------------------------------------------------------------- symbolic execution of straight-line scalar SSE
-def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=None, cos_target=None, calls=None, take=()):
+def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=None, cos_target=None, calls=None, take=(),
+            named_consts=None, named_calls=None):
     """`calls`: {target: name} for opaque unary functions; `take`: addresses of conditional jumps that are taken."""
     """in_bases: {'%rdx': 'v', ...} memory operands through these registers are inputs ('in', name, index).
     out_base: register through which results are stored.  stack_args: {entry_rsp_offset: tree}."""
     reg = dict(reg0 or {})
     mem = dict(stack_args or {})
-    out, gpr, alias = {}, {}, {out_base: out_base}
+    out, gpr = {}, {}
+    # several result pointers: {'%rdx': 'yaw', ...}; results are then keyed (name, index)
+    alias = dict(out_base) if isinstance(out_base, dict) else {out_base: out_base}
     sp = 0
 
     def addr(op):
@@ -262,6 +267,8 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
 
     def load(op, pc_next):
         r, d = addr(op)
+        if r == "%rip" and named_consts is not None:      # object file: the relocation names the constant
+            return named_consts[pc_next]
         if r in in_bases:
             assert d % 4 == 0
             return ("in", in_bases[r], d // 4)
@@ -279,7 +286,7 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             skip_to = None
         pc_next = ins[k + 1][0] if k + 1 < len(ins) else pc + 1
         parts = [p.strip() for p in re.split(r",(?![^(]*\))", ops)] if ops else []
-        if mn in ("jne", "ja", "jbe", "je", "jp"):
+        if mn in ("jne", "ja", "jbe", "je", "jp", "jb", "jae"):
             if pc in take:
                 skip_to = int(parts[0], 16)
             continue
@@ -294,16 +301,22 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             assert v[0] == "int", v
             reg[parts[1]] = ("trunc", v[1][1]) if isinstance(v[1], tuple) else ("const", float(v[1]))
             continue
-        if mn in ("and", "test", "dec", "cmp", "comiss", "ucomiss"):
+        if mn in ("and", "test", "dec", "cmp", "cmpl", "comiss", "ucomiss"):
+            continue
+        if mn == "jmp":
+            skip_to = int(parts[0], 16)
             continue
         if mn == "ret":
             break
         if mn == "sub" and len(parts) == 2 and parts[1] == "%rsp":
             sp -= int(parts[0][1:], 16)
-        elif mn == "push":
+        elif mn == "push" or (mn == "rex" and ops.startswith("push")):
             sp -= 8
-        elif mn == "mov" and len(parts) == 2 and parts[0] == out_base and parts[1].startswith("%r"):
-            alias[parts[1]] = out_base                        # mov %rcx,%rbx
+        elif mn == "mov" and len(parts) == 2 and parts[0] in alias and parts[1].startswith("%r") and not addr(parts[1]):
+            alias[parts[1]] = alias[parts[0]]                 # mov %rcx,%rbx: another name for a result pointer
+        elif mn == "mov" and len(parts) == 2 and parts[0] in in_bases and parts[1].startswith("%r") and not addr(parts[1]):
+            in_bases = dict(in_bases)
+            in_bases[parts[1]] = in_bases[parts[0]]           # ... or for an input pointer
         elif mn == "xor" and parts[0] == parts[1]:
             gpr[parts[0]] = 0
         elif mn == "mov" and len(parts) == 2 and parts[0].startswith("$") and parts[1].startswith("%e"):
@@ -312,8 +325,8 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             d = addr(parts[1])[1]                             # integer store of a float constant into the result
             bits = gpr[parts[0]] if parts[0].startswith("%") else int(parts[0][1:], 16)
             out[d // 4] = ("const", struct.unpack("<f", struct.pack("<I", bits))[0])
-        elif mn in ("mov", "lea", "pop", "ret", "add"):
-            pass
+        elif mn in ("mov", "lea", "pop", "ret", "add", "xor", "movslq", "mul", "shr", "inc", "seta", "cmova", "nopw"):
+            pass                                              # integer bookkeeping: not modelled
         elif mn in ("movss", "movaps"):
             src, dst = parts
             if dst.startswith("%xmm"):
@@ -321,7 +334,8 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             else:
                 r, d = addr(dst)
                 if r in alias:
-                    out[d // 4] = reg.get(src, ("opaque", src))
+                    key = d // 4 if not isinstance(out_base, dict) else (alias[r], d // 4)
+                    out[key] = reg.get(src, ("opaque", src))
                 elif r == "%rsp":
                     mem[sp + d] = reg.get(src, ("opaque", src))
                 # saves of callee-saved registers through %rax / %r11: not modelled (restored before ret)
@@ -329,6 +343,15 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             src, dst = parts
             b = reg.get(src, ("opaque", src)) if src.startswith("%xmm") else load(src, pc_next)
             reg[dst] = ({"mulss": "mul", "addss": "add", "subss": "sub", "divss": "div"}[mn], reg[dst], b)
+        elif mn == "andps":
+            src, dst = parts
+            m = reg.get(src) if src.startswith("%xmm") else load(src, pc_next)
+            assert m == ("absmask",), (hex(pc), m)
+            reg[dst] = ("abs", reg[dst])
+        elif mn in ("maxss", "minss"):
+            src, dst = parts
+            b = reg.get(src, ("opaque", src)) if src.startswith("%xmm") else load(src, pc_next)
+            reg[dst] = (mn[:3], reg[dst], b)                  # x86 semantics kept: (dst, src), not commutative
         elif mn == "xorps":
             src, dst = parts
             if src == dst:
@@ -337,6 +360,17 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
                 m = reg.get(src) if src.startswith("%xmm") else load(src, pc_next)
                 assert m == ("signmask",), (hex(pc), m)
                 reg[dst] = ("neg", reg[dst])
+        elif mn == "sqrtss":
+            src, dst = parts
+            reg[dst] = ("sqrtf", reg.get(src, ("opaque", src)))
+        elif mn == "call" and named_calls is not None:
+            name = named_calls[pc_next]
+            if name.startswith("__security"):
+                continue
+            nargs = {"atan2f": 2}.get(name, 1)
+            reg["%xmm0"] = (name, reg["%xmm0"]) if nargs == 1 else (name, reg["%xmm0"], reg["%xmm1"])
+            for v in ("%xmm1", "%xmm2", "%xmm3", "%xmm4", "%xmm5"):
+                reg[v] = ("opaque", f"clobbered {v} @ {pc:#x}")
         elif mn == "call":
             tgt = int(parts[0], 16)
             if calls and tgt in calls:
