@@ -278,7 +278,8 @@ __device__ __forceinline__ Q4 bt_integrate_orientation(const Q4& orn0, const F3&
     if (fAngle * dt > kBtAngularMotionThreshold) fAngle = kBtAngularMotionThreshold / dt;
     float k;
     if (fAngle < 0.001f) {
-        k = 0.5f * dt - (dt * dt * dt) * 0.020833333333f * fAngle * fAngle;
+        // association as compiled in the reference's build: (dt*dt) * (dt * 1/48), oracle/tools/check_bullet_order.py
+        k = 0.5f * dt - ((dt * dt) * (dt * 0.020833333333f)) * fAngle * fAngle;
     } else {
         k = bge_det_sinf(0.5f * fAngle * dt) / fAngle;
     }
@@ -289,7 +290,8 @@ __device__ __forceinline__ Q4 bt_integrate_orientation(const Q4& orn0, const F3&
     r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
     r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
     r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
-    const float l2 = bt_quat_length2(r);
+    // safeNormalize's length2 is summed pairwise in the compiled integrateTransform: (x^2 + y^2) + (z^2 + w^2)
+    const float l2 = (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
     if (l2 > kBtEpsilon) {
         const float s = 1.0f / __builtin_sqrtf(l2);
         r.x *= s;

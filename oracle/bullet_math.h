@@ -105,9 +105,11 @@ inline Quat QuatMul(const Quat& a, const Quat& b)
 inline float QuatLength2(const Quat& q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
 
 // btQuaternion::safeNormalize: normalize (multiply by 1/length) iff length2 > SIMD_EPSILON
+// (inside the compiled integrateTransform the squares are summed pairwise, (x^2 + y^2) + (z^2 + w^2) —
+//  check_bullet_order.py; btMatrix3x3::setRotation's length2 is the left-associated sum of QuatLength2)
 inline Quat QuatSafeNormalize(Quat q)
 {
-    const float l2 = QuatLength2(q);
+    const float l2 = (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
     if (l2 > kEpsilon) {
         const float s = 1.0f / std::sqrt(l2);
         q.x *= s;
@@ -197,7 +199,9 @@ inline Vec3 TransformEulerFromMat(const Mat3& a)
 }
 
 // btTransformUtil::integrateTransform, rotation part (LinearMath/btTransformUtil.h):
-// exponential map of angvel*dt applied on the left of the current orientation.
+// exponential map of angvel*dt applied on the left of the current orientation.  Checked against the compiled function
+// in the reference's SandboxCity.exe (found through its unique reference to the constant 1/48) on its three control
+// paths — regular, Taylor (fAngle < 0.001) and clamped (fAngle*dt > pi/4) — by oracle/tools/check_bullet_order.py.
 inline Quat IntegrateOrientation(const Quat& orn0, const Vec3& angvel, float dt)
 {
     const float fAngle2 = angvel.x * angvel.x + angvel.y * angvel.y + angvel.z * angvel.z;
@@ -210,7 +214,8 @@ inline Quat IntegrateOrientation(const Quat& orn0, const Vec3& angvel, float dt)
     }
     float k;
     if (fAngle < 0.001f) {
-        k = 0.5f * dt - (dt * dt * dt) * 0.020833333333f * fAngle * fAngle;
+        // association as compiled in the reference's build ((dt*dt) * (dt * 1/48)): oracle/tools/check_bullet_order.py
+        k = 0.5f * dt - ((dt * dt) * (dt * 0.020833333333f)) * fAngle * fAngle;
     } else {
         k = Sin(0.5f * fAngle * dt) / fAngle;
     }

@@ -147,6 +147,101 @@ def euler_zyx_from_mat(m, path):
     return yaw, pitch, roll
 
 
+def quat_mul(a, b):
+    """bt::QuatMul (btQuaternion operator*), components x, y, z, w."""
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return [aw * bx + ax * bw + ay * bz - az * by,
+            aw * by + ay * bw + az * bx - ax * bz,
+            aw * bz + az * bw + ax * by - ay * bx,
+            aw * bw - ax * bx - ay * by - az * bz]
+
+
+def integrate_orientation(q0, w, dt, path):
+    """bt::IntegrateOrientation up to the normalised quaternion handed to setRotation, on one control path."""
+    eps_thresh = C(0.5 * (3.1415926535897932384626433832795029 * 0.5))   # ANGULAR_MOTION_THRESHOLD
+    f2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2]
+    f = fn("sqrtf", f2)
+    if path == "clamped":
+        f = E(("div", eps_thresh.t, dt.t))
+    if path == "taylor":
+        k = dt * 0.5 - dt * dt * (dt * 0.020833333333) * f * f       # association as compiled, see bullet_math.h
+    else:
+        k = E(("div", fn("sinf", f * 0.5 * dt).t, f.t))
+    dorn = [w[0] * k, w[1] * k, w[2] * k, fn("cosf", f * dt * 0.5)]
+    p = quat_mul(dorn, q0)
+    l2 = (p[0] * p[0] + p[1] * p[1]) + (p[2] * p[2] + p[3] * p[3])     # pairwise, as compiled
+    s = E(("div", ("const", 1.0), fn("sqrtf", l2).t))
+    return [(x * s).t for x in p]
+
+
+def check_integrate_transform():
+    """btTransformUtil::integrateTransform exists once in the exe (symbol-less); it is the only code that references the
+    constant 1/48 = 0x3caaaaab of its Taylor branch, which is how it is found."""
+    import numpy as np
+    from check_bx_order import EXE, Pe, objdump, parse
+    pe = Pe(EXE)
+    b = pe.b
+    va, _, raw, rs = pe.secs[0]
+    rva_c = None
+    rd_va, _, rd_raw, rd_rs = pe.secs[1]
+    i = b.find(struct.pack("<I", 0x3CAAAAAB), rd_raw, rd_raw + rd_rs)
+    assert i != -1 and b.find(struct.pack("<I", 0x3CAAAAAB), i + 1, rd_raw + rd_rs) == -1
+    rva_c = rd_va + i - rd_raw
+    code = np.frombuffer(b[raw: raw + rs], dtype=np.uint8).astype(np.int64)
+    n = len(code) - 4
+    d = code[:n] | (code[1:n + 1] << 8) | (code[2:n + 2] << 16) | (code[3:n + 3] << 24)
+    d = np.where(d >= 2 ** 31, d - 2 ** 32, d)
+    refs = np.nonzero(np.arange(n, dtype=np.int64) + va + 4 + d == rva_c)[0]
+    assert len(refs) == 1, refs
+    j = int(refs[0])
+    while not (code[j - 1] == 0xCC and code[j - 2] == 0xCC):      # back to the int3 padding in front of the function
+        j -= 1
+    start = va + j
+    ins = parse(objdump(EXE, [f"--start-address={pe.base + start:#x}", f"--stop-address={pe.base + start + 0x400:#x}"]))
+    calls = [int(x[2], 16) for x in ins if x[1] == "call"]
+    assert len(calls) == 4, calls                                   # sinf, cosf, getRotation, setRotation (in this order)
+    sinf_t, cosf_t, getrot_t, setrot_t = calls
+    pcs = {m: [x[0] for x in ins if x[1] == m] for m in ("jbe", "jae")}
+    jbe, jae = pcs["jbe"], pcs["jae"]
+    assert len(jbe) == 4 and len(jae) == 1, (jbe, jae)
+    # jbe[0]: fAngle2 <= eps (skip sqrt)   jbe[1]: fAngle*dt <= threshold (skip clamp)   jae[0]: fAngle >= 0.001 (sin branch)
+    # jbe[2]: length2 <= eps (skip normalise)   jbe[3]: length2 <= eps (copy the basis instead of setRotation)
+    dt = E(("in", "dt", 0))
+    w = [E(("in", "w", k)) for k in range(3)]
+    q0 = [E(("in", "q0", k)) for k in range(4)]
+    x0 = [E(("in", "cur", 12 + k)) for k in range(3)]
+    v = [E(("in", "v", k)) for k in range(3)]
+    probe_pc = next(x[0] for x in ins if x[1] == "movups")        # the predicted origin is assembled and stored here
+
+    def hook_get(reg, mem, sp, out):
+        for k in range(4):
+            mem[sp + 0x20 + 4 * k] = q0[k].t                       # getRotation(&q) with q at 0x20(%rsp)
+
+    def hook_set(reg, mem, sp, out):
+        for k in range(4):
+            out[("setRotation", k)] = mem[sp + 0x20 + 4 * k]
+
+    ok = True
+    for path, take in (("regular", [jbe[1], jae[0]]), ("taylor", [jbe[1]]), ("clamped", [jae[0]])):
+        got = execute(ins, {"%rcx": "cur", "%rdx": "v", "%r8": "w"}, "%none", {"%xmm3": dt.t}, {}, pe.bytes_at_va,
+                      calls={sinf_t: "sinf", cosf_t: "cosf"}, hooks={getrot_t: hook_get, setrot_t: hook_set}, take=tuple(take),
+                      probes={probe_pc: ["%xmm1", "%xmm2", "%xmm3"]})
+        want_q = integrate_orientation(q0, w, dt, path)
+        bad = [k for k in range(4) if norm(got.get(("setRotation", k), ("missing",))) != norm(want_q[k])]
+        want_x = [(x0[k] + v[k] * dt).t for k in range(3)]
+        badx = [k for k, r in enumerate(("%xmm1", "%xmm2", "%xmm3")) if norm(got[("probe", probe_pc, r)]) != norm(want_x[k])]
+        print(f"btTransformUtil::integrateTransform, {path}: quaternion {4 - len(bad)} of 4, origin {3 - len(badx)} of 3 identical"
+              + ("" if not (bad or badx) else "  <-- MISMATCH"))
+        for k in bad[:2]:
+            print("   compiled   :", norm(got.get(("setRotation", k), ("missing",))))
+            print("   restatement:", norm(want_q[k]))
+        ok &= not (bad or badx)
+    print(f"  (found at VA {pe.base + start:#x} through its reference to 0x3caaaaab; thresholds: "
+          f"{[struct.unpack('<f', pe.bytes_at_va(pe.base + r, 4))[0] for r in sorted({rva_c - 4, rva_c + 4})]})")
+    return ok
+
+
 def main():
     ok = True
     # 1. ToBtQuaternion(euler): result through rcx (hidden return pointer), euler through rdx
@@ -200,6 +295,7 @@ def main():
     bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
     print(f"btMatrix3x3::getRotation, trace > 0: {4 - len(bad)} of 4 components identical" + ("" if not bad else f"  <-- MISMATCH {bad}"))
     ok &= not bad
+    ok &= check_integrate_transform()
     print("RESULT:", "the restatement has the compiled code's operation order" if ok else "MISMATCH")
     return 0 if ok else 1
 

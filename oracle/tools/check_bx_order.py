@@ -245,7 +245,9 @@ def parse(text, start_label=None, multi_ret=False):
 
 # ---------------------------------------------------------------- symbolic execution of straight-line scalar SSE
 def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=None, cos_target=None, calls=None, take=(),
-            named_consts=None, named_calls=None):
+            named_consts=None, named_calls=None, probes=None, hooks=None):
+    """probes: {pc: [registers]} -> out[('probe', pc, reg)] = tree at that point.
+    hooks: {call target: fn(reg, mem, sp, gpr_alias)} for calls with side effects on memory."""
     """`calls`: {target: name} for opaque unary functions; `take`: addresses of conditional jumps that are taken."""
     """in_bases: {'%rdx': 'v', ...} memory operands through these registers are inputs ('in', name, index).
     out_base: register through which results are stored.  stack_args: {entry_rsp_offset: tree}."""
@@ -286,6 +288,9 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             skip_to = None
         pc_next = ins[k + 1][0] if k + 1 < len(ins) else pc + 1
         parts = [p.strip() for p in re.split(r",(?![^(]*\))", ops)] if ops else []
+        if probes and pc in probes:
+            for r in probes[pc]:
+                out[("probe", pc, r)] = reg.get(r)
         if mn in ("jne", "ja", "jbe", "je", "jp", "jb", "jae"):
             if pc in take:
                 skip_to = int(parts[0], 16)
@@ -327,6 +332,8 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             out[d // 4] = ("const", struct.unpack("<f", struct.pack("<I", bits))[0])
         elif mn in ("mov", "lea", "pop", "ret", "add", "xor", "movslq", "mul", "shr", "inc", "seta", "cmova", "nopw"):
             pass                                              # integer bookkeeping: not modelled
+        elif mn in ("shufps", "movups", "movl"):
+            pass                                              # vector assembly / packed copies: lanes are not modelled
         elif mn in ("movss", "movaps"):
             src, dst = parts
             if dst.startswith("%xmm"):
@@ -370,6 +377,10 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             nargs = {"atan2f": 2}.get(name, 1)
             reg["%xmm0"] = (name, reg["%xmm0"]) if nargs == 1 else (name, reg["%xmm0"], reg["%xmm1"])
             for v in ("%xmm1", "%xmm2", "%xmm3", "%xmm4", "%xmm5"):
+                reg[v] = ("opaque", f"clobbered {v} @ {pc:#x}")
+        elif mn == "call" and hooks and int(parts[0], 16) in hooks:
+            hooks[int(parts[0], 16)](reg, mem, sp, out)
+            for v in ("%xmm0", "%xmm1", "%xmm2", "%xmm3", "%xmm4", "%xmm5"):
                 reg[v] = ("opaque", f"clobbered {v} @ {pc:#x}")
         elif mn == "call":
             tgt = int(parts[0], 16)
