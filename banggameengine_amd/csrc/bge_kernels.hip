@@ -190,17 +190,20 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             }
 
             if (dynamic) {
-                // mass class -> (inv_mass, 1/inv_mass) from the world's palette (a few distinct masses per scene,
-                // L1/L2-resident); class 127 falls back to the per-slot array
+                // mass class -> (gravity force, inv_mass) from the world's palette (a few distinct masses per scene,
+                // L1/L2-resident); class 127 falls back to the per-slot array.  The force is btRigidBody::setGravity's
+                // m_gravity = acceleration / m_inverseMass — a DIVISION per component in the reference's build
+                // (oracle/tools/check_bullet_order.py) — which the host evaluates once per class and gravity vector.
                 const uint32_t cls = f >> kMassShift;
-                float inv_mass, mass;
+                float inv_mass;
+                F3 force;
                 if (cls != kMassClassArray) {
-                    const float2 mm = w.mass_palette[cls];
-                    inv_mass = mm.x;
-                    mass = mm.y;
+                    const float4 gf = w.grav_palette[cls];
+                    inv_mass = gf.w;
+                    force = F3{gf.x, gf.y, gf.z};
                 } else {
                     inv_mass = w.inv_mass[slot];
-                    mass = 1.0f / inv_mass;
+                    force = F3{p.gx / inv_mass, p.gy / inv_mass, p.gz / inv_mass};
                 }
                 // Deactivation record: untouched (and unread) while the body is fast and its timer is zero.
                 // (kDrowsy <=> record != 0; body (re)creation clears the bit: a new btRigidBody is ACTIVE_TAG, timer 0)
@@ -219,9 +222,9 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     }
                 } else if (inv_mass != 0.0f) {
                     // applyGravity (F = g * (1/invMass)) + solver write-back of the external force impulse
-                    v.x = v.x + ((p.gx * mass) * inv_mass) * p.dt;
-                    v.y = v.y + ((p.gy * mass) * inv_mass) * p.dt;
-                    v.z = v.z + ((p.gz * mass) * inv_mass) * p.dt;
+                    v.x = v.x + (force.x * inv_mass) * p.dt;
+                    v.y = v.y + (force.y * inv_mass) * p.dt;
+                    v.z = v.z + (force.z * inv_mass) * p.dt;
                     // integrateTransforms
                     pos.x = pos.x + v.x * p.dt;
                     pos.y = pos.y + v.y * p.dt;

@@ -119,7 +119,9 @@ struct bge_world {
     // device arrays
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
-    DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table;
+    DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table, grav_palette;
+    float grav_cached[3] = {0.0f, 0.0f, 0.0f};
+    bool grav_palette_stale = true; // the mass palette or the gravity vector changed since the table was built
     // Collision-filter palette: scenes use a handful of (layer, mask, static) combinations, so the broadphase's sorted
     // records carry an 8-bit class instead of two 32-bit words (32-byte records instead of 48).  Class 0 = (1, ~0, not
     // static), the component defaults; with more than 255 combinations the broadphase falls back to full records.
@@ -234,6 +236,7 @@ struct bge_world {
         view.mask = mask.as<uint32_t>();
         view.aabb = aabb.as<float>();
         view.mass_palette = mass_palette.as<float2>();
+        view.grav_palette = grav_palette.as<float4>();
         view.deact = deact.as<uint32_t>();
         view.filter_class = filter_class.as<uint32_t>();
         view.root_index = root_index.as<uint32_t>();
@@ -243,7 +246,7 @@ struct bge_world {
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count}) {
             b->release();
         }
@@ -629,6 +632,8 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     HIP_TRY(w->root_worlds.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 64));
     HIP_TRY(w->counter.ensure(64));
     HIP_TRY(w->mass_palette.ensure(256 * sizeof(float2)));
+    HIP_TRY(w->grav_palette.ensure(256 * sizeof(float4)));
+    w->grav_palette_stale = true;
     w->rebuild_view();
 
     if (nf.n_slots) {
@@ -821,6 +826,7 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
             const float im = w->palette_inv_mass[k];
             pal[k] = float2{im, im != 0.0f ? 1.0f / im : 0.0f}; // same IEEE divide the kernel's fallback path performs
         }
+        w->grav_palette_stale = true;
         HIP_TRY(hipMemcpyAsync(w->mass_palette.p, pal.data(), pal.size() * sizeof(float2), hipMemcpyHostToDevice, w->stream));
         HIP_TRY(hipStreamSynchronize(w->stream));
     }
@@ -874,6 +880,26 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
     }
     const bool phys = (flags & BGE_TICK_PHYSICS) != 0;
     const bool xform = (flags & BGE_TICK_TRANSFORMS) != 0;
+    if (phys && (w->grav_palette_stale || gravity[0] != w->grav_cached[0] || gravity[1] != w->grav_cached[1] ||
+                 gravity[2] != w->grav_cached[2] || std::memcmp(gravity, w->grav_cached, 12) != 0)) {
+        // btRigidBody::setGravity: m_gravity = acceleration / m_inverseMass, one IEEE division per component (the same
+        // correctly rounded binary32 division on the host as the kernel's fallback path performs on the device)
+        std::vector<float> tab(256 * 4, 0.0f);
+        for (size_t k = 0; k < w->palette_inv_mass.size() && k < 256; ++k) {
+            const float im = w->palette_inv_mass[k];
+            if (im != 0.0f) {
+                tab[4 * k] = gravity[0] / im;
+                tab[4 * k + 1] = gravity[1] / im;
+                tab[4 * k + 2] = gravity[2] / im;
+            }
+            tab[4 * k + 3] = im;
+        }
+        HIP_TRY(hipStreamSynchronize(w->stream)); // ticks in flight still read the old table
+        HIP_TRY(hipMemcpy(w->grav_palette.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        std::memcpy(w->grav_cached, gravity, 12);
+        w->grav_palette_stale = false;
+        w->drop_graph();
+    }
     if (w->profiling) {
         // room for every pair of this call, so that no mid-run synchronisation is needed
         const size_t need = w->prof_used + 2 * static_cast<size_t>(w->profiling == 2 ? ticks : 1);

@@ -93,10 +93,9 @@ def integrate(pos, vel, dynamic, ticks, dt, gravity=(0.0, -9.81, 0.0), inv_mass=
     pos, vel = np.array(pos, F), np.array(vel, F)
     dt = F(dt)
     inv_mass = np.ones(len(pos), F) if inv_mass is None else np.asarray(inv_mass, F)
-    mass = F(1.0) / inv_mass
     p, v = pos[dynamic], vel[dynamic]
-    im, m = inv_mass[dynamic], mass[dynamic]
-    imp = [((F(g) * m) * im) * dt for g in gravity]
+    im = inv_mass[dynamic]
+    imp = [((F(g) / im).astype(F) * im) * dt for g in gravity]   # m_gravity = g / invMass; impulse = (F * invMass) * dt
     for _ in range(ticks):
         for a in range(3):
             v[:, a] = v[:, a] + imp[a]

@@ -20,7 +20,7 @@
 // and, inside stepSimulation, Bullet's published per-step sequence for an active free body
 // (BulletDynamics/Dynamics/btDiscreteDynamicsWorld.cpp, btRigidBody.cpp,
 //  BulletDynamics/ConstraintSolver/btSequentialImpulseConstraintSolver.cpp):
-//   applyGravity:            totalForce += g * (1/invMass)
+//   applyGravity:            totalForce += m_gravity, m_gravity = g / invMass (btRigidBody::setGravity)
 //   predictUnconstraintMotion: damping factor pow(1-0, dt) == 1; predicted pose = integrate(x, v, w, dt)
 //   updateAabbs:             AABB(current pose) ∪ AABB(predicted pose), each grown by 0.02
 //   solver writeback:        v += (totalForce * invMass) * dt          (externalForceImpulse)
@@ -284,9 +284,9 @@ private:
                 continue;
             }
 
-            // applyGravity + solver write-back of the external force impulse
-            const float massInv = 1.0f / rt.invMass;
-            const bt::Vec3 force{g.x * massInv, g.y * massInv, g.z * massInv};
+            // applyGravity + solver write-back of the external force impulse.  m_gravity = acceleration / m_inverseMass:
+            // a division per component in the reference's build (btRigidBody::setGravity, check_bullet_order.py)
+            const bt::Vec3 force{g.x / rt.invMass, g.y / rt.invMass, g.z / rt.invMass};
             rt.linvel.x = rt.linvel.x + (force.x * rt.invMass) * dt;
             rt.linvel.y = rt.linvel.y + (force.y * rt.invMass) * dt;
             rt.linvel.z = rt.linvel.z + (force.z * rt.invMass) * dt;

@@ -242,6 +242,80 @@ def check_integrate_transform():
     return ok
 
 
+def check_external_force_impulse():
+    """How gravity reaches the velocity.  Two candidates are linked into the exe (btRigidBody layout of this build:
+    m_inverseMass at +0x1d0, m_totalForce at +0x220, m_linearVelocity at +0x1b0):
+      * btSequentialImpulseConstraintSolver::initSolverBody: m_externalForceImpulse = totalForce * invMass * timeStep,
+        added to the velocity when the solver writes back  -> (F * invMass) * dt
+      * btRigidBody::integrateVelocities: m_linearVelocity += m_totalForce * (m_inverseMass * step) -> F * (invMass * dt)
+    The first is executed symbolically; the second is shown to have no caller."""
+    import numpy as np
+    from check_bx_order import EXE, Pe, objdump, parse
+    pe = Pe(EXE)
+    b = pe.b
+    va, _, raw, rs = pe.secs[0]
+    text = b[raw: raw + rs]
+    ok = True
+    # initSolverBody: the only `mulss 0x220(%r8),%xmm1`
+    sig = bytes.fromhex("f3410f59882002 0000".replace(" ", ""))
+    hits = [m.start() for m in re.finditer(re.escape(sig), text)]
+    assert len(hits) == 1, hits
+    at = va + hits[0]
+    ins = parse(objdump(EXE, [f"--start-address={pe.base + at - 0x14:#x}", f"--stop-address={pe.base + at + 0x60:#x}"]), multi_ret=True)
+    # window: from the load of m_inverseMass (movss 0x1d0(%r8),%xmm3) to the vector assembly
+    first = next(k for k, x in enumerate(ins) if x[1] == "movss" and x[2].startswith("0x1d0(%r8)"))
+    last = next(k for k, x in enumerate(ins) if k > first and x[1] == "movss" and x[2] == "%xmm1,%xmm0")
+    dt = E(("in", "dt", 0))
+    got = execute(ins[first:last + 1], {"%r8": "rb"}, "%none", {"%xmm7": dt.t}, {}, pe.bytes_at_va,
+                  probes={ins[last][0]: ["%xmm1", "%xmm2", "%xmm3"]})
+    inv = E(("in", "rb", 0x1D0 // 4))
+    want = [((E(("in", "rb", (0x220 + 4 * k) // 4)) * inv) * dt).t for k in range(3)]
+    bad = [k for k, r in enumerate(("%xmm1", "%xmm2", "%xmm3")) if norm(got[("probe", ins[last][0], r)]) != norm(want[k])]
+    print(f"initSolverBody: externalForceImpulse = (totalForce * invMass) * timeStep: {3 - len(bad)} of 3 components identical"
+          + ("" if not bad else "  <-- MISMATCH"))
+    ok &= not bad
+    # btRigidBody::setGravity: the only function that stores a vector to m_gravity (+0x1f0): `movups %xmm3,0x1f0(%rcx)`
+    sigg = bytes.fromhex("0f1199f0010000")
+    # (a second function stores through the same encoding at another layout; setGravity is the one that divides by +0x1d0)
+    hg = [m.start() for m in re.finditer(re.escape(sigg), text)
+          if text.find(bytes.fromhex("f30f1099d0010000"), max(m.start() - 0x80, 0), m.start()) != -1]   # movss 0x1d0(%rcx),%xmm3
+    assert len(hg) == 1, hg
+    j = hg[0]
+    while not (text[j - 1] == 0xCC and text[j - 2] == 0xCC):
+        j -= 1
+    gins = parse(objdump(EXE, [f"--start-address={pe.base + va + j:#x}", f"--stop-address={pe.base + va + hg[0] + 7:#x}"]), multi_ret=True)
+    shuf = next(x[0] for x in gins if x[1] == "shufps")
+    got = execute(gins, {"%rcx": "rb", "%rdx": "acc"}, "%none", {}, {}, pe.bytes_at_va, probes={shuf: ["%xmm0", "%xmm1", "%xmm2"]})
+    want = [("div", ("in", "acc", k), ("in", "rb", 0x1D0 // 4)) for k in range(3)]
+    bad = [k for k, r in enumerate(("%xmm0", "%xmm1", "%xmm2")) if norm(got[("probe", shuf, r)]) != norm(want[k])]
+    print(f"btRigidBody::setGravity: m_gravity = acceleration / m_inverseMass (one division per component): {3 - len(bad)} of 3 identical"
+          + ("" if not bad else "  <-- MISMATCH"))
+    ok &= not bad
+    # integrateVelocities: `mulss 0x1d0(%rcx),%xmm4` followed within 64 bytes by `mulss 0x220(%rcx),%xmm0`
+    s1, s2 = bytes.fromhex("f30f59a1d0010000"), bytes.fromhex("f30f598120020000")
+    cand = [m.start() for m in re.finditer(re.escape(s1), text) if text.find(s2, m.start(), m.start() + 64) != -1]
+    assert len(cand) == 1, cand
+    j = cand[0]
+    while not (text[j - 1] == 0xCC and text[j - 2] == 0xCC):
+        j -= 1
+    fn_rva = va + j
+    code = np.frombuffer(text, dtype=np.uint8).astype(np.int64)
+    n = len(code) - 5
+    d = code[1:n + 1] | (code[2:n + 2] << 8) | (code[3:n + 3] << 16) | (code[4:n + 4] << 24)
+    d = np.where(d >= 2 ** 31, d - 2 ** 32, d)
+    tgt = np.arange(n, dtype=np.int64) + va + 5 + d
+
+    def refs(rva, opcode):
+        return [int(i) + va for i in np.nonzero((code[:n] == opcode) & (tgt == rva))[0]]
+
+    thunks = refs(fn_rva, 0xE9)
+    callers = refs(fn_rva, 0xE8) + [c for t in thunks for c in refs(t, 0xE8) + refs(t, 0xE9)]
+    print(f"btRigidBody::integrateVelocities (F * (invMass * dt)) at VA {pe.base + fn_rva:#x}: {len(thunks)} thunk(s), "
+          f"{len(callers)} callers -> {'never called' if not callers else 'CALLED'}")
+    ok &= not callers
+    return ok
+
+
 def main():
     ok = True
     # 1. ToBtQuaternion(euler): result through rcx (hidden return pointer), euler through rdx
@@ -296,6 +370,7 @@ def main():
     print(f"btMatrix3x3::getRotation, trace > 0: {4 - len(bad)} of 4 components identical" + ("" if not bad else f"  <-- MISMATCH {bad}"))
     ok &= not bad
     ok &= check_integrate_transform()
+    ok &= check_external_force_impulse()
     print("RESULT:", "the restatement has the compiled code's operation order" if ok else "MISMATCH")
     return 0 if ok else 1
 

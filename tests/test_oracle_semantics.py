@@ -146,7 +146,7 @@ def test_b9_body_recreation_resets_velocity_and_clamps_mass():
     sc.PhysicsSystemUpdate(DT)
     sc.TransformSystemUpdate()
     inv_m = np.float32(1.0) / np.float32(0.01)
-    f = np.float32(-9.81) * (np.float32(1.0) / inv_m)
+    f = np.float32(-9.81) / inv_m   # btRigidBody::setGravity: acceleration / m_inverseMass (a division in the reference's build)
     assert sc.GetBody(d)["linvel"][1] == (f * inv_m) * np.float32(DT)
     sc.PhysicsSystemUpdate(DT)
     sc.TransformSystemUpdate()
