@@ -8,7 +8,7 @@ implementation: importing works without a GPU, creating a :class:`World` without
 """
 from ._capi import BgeError, lib, lib_path  # noqa: F401
 from .world import (BODY_DYNAMIC, BODY_KINEMATIC, BODY_NONE, BODY_STATIC, NO_PARENT, SHAPE_BOX, SHAPE_CAPSULE,  # noqa: F401
-                    TICK_AABBS, TICK_ALL, TICK_BROADPHASE, TICK_GATHER_ROOTS, TICK_NORMAL_MATRICES, TICK_PHYSICS, TICK_TRANSFORMS, World, flatten_topology,
+                    TICK_AABBS, TICK_ALL, TICK_BULLET_BASIS, TICK_BROADPHASE, TICK_GATHER_ROOTS, TICK_NORMAL_MATRICES, TICK_PHYSICS, TICK_TRANSFORMS, World, flatten_topology,
                     partition_subtrees)
 
 __all__ = ["World", "BgeError", "lib", "lib_path", "flatten_topology", "partition_subtrees"]

@@ -243,6 +243,39 @@ __device__ __forceinline__ M3 bt_mat_from_quat(const Q4& q)
     return r;
 }
 
+// btMatrix3x3::getRotation(q), scalar path (oracle/bullet_math.h QuatFromMat; the trace > 0 side is checked against the
+// reference's PhysicsSystem.obj by oracle/tools/check_bullet_order.py, the other side was read from the same code).  The
+// run-time indices i, j, k of Bullet's code are spelled out as three cases: no dynamically indexed arrays (scratch).
+__device__ __forceinline__ Q4 bt_quat_from_mat(const M3& a)
+{
+    const float trace = a.m[0][0] + a.m[1][1] + a.m[2][2];
+    if (trace > 0.0f) {
+        float s = __builtin_sqrtf(trace + 1.0f);
+        const float w = s * 0.5f;
+        s = 0.5f / s;
+        return Q4{(a.m[2][1] - a.m[1][2]) * s, (a.m[0][2] - a.m[2][0]) * s, (a.m[1][0] - a.m[0][1]) * s, w};
+    }
+    const int i = a.m[0][0] < a.m[1][1] ? (a.m[1][1] < a.m[2][2] ? 2 : 1) : (a.m[0][0] < a.m[2][2] ? 2 : 0);
+    // t[i] = s/2, t[3] = (m[k][j] - m[j][k]) s', t[j] = (m[j][i] + m[i][j]) s', t[k] = (m[k][i] + m[i][k]) s'
+    if (i == 0) { // j = 1, k = 2
+        float s = __builtin_sqrtf(a.m[0][0] - a.m[1][1] - a.m[2][2] + 1.0f);
+        const float ti = s * 0.5f;
+        s = 0.5f / s;
+        return Q4{ti, (a.m[1][0] + a.m[0][1]) * s, (a.m[2][0] + a.m[0][2]) * s, (a.m[2][1] - a.m[1][2]) * s};
+    }
+    if (i == 1) { // j = 2, k = 0
+        float s = __builtin_sqrtf(a.m[1][1] - a.m[2][2] - a.m[0][0] + 1.0f);
+        const float ti = s * 0.5f;
+        s = 0.5f / s;
+        return Q4{(a.m[0][1] + a.m[1][0]) * s, ti, (a.m[2][1] + a.m[1][2]) * s, (a.m[0][2] - a.m[2][0]) * s};
+    }
+    // i = 2, j = 0, k = 1
+    float s = __builtin_sqrtf(a.m[2][2] - a.m[0][0] - a.m[1][1] + 1.0f);
+    const float ti = s * 0.5f;
+    s = 0.5f / s;
+    return Q4{(a.m[0][2] + a.m[2][0]) * s, (a.m[1][2] + a.m[2][1]) * s, ti, (a.m[1][0] - a.m[0][1]) * s};
+}
+
 // Transform::rotationEuler written by SyncRigidBodiesFromPhysics: {pitch, yaw, roll} of getEulerZYX
 __device__ __forceinline__ F3 bt_transform_euler_from_mat(const M3& a)
 {

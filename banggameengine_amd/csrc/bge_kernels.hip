@@ -1,6 +1,6 @@
 // bge_kernels.hip — hand-written gfx950 kernels of the world tick.
 //
-// k_tick<PHYS, XFORM, AABB, NORMAL>: one workgroup (4 wave64) per 256-slot tile.
+// k_tick<PHYS, XFORM, AABB, NORMAL, BASIS>: one workgroup (4 wave64) per 256-slot tile.
 //   PHYS   rigid-body slice of PhysicsSystem::Update for free bodies
 //          (src/physics/PhysicsSystem.cpp:952-989 re-pose rule, :863 one Bullet sub-step,
 //           :916-950 write-back + mark dirty)
@@ -111,10 +111,13 @@ constexpr bool kSleepEnabled = true;
 #ifndef BGE_AABB_MIN_WAVES
 #define BGE_AABB_MIN_WAVES 4 /* waves per SIMD the AABB variant is compiled for: at 8 it spills 20 VGPRs (measured ~2 % slower at 4 M bodies) */
 #endif
-template <bool PHYS, bool XFORM, bool AABB, bool NORMAL>
+#ifndef BGE_BASIS_MIN_WAVES
+#define BGE_BASIS_MIN_WAVES 6 /* the BGE_TICK_BULLET_BASIS variants without AABBs / normal matrices: 80 VGPRs; measured at 1 M bodies 35.1 us at 4, 34.8 at 6, 36.4 at 8 (64 VGPRs + 12 B scratch) */
+#endif
+template <bool PHYS, bool XFORM, bool AABB, bool NORMAL, bool BASIS>
 // 8 waves per SIMD (<= 64 VGPRs): the kernel waits on memory and, in block tiles, on barriers; occupancy hides both
 // (the NORMAL variant carries a 4x4 inverse: it gets 128 VGPRs instead of spilling)
-__global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES : 8)) k_tick(WorldView w, TickParams p)
+__global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES : (BASIS ? BGE_BASIS_MIN_WAVES : 8))) k_tick(WorldView w, TickParams p)
 {
     __shared__ float4 lds[kTile * 4];
 
@@ -142,6 +145,12 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             const bool dynamic = type == 2u;
             const bool repose = (f & (kTDirty | kBDirty)) != 0;
             bool spin = (f & kSpin) != 0;
+            // BASIS (BGE_TICK_BULLET_BASIS): Bullet's own orientation scheme.  Its state is the 3x3 basis, which every step
+            // goes basis -> getRotation -> exponential map -> safeNormalize -> setRotation for EVERY non-static body, spinning
+            // or not.  The basis is always setRotation(q) of a stored quaternion, so q stays the state here and the basis
+            // is recomputed from it: same bits, 16 instead of 36 bytes.
+            const bool turn = BASIS ? dynamic : spin;
+            bool advanced = false;
             Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
             F3 v{0.0f, 0.0f, 0.0f};
             F3 av{0.0f, 0.0f, 0.0f};
@@ -157,7 +166,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             } else {
                 if (dynamic) v = ld3(w.vel, slot);
                 if (spin) av = ld3(w.angvel, slot);
-                if (spin || AABB) q = ld4(w.quat, slot);
+                if (turn || AABB) q = ld4(w.quat, slot);
             }
 
             if (AABB) {
@@ -169,8 +178,8 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     // interpolation transform of predictUnconstraintMotion: velocity before the gravity impulse
                     const F3 pp{pos.x + v.x * p.dt, pos.y + v.y * p.dt, pos.z + v.z * p.dt};
                     float mn2[3], mx2[3];
-                    if (spin) {
-                        const M3 r2 = bt_mat_from_quat(bt_integrate_orientation(q, av, p.dt));
+                    if (turn) {
+                        const M3 r2 = bt_mat_from_quat(bt_integrate_orientation(BASIS ? bt_quat_from_mat(r) : q, av, p.dt));
                         bt_aabb_of_pose(pp, r2, he, mn2, mx2);
                     } else {
                         bt_aabb_of_pose(pp, r, he, mn2, mx2);
@@ -229,9 +238,10 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     pos.x = pos.x + v.x * p.dt;
                     pos.y = pos.y + v.y * p.dt;
                     pos.z = pos.z + v.z * p.dt;
-                    if (spin) {
-                        q = bt_integrate_orientation(q, av, p.dt);
+                    if (turn) {
+                        q = bt_integrate_orientation(BASIS ? bt_quat_from_mat(bt_mat_from_quat(q)) : q, av, p.dt);
                         st4(w.quat, slot, q);
+                        advanced = true;
                     }
                     st3(w.vel, slot, v);
                     st3(w.pos, slot, pos);
@@ -259,7 +269,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 }
                 // SyncRigidBodiesFromPhysics: rotationEuler <- getEulerZYX(basis) whenever the orientation was
                 // (re)posed or advanced; a non-spinning body keeps its euler triple bit for bit
-                if (repose || spin) {
+                if (repose || advanced) {
                     eul = bt_transform_euler_from_mat(bt_mat_from_quat(q));
                     st3(w.euler, slot, eul);
                 }
@@ -645,7 +655,12 @@ hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams&
     if (n_tiles == 0) return hipSuccess;
     const bool phys = (flags & 1u) != 0, xform = (flags & 2u) != 0, aabb = (flags & (4u | 32u)) != 0, normal = (flags & 16u) != 0;
     const dim3 grid(n_tiles), block(kTile);
-#define BGE_LAUNCH(P, X, A, N) hipLaunchKernelGGL((k_tick<P, X, A, N>), grid, block, 0, stream, w, p)
+    const bool basis = phys && (flags & 64u) != 0;
+#define BGE_LAUNCH(P, X, A, N)                                                                      \
+    do {                                                                                            \
+        if (basis) hipLaunchKernelGGL((k_tick<P, X, A, N, P>), grid, block, 0, stream, w, p);       \
+        else hipLaunchKernelGGL((k_tick<P, X, A, N, false>), grid, block, 0, stream, w, p);         \
+    } while (0)
     if (normal && xform) {
         if (phys && aabb) BGE_LAUNCH(true, true, true, true);
         else if (phys) BGE_LAUNCH(true, true, false, true);

@@ -867,6 +867,9 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
     if ((flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS)) && !(flags & BGE_TICK_PHYSICS)) {
         return fail(BGE_ERR_INVALID, "BGE_TICK_BROADPHASE / BGE_TICK_AABBS need BGE_TICK_PHYSICS (the AABBs come from the physics step)");
     }
+    if ((flags & BGE_TICK_BULLET_BASIS) && !(flags & BGE_TICK_PHYSICS)) {
+        return fail(BGE_ERR_INVALID, "BGE_TICK_BULLET_BASIS needs BGE_TICK_PHYSICS (it selects how the physics step carries orientations)");
+    }
     if ((flags & BGE_TICK_PHYSICS) && !gravity) return fail(BGE_ERR_INVALID, "gravity is NULL");
     if ((flags & BGE_TICK_NORMAL_MATRICES) && !(flags & BGE_TICK_TRANSFORMS)) {
         return fail(BGE_ERR_INVALID, "BGE_TICK_NORMAL_MATRICES needs BGE_TICK_TRANSFORMS (they are derived from the new world matrices)");

@@ -72,6 +72,9 @@ public:
     bool ok() const { return world_ != nullptr; }
     bge_world* world() { return world_; }
     float gravity[3] = {0.0f, -9.81f, 0.0f}; // PhysicsSystem.cpp:130 with assets/config/physics.json:2
+    // BGE_TICK_BULLET_BASIS: carry every Dynamic body's orientation the way Bullet does (basis round trip each step, euler
+    // rewritten from it) instead of leaving a non-spinning body's orientation and euler untouched
+    bool bullet_basis = false;
 
     // Resident mode: the world matrices stay on the device after TransformSystem::Update; only the host `dirty` flags
     // are kept coherent and the caller fetches the matrices it needs (FetchWorld) — e.g. the visible set.  Coherent
@@ -134,6 +137,7 @@ public:
     {
         if (!ok() || !RefreshTopology(scene) || !UploadBodies(scene) || !UploadDirtyTransforms(scene)) return false;
         uint32_t flags = BGE_TICK_PHYSICS;
+        if (bullet_basis) flags |= BGE_TICK_BULLET_BASIS;
         bool triggers = false;
         if constexpr (detail::has_trigger_volumes<SceneT>::value) {
             if (!UploadTriggers(scene, triggers)) return false;
@@ -500,6 +504,9 @@ public:
     void OnSceneReloaded(SceneT& scene) { GpuMirrors<SceneT>::Drop(scene); }
     double GetFixedStep() const { return fixedStep_; }
     void SetGravity(float g) { gravityY_ = g; }
+    // Bullet's own orientation scheme for every Dynamic body (include/bge_world.h, BGE_TICK_BULLET_BASIS); choose before
+    // the first Update of a scene
+    void SetBulletBasis(bool on) { bulletBasis_ = on; }
     // rigid-body slice of PhysicsSystem::Update(Scene&, const Camera&, const InputSystem&, double dt)
     void Update(SceneT& scene, double dt)
     {
@@ -507,6 +514,7 @@ public:
         m.gravity[0] = 0.0f;
         m.gravity[1] = gravityY_;
         m.gravity[2] = 0.0f;
+        m.bullet_basis = bulletBasis_;
         m.UpdatePhysics(scene, dt);
     }
     // trigger events of the last Update (publish them on the engine's EventBus, src/core/EventBus.h)
@@ -514,6 +522,7 @@ public:
 
 private:
     float gravityY_ = -9.81f;
+    bool bulletBasis_ = false;
     double fixedStep_ = 1.0f / 120.0f; // PhysicsSystem.h:88
 };
 

@@ -12,6 +12,7 @@ NO_PARENT = 0xFFFFFFFF
 BODY_STATIC, BODY_DYNAMIC, BODY_KINEMATIC, BODY_NONE = 0, 1, 2, 255
 SHAPE_BOX, SHAPE_CAPSULE = 0, 1
 TICK_PHYSICS, TICK_TRANSFORMS, TICK_BROADPHASE, TICK_ALL, TICK_GATHER_ROOTS, TICK_NORMAL_MATRICES, TICK_AABBS = 1, 2, 4, 3, 8, 16, 32
+TICK_BULLET_BASIS = 64
 ARRAY_WORLD, ARRAY_ROOT_WORLDS, ARRAY_SLOT_OF_ENTITY, ARRAY_POSITION, ARRAY_PAIRS = 0, 1, 2, 3, 4
 
 # fixed step and gravity of the reference (assets/config/physics.json:2-3)

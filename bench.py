@@ -46,6 +46,9 @@ def parse_args():
                                                               "double-buffered on a side stream")
     ap.add_argument("--gather-mode", choices=["allgather", "direct"], default=None,
                     help="force the schedule of the native root gather (default: time both before the timed region, keep the faster)")
+    ap.add_argument("--bullet-basis", action="store_true",
+                    help="BGE_TICK_BULLET_BASIS: Bullet's basis round trip + euler rewrite for every Dynamic body each tick "
+                         "(+44 B per body: quaternion in and out, rotationEuler out); default: zero-spin bodies keep theirs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-core CPU leg (a 1-GPU box's CPU share)")
@@ -143,7 +146,7 @@ def main():
     elif base.shape == synth.CHAINS4:
         per_gpu -= per_gpu % 4
     wl = synth.config(name, n=per_gpu, first=rank * per_gpu)  # global entity numbering: shard r = [r*per_gpu, (r+1)*per_gpu)
-    flags = B.TICK_ALL | (B.TICK_BROADPHASE if name == "cube4m" else 0)
+    flags = B.TICK_ALL | (B.TICK_BROADPHASE if name == "cube4m" else 0) | (B.TICK_BULLET_BASIS if args.bullet_basis else 0)
 
     # a dedicated (non-null) torch stream carries the world's kernels, the events and the collective
     stream = torch.cuda.Stream()
@@ -306,6 +309,10 @@ def main():
             # broadphase kernels of every step, so both sides of the ratio cover the whole step
             bytes_per_update = 208.0 + 8.0 * world.pair_count() / per_gpu
             kernel_name = "k_tick<physics,transforms,aabb> + broadphase (sort, pair search)"
+        if args.bullet_basis:
+            # every Dynamic body also reads and writes its quaternion (16 + 16 B) and writes rotationEuler (12 B)
+            bytes_per_update += 44.0 * float((wl.body_type == 1).mean())
+            kernel_name += " [bullet basis]"
         alg_bytes = bytes_per_update * per_gpu  # per step on one GPU
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -336,6 +343,8 @@ def main():
                 "gather_check": gather_check,
                 "gather_schedule_trials_ms": gather_trials,
                 "dt": FIXED_DT, "gravity": list(GRAVITY),
+                "orientation": "bullet basis round trip every tick" if args.bullet_basis
+                               else "quaternion state; a body with zero angular velocity keeps its orientation (DESIGN.md 4.2)",
                 "bytes_per_update_algorithmic": bytes_per_update,
             },
             "roofline": {

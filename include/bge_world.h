@@ -66,8 +66,15 @@ enum bge_tick_flags {
     BGE_TICK_GATHER_ROOTS = 8u, /* after the tick: bge_world_gather_roots (needs bge_world_comm_init) */
     BGE_TICK_NORMAL_MATRICES = 16u, /* with TRANSFORMS: also write transpose(inverse(world)) per entity, the normalMtx
                                       Renderer::BeginFrame computes on the CPU per mesh (src/render/Renderer.cpp:633-636) */
-    BGE_TICK_AABBS = 32u      /* with PHYSICS: update the AABBs (Bullet updateAabbs) without the local pair search —
+    BGE_TICK_AABBS = 32u,     /* with PHYSICS: update the AABBs (Bullet updateAabbs) without the local pair search —
                                  the sharded broadphase (bge_world_bp_*) searches them across ranks instead */
+    BGE_TICK_BULLET_BASIS = 64u /* with PHYSICS: Bullet's own orientation scheme for every Dynamic body, spinning or not —
+                                 each step its basis goes through btMatrix3x3::getRotation, btTransformUtil::integrateTransform's
+                                 exponential map + safeNormalize and setRotation, and SyncRigidBodiesFromPhysics
+                                 (src/physics/PhysicsSystem.cpp:925-950) rewrites Transform::rotationEuler from it.  Without the
+                                 flag a body whose angular velocity is exactly zero keeps its orientation and euler triple bit
+                                 for bit (within 1e-5 relative of this mode; 44 bytes per body and tick cheaper).
+                                 Use one mode for the whole life of a world. */
 };
 
 enum bge_device_array {

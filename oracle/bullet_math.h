@@ -18,7 +18,9 @@
 // (setEulerZYX through the reference's ToBtQuaternion, btMatrix3x3::setRotation / getEulerZYX /
 // getRotation), whose compiled bodies sit in the reference's committed PhysicsSystem.obj and were
 // executed symbolically against the formulas below (oracle/tools/check_bullet_order.py: operation
-// order, association, constants, branch structure and the euler.y/x/z -> yaw/pitch/roll mapping).
+// order, association, constants, branch structure and the euler.y/x/z -> yaw/pitch/roll mapping);
+// AND integrateTransform, setGravity / the force impulse, btBoxShape / btCapsuleShape (margins, getAabb)
+// and updateSingleAabb, which the same script finds inside the symbol-less SandboxCity.exe.
 //
 // libm: Bullet calls the platform sinf/cosf/asinf/atan2f.  g_libm selects either the
 // platform libm (what Bullet does) or the deterministic routines of

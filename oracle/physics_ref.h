@@ -47,10 +47,14 @@
 //                  angular velocity is exactly zero keeps its orientation and its Transform euler
 //                  bit for bit after the tick in which it was (re)posed.
 //   kOrientQuat    state is a quaternion, re-normalised and written back every tick.
-//   kOrientBasis   Bullet's own scheme: 3x3 basis state, getRotation/setRotation every tick.
+//   kOrientBasis   Bullet's own scheme: 3x3 basis state, getRotation/setRotation every tick
+//                  (the GPU path's BGE_TICK_BULLET_BASIS, bit-identical to this mode).
 // tests/test_oracle_physics.py bounds the distance between the modes.
 //
-// PARITY STATUS: "parity unpinned" (Bullet absent and unpinned; spec-derived).
+// PARITY STATUS: "parity unpinned" in the strict sense (Bullet absent; the reference holds no fixtures).  The arithmetic
+// of every step below — pose conversions, integrateTransform, gravity force and impulse, shape margins, getAabb,
+// updateSingleAabb — is checked against the reference's compiled code by oracle/tools/check_bullet_order.py; the
+// deactivation rule was read from the same disassembly; the ORDER of the steps is from Bullet's published code.
 #pragma once
 
 #include <algorithm>

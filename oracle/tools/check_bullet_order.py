@@ -31,8 +31,8 @@ from check_bx_order import E, compare, execute, norm  # noqa: E402
 OBJ = "/root/reference/build/SandboxCity.dir/RelWithDebInfo/PhysicsSystem.obj"
 
 
-def coff_function(path, wanted):
-    """(instructions, {pc_next: constant tree}, {pc_next: callee}) of the COMDAT function whose symbol contains `wanted`."""
+def coff_section(path, wanted):
+    """(symbol, code bytes, {offset: relocation symbol}) of the COMDAT function whose symbol contains `wanted`."""
     b = open(path, "rb").read()
     _, nsec, _, symoff, nsym, optsz, _ = struct.unpack_from("<HHIIIHH", b, 0)
     secs, off = [], 20 + optsz
@@ -54,7 +54,7 @@ def coff_function(path, wanted):
         _, sec, _, _, naux = struct.unpack_from("<IhHBB", e, 8)
         syms[i] = (sname(e), sec)
         i += 1 + naux
-    hits = [(n, s) for n, s in syms.values() if wanted in n and s > 0 and not n.startswith("$")]
+    hits = [(n, s) for n, s in syms.values() if wanted in n and s > 0 and not n.startswith("$") and not n.startswith("?dtor$")]
     assert len(hits) == 1, hits
     rsz, raw, reloc, nreloc = secs[hits[0][1] - 1]
     code = b[raw: raw + rsz]
@@ -62,6 +62,12 @@ def coff_function(path, wanted):
     for k in range(nreloc):
         va, si, _ = struct.unpack_from("<IIH", b, reloc + k * 10)
         rel[va] = syms[si][0]
+    return hits[0][0], code, rel
+
+
+def coff_function(path, wanted):
+    """(instructions, {pc_next: constant tree}, {pc_next: callee}) of the COMDAT function whose symbol contains `wanted`."""
+    symbol, code, rel = coff_section(path, wanted)
     tmp = "/tmp/_bge_fn.bin"
     open(tmp, "wb").write(code)
     text = subprocess.run(["objdump", "-D", "-b", "binary", "-m", "i386:x86-64", "--no-show-raw-insn", tmp],
@@ -91,7 +97,7 @@ def coff_function(path, wanted):
             consts[nxt] = ("opaque", name)
         else:
             raise AssertionError(name)
-    return hits[0][0], ins, consts, calls
+    return symbol, ins, consts, calls
 
 
 def C(x):
@@ -316,6 +322,303 @@ def check_external_force_impulse():
     return ok
 
 
+def _resolve(pe, va):
+    """Through an incremental-link thunk (jmp rel32), if there is one."""
+    fo = pe.r2f(va - pe.base)
+    return va + 5 + struct.unpack_from("<i", pe.b, fo + 1)[0] if pe.b[fo] == 0xE9 else va
+
+
+def _disasm(pe, va, size=0x400, multi_ret=False):
+    from check_bx_order import EXE, objdump, parse
+    return parse(objdump(EXE, [f"--start-address={va:#x}", f"--stop-address={va + size:#x}"]), multi_ret=multi_ret)
+
+
+def _rip_refs(pe, rva):
+    """RVAs of the disp32 fields in .text that resolve (as the last 4 bytes of an instruction) to `rva`."""
+    import numpy as np
+    va, _, raw, rs = pe.secs[0]
+    code = np.frombuffer(pe.b[raw: raw + rs], dtype=np.uint8).astype(np.int64)
+    n = len(code) - 4
+    d = code[:n] | (code[1:n + 1] << 8) | (code[2:n + 2] << 16) | (code[3:n + 3] << 24)
+    d = np.where(d >= 2 ** 31, d - 2 ** 32, d)
+    return [int(i) + va for i in np.nonzero(np.arange(n, dtype=np.int64) + va + 4 + d == rva)[0]]
+
+
+def _function_start(pe, rva):
+    va, _, raw, rs = pe.secs[0]
+    j = raw + rva - va
+    while not (pe.b[j - 1] == 0xCC and pe.b[j - 2] == 0xCC):
+        j -= 1
+    return va + j - raw
+
+
+def _virtual(ins, slot, token):
+    """`call *slot(%rax)` -> `call token`, so that a hook can model the virtual callee."""
+    return [(pc, mn, f"{token:#x}") if mn == "call" and ops == f"*{slot:#x}(%rax)" else (pc, mn, ops) for pc, mn, ops in ins]
+
+
+def check_box_aabb():
+    """btBoxShape (constructor, setSafeMargin, setMargin, getAabb) and btCollisionWorld::updateSingleAabb, all inside the
+    symbol-less exe.  The constructor is found through the call PhysicsSystem::CreateShape makes to it (the relocation in
+    PhysicsSystem.obj names ??0btBoxShape@@...; the bytes in front of that call are found again in the exe), everything else
+    from there: the base constructors through its first call, getAabb / getMargin / setMargin through the vtable it stores.
+    btBoxShape of this build: m_localScaling +0x20, m_implicitShapeDimensions +0x30, m_collisionMargin +0x40."""
+    from check_bx_order import EXE, Pe
+    pe = Pe(EXE)
+    ok = True
+    _, code, rel = coff_section(OBJ, "?CreateShape@PhysicsSystem@@AEBA")
+    sites = sorted(off for off, name in rel.items() if name.startswith("??0btBoxShape@@"))
+    assert sites, "CreateShape does not construct a btBoxShape?"
+    targets = set()
+    for off in sites:
+        pat = code[off - 13: off]                                   # 12 bytes of set-up + the E8 opcode
+        assert pat[-1] == 0xE8
+        for m in re.finditer(re.escape(pat), pe.b):
+            targets.add(pe.call_target(m.start() + 12))
+    assert len(targets) == 1, targets
+    ctor = pe.base + targets.pop()
+    ins = _disasm(pe, ctor)
+    calls = [int(x[2], 16) for x in ins if x[1] == "call"]
+    assert len(calls) == 2, calls                                   # btPolyhedralConvexShape(), setMargin(safeMargin)
+    # ---- base constructors: btPolyhedralConvexShape() -> btConvexInternalShape(): scaling (1,1,1), margin 0.04
+    base1 = _disasm(pe, _resolve(pe, calls[0]))
+    base2 = _disasm(pe, _resolve(pe, next(int(x[2], 16) for x in base1 if x[1] == "call")))
+    imm = {x[2] for x in base2 if x[1] in ("movl", "movq")}
+    want_imm = {"$0x3f800000,0x20(%rbx)", "$0x3f800000,0x24(%rbx)", "$0x3f800000,0x28(%rbx)", "$0x3d23d70a,0x40(%rbx)"}
+    good = want_imm <= imm
+    print(f"btConvexInternalShape(): localScaling = (1, 1, 1), collisionMargin = 0x3d23d70a (0.04f): {'as restated' if good else 'MISMATCH'}")
+    ok &= good
+    # ---- constructor, part 1: implicitShapeDimensions = halfExtents * localScaling - margin
+    first_shuf = next(x[0] for x in ins if x[1] == "shufps")
+    k_cmp = next(k for k, x in enumerate(ins) if x[1] == "comiss")
+    noop = {calls[0]: lambda reg, mem, sp, out: None}
+    got = execute(ins[:k_cmp], {"%rdx": "he", "%rcx": "this"}, "%none", {}, {}, pe.bytes_at_va, hooks=noop,
+                  probes={first_shuf: ["%xmm3", "%xmm1", "%xmm2"]})
+    margin = E(("in", "this", 0x40 // 4))
+    want = [(E(("in", "he", k)) * E(("in", "this", 0x20 // 4 + k)) - margin).t for k in range(3)]
+    bad = [k for k, r in enumerate(("%xmm3", "%xmm1", "%xmm2")) if norm(got[("probe", first_shuf, r)]) != norm(want[k])]
+    print(f"btBoxShape(halfExtents): implicit = halfExtents * localScaling - margin: {3 - len(bad)} of 3 identical"
+          + ("" if not bad else "  <-- MISMATCH"))
+    ok &= not bad
+    # ---- constructor, part 2: setSafeMargin(halfExtents, 0.1).  minAxis() is integer selection, compared as text:
+    k_mul = next(k for k, x in enumerate(ins) if k > k_cmp and x[1] == "mulss")
+    sel = [(x[1], x[2]) for x in ins[k_cmp - 3: k_mul]]
+    want_sel = [("movss", "(%rdi),%xmm2"), ("movss", "0x4(%rdi),%xmm1"), ("movss", "0x8(%rdi),%xmm0"),
+                ("comiss", "%xmm1,%xmm2"), ("jae", None), ("mov", "$0x2,%eax"), ("comiss", "%xmm2,%xmm0"), ("cmova", "%ecx,%eax"),
+                ("jmp", None), ("mov", "%ecx,%eax"), ("comiss", "%xmm1,%xmm0"), ("setbe", "%al"), ("inc", "%eax"),
+                ("movss", "(%rdi,%rax,4),%xmm1")]
+    # x < y ? (x < z ? 0 : 2) : (y < z ? 1 : 2)   [ecx = 0]
+    good = len(sel) == len(want_sel) and all(a[0] == b[0] and (b[1] is None or a[1] == b[1]) for a, b in zip(sel, want_sel))
+    print(f"btVector3::minAxis of the half extents, x < y ? (x < z ? 0 : 2) : (y < z ? 1 : 2): {'as restated' if good else 'MISMATCH'}")
+    ok &= good
+    seen = {}
+
+    def hook_set_margin(reg, mem, sp, out):
+        seen["arg"] = reg["%xmm1"]
+
+    tail = ins[k_mul:]
+    cmp_pc = next(x for x in tail if x[1] == "comiss")
+    got = execute(tail, {"%rbx": "this"}, "%none", {"%xmm1": ("in", "he", "min"), "%xmm4": margin.t}, {}, pe.bytes_at_va,
+                  hooks={calls[1]: hook_set_margin})
+    good = (norm(seen.get("arg", ("missing",))) == norm(("mul", ("in", "he", "min"), C(0.1).t))
+            and cmp_pc[2] == "%xmm4,%xmm1" and tail[tail.index(cmp_pc) + 1][1] == "jae")
+    print("setSafeMargin: safe = 0.1f * min; setMargin(safe) iff safe < margin: " + ("as restated" if good else "MISMATCH"))
+    ok &= good
+    # ---- the vtable the constructor stores: getAabb (slot 1), getMargin (slot 11), setMargin (the call above)
+    lea = next(x[0] for x in ins if x[1] == "lea" and "(%rip)" in x[2])
+    raw = pe.bytes_at_va(lea, 7)
+    assert raw[:3] == b"\x48\x8d\x05", raw.hex()
+    vtable = lea + 7 + struct.unpack("<i", raw[3:])[0]
+    slot = lambda k: _resolve(pe, struct.unpack("<Q", pe.bytes_at_va(vtable + 8 * k, 8))[0])
+    gm = [(x[1], x[2]) for x in _disasm(pe, slot(0x58 // 8))]
+    good = gm == [("movss", "0x40(%rcx),%xmm0"), ("ret", "")]
+    print(f"btBoxShape vtable at {vtable:#x}: getMargin (slot 11) returns m_collisionMargin: {'yes' if good else 'MISMATCH'}")
+    ok &= good
+
+    def get_margin(reg, mem, sp, out):
+        return out.get(("this", 0x40 // 4), margin.t)               # the member as it is when the call is made
+
+    # ---- setMargin(new): implicit = (implicit + old) - new
+    sm = _virtual(_disasm(pe, _resolve(pe, calls[1])), 0x58, 0xFFFF58)
+    packs = [x for x in sm if x[1] == "movss" and x[2].endswith(",%xmm13") and x[2].startswith("%xmm")]
+    first_shuf = next(x[0] for x in sm if x[1] == "shufps")
+    assert [x[2] for x in packs[:2]] == ["%xmm10,%xmm13", "%xmm12,%xmm13"], packs
+    new = E(("in", "new", 0))
+    got = execute(sm, {"%rcx": "this"}, {"%rcx": "this"}, {"%xmm1": new.t}, {}, pe.bytes_at_va, hooks={0xFFFF58: get_margin},
+                  probes={first_shuf: ["%xmm13"], packs[0][0]: ["%xmm10"], packs[1][0]: ["%xmm12"]})
+    trees = [got[("probe", first_shuf, "%xmm13")], got[("probe", packs[0][0], "%xmm10")], got[("probe", packs[1][0], "%xmm12")]]
+    want = [((E(("in", "this", 0x30 // 4 + k)) + margin) - new).t for k in range(3)]
+    bad = [k for k in range(3) if norm(trees[k]) != norm(want[k])]
+    good = not bad and norm(got.get(("this", 0x40 // 4))) == norm(new.t)
+    print(f"btBoxShape::setMargin: implicit = (implicit + oldMargin) - newMargin, margin = new: {3 - len(bad)} of 3 identical"
+          + ("" if good else "  <-- MISMATCH"))
+    ok &= good
+    # ---- getAabb(t, mn, mx): half = implicit + margin; extent_i = (|r_i0| hx + |r_i1| hy) + |r_i2| hz; origin -/+ extent
+    ga = _virtual(_disasm(pe, slot(1)), 0x58, 0xFFFF58)
+    # the origin is loaded packed (movaps 0x30(%rdi),%xmm9) and y / z are taken out with shufps: rewritten as the scalar loads
+    # they are, after checking that %xmm9 still holds the origin at that point
+    k_mod = next(k for k, x in enumerate(ga) if x[2].endswith(",%xmm9") and x[1] != "movaps")
+    lanes = {"$0xaa": "0x38(%rdi)", "$0x55": "0x34(%rdi)"}
+    for k, (pc, mn, ops) in enumerate(ga):
+        if mn == "shufps":
+            imm8, src, dst = ops.split(",")
+            assert src == "%xmm9" and k < k_mod and any(g[1:] == ("movaps", f"%xmm9,{dst}") for g in ga[k - 4:k]), (hex(pc), ops)
+            ga[k] = (pc, "movss", f"{lanes[imm8]},{dst}")
+    got = execute(ga, {"%rcx": "this", "%rdx": "t"}, {"%r8": "mn", "%r9": "mx"}, {}, {}, pe.bytes_at_va, hooks={0xFFFF58: get_margin})
+    t = lambda r, c: E(("abs", ("in", "t", 4 * r + c)))
+    half = [E(("in", "this", 0x30 // 4 + k)) + margin for k in range(3)]
+    ext = [(t(r, 0) * half[0] + t(r, 1) * half[1]) + t(r, 2) * half[2] for r in range(3)]
+    want = {}
+    for r in range(3):
+        want[("mn", r)] = (E(("in", "t", 12 + r)) - ext[r]).t
+        want[("mx", r)] = (E(("in", "t", 12 + r)) + ext[r]).t
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    print(f"btBoxShape::getAabb: origin -/+ ((|r0| hx + |r1| hy) + |r2| hz), h = implicit + margin: {6 - len(bad)} of 6 identical"
+          + ("" if not bad else f"  <-- MISMATCH {bad}"))
+    for k in bad[:2]:
+        print("   compiled   :", norm(got.get(k, ("missing",))))
+        print("   restatement:", norm(want[k]))
+    ok &= not bad
+    ok &= check_capsule_aabb(pe, code, rel)
+    ok &= check_update_single_aabb(pe)
+    return ok
+
+
+
+def check_capsule_aabb(pe, code, rel):
+    """btCapsuleShape(radius, height) as PhysicsSystem::CreateShape calls it, and btCapsuleShape::getAabb (vtable slot 1).
+    The up axis is a run-time member (m_upAxis, +0x50) that the constructor sets to 1: the three indexed accesses of getAabb
+    are rewritten for that value before the symbolic execution."""
+    ok = True
+    sites = sorted(off for off, name in rel.items() if name.startswith("??0btCapsuleShape@@"))
+    assert sites
+    targets = set()
+    for off in sites:
+        pat = code[off - 13: off]
+        assert pat[-1] == 0xE8
+        for m in re.finditer(re.escape(pat), pe.b):
+            targets.add(pe.call_target(m.start() + 12))
+    assert len(targets) == 1, targets
+    ins = _disasm(pe, pe.base + targets.pop())
+    text = [(x[1], x[2]) for x in ins]
+    call = next(int(x[2], 16) for x in ins if x[1] == "call")
+    got = execute(ins, {}, {"%rcx": "this"}, {"%xmm1": ("in", "radius", 0), "%xmm2": ("in", "height", 0)}, {}, pe.bytes_at_va,
+                  hooks={call: lambda reg, mem, sp, out: None})
+    r, h = E(("in", "radius", 0)), E(("in", "height", 0))
+    want = {("this", 0x30 // 4): r.t, ("this", 0x34 // 4): (h * 0.5).t, ("this", 0x38 // 4): r.t, ("this", 0x40 // 4): r.t}
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    good = not bad and ("movl", "$0x1,0x50(%rbx)") in text
+    print("btCapsuleShape(radius, height): implicit = (radius, 0.5f * height, radius), margin = radius, upAxis = 1: "
+          + ("as restated" if good else f"MISMATCH {bad}"))
+    ok &= good
+    lea = next(x[0] for x in ins if x[1] == "lea" and "(%rip)" in x[2])
+    raw = pe.bytes_at_va(lea, 7)
+    vtable = lea + 7 + struct.unpack("<i", raw[3:])[0]
+    ga = _disasm(pe, _resolve(pe, struct.unpack("<Q", pe.bytes_at_va(vtable + 8, 8))[0]))
+    assert ga[2][1:] == ("movslq", "0x50(%rcx),%r11")               # r11 = m_upAxis;  rax = (r11 + 2) % 3 by the 0x55555556 multiply
+    fixed = {"0x30(%rcx,%rax,4),%xmm0": "0x30(%rcx),%xmm0", "0x30(%rcx,%r11,4),%xmm0": "0x34(%rcx),%xmm0",
+             "%xmm0,(%rsp,%r11,4)": "%xmm0,0x4(%rsp)"}
+    n_fixed = sum(x[2] in fixed for x in ga)
+    ga = [(pc, mn, fixed.get(ops, ops)) for pc, mn, ops in ga]
+    k_mod = next((k for k, x in enumerate(ga) if x[2].endswith(",%xmm9") and x[1] != "movaps"), len(ga))
+    lanes = {"$0xaa": "0x38(%rbx)", "$0x55": "0x34(%rbx)"}
+    for k, (pc, mn, ops) in enumerate(ga):
+        if mn == "shufps":
+            imm8, src, dst = ops.split(",")
+            assert src == "%xmm9" and k < k_mod and any(g[1:] == ("movaps", f"%xmm9,{dst}") for g in ga[k - 4:k]), (hex(pc), ops)
+            ga[k] = (pc, "movss", f"{lanes[imm8]},{dst}")
+    got = execute(ga, {"%rcx": "this", "%rdx": "t"}, {"%r8": "mn", "%r9": "mx"}, {}, {}, pe.bytes_at_va)
+    rad, hh = E(("in", "this", 0x30 // 4)), E(("in", "this", 0x34 // 4))
+    half = [rad, rad + hh, rad]
+    t = lambda r_, c: E(("abs", ("in", "t", 4 * r_ + c)))
+    ext = [(t(r_, 0) * half[0] + t(r_, 1) * half[1]) + t(r_, 2) * half[2] for r_ in range(3)]
+    want = {}
+    for r_ in range(3):
+        want[("mn", r_)] = (E(("in", "t", 12 + r_)) - ext[r_]).t
+        want[("mx", r_)] = (E(("in", "t", 12 + r_)) + ext[r_]).t
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    good = not bad and n_fixed == 3
+    print(f"btCapsuleShape::getAabb (up axis 1): half = (r, r + halfHeight, r), no margin added, same extent sum as the box: "
+          f"{6 - len(bad)} of 6 identical" + ("" if good else f"  <-- MISMATCH {bad}"))
+    for k in bad[:2]:
+        print("   compiled   :", norm(got.get(k, ("missing",))))
+        print("   restatement:", norm(want[k]))
+    ok &= good
+    return ok
+
+
+def check_update_single_aabb(pe):
+    """btCollisionWorld::updateSingleAabb: the function that reads gContactBreakingThreshold (a .data float, 0.02f) and, within
+    0x300 bytes after it, the 1e12f of its "AABB too large" test."""
+    ok = True
+    rd_va, _, rd_raw, rd_rs = pe.secs[1]
+    big = [rd_va + m.start() for m in re.finditer(re.escape(struct.pack("<f", 1e12)), pe.b[rd_raw: rd_raw + rd_rs]) if m.start() % 4 == 0]
+    big_refs = sorted(r for c in big for r in _rip_refs(pe, c))
+    dsec = next(s for s in pe.secs if pe.b[s[2]: s[2] + s[3]].find(struct.pack("<f", 0.02)) != -1 and s not in pe.secs[:2])
+    thr = [dsec[0] + m.start() for m in re.finditer(re.escape(struct.pack("<f", 0.02)), pe.b[dsec[2]: dsec[2] + dsec[3]]) if m.start() % 4 == 0]
+    cand = sorted({_function_start(pe, r) for c in thr for r in _rip_refs(pe, c)
+                   if any(0 < b - r < 0x300 for b in big_refs)})
+    assert len(cand) == 1, [hex(c) for c in cand]
+    fn_va = pe.base + cand[0]
+    ins = _disasm(pe, fn_va, 0x300)
+    text = [(x[1], x[2]) for x in ins]
+    virt = [k for k, x in enumerate(ins) if x[1] == "call" and x[2] == "*0x8(%rax)"]     # shape->getAabb
+    assert len(virt) == 2, virt
+    # conditions of the second (interpolation transform) box, in order
+    k0 = text.index(("cmpb", "$0x0,0x40(%rdi)"))                    # m_dispatchInfo.m_useContinuous
+    k1 = text.index(("cmpl", "$0x2,0x118(%rbx)"))                   # getInternalType() == CO_RIGID_BODY
+    k2 = text.index(("testb", "$0x3,0xe8(%rbx)"))                   # !isStaticOrKinematicObject()
+    good = virt[0] < k0 < k1 < k2 < virt[1] and ins[k1 + 1][1] == "jne" and ins[k2 + 1][1] == "jne"
+    good &= ("add", "$0x10,%rdx") in text[:virt[0]] and ("lea", "0x50(%rbx),%rdx") in text[k2:virt[1]]
+    print("updateSingleAabb: getAabb(worldTransform [+0x10]); second box from the interpolation transform [+0x50] iff useContinuous "
+          "&& CO_RIGID_BODY && !(flags & (STATIC|KINEMATIC)): " + ("as restated" if good else "MISMATCH"))
+    ok &= good
+    ins2 = [(pc, mn, "0xffff08") if (mn, ops) == ("call", "*0x8(%rax)") else (pc, mn, ops) for pc, mn, ops in ins]
+    noop = {0xFFFF08: lambda reg, mem, sp, out: None}
+    kje = next(k for k, x in enumerate(ins) if k > virt[0] and x[1] == "je")
+    got = execute(ins2[:kje], {}, {"%rbp": "frame"}, {}, {}, pe.bytes_at_va, hooks=noop)
+    thr_c = C(0.02)
+    o = lambda d: E(("opaque", f"%rbp{d:#x}"))
+    mins, maxs = (-0x19, -0x15, -0x11), (-0x29, -0x25, -0x21)
+    want = {("frame", d // 4): (o(d) - thr_c).t for d in mins}
+    want.update({("frame", d // 4): (o(d) + thr_c).t for d in maxs})
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    print(f"updateSingleAabb: min -= gContactBreakingThreshold (0.02f), max += it: {6 - len(bad)} of 6 identical"
+          + ("" if not bad else f"  <-- MISMATCH {bad}"))
+    ok &= not bad
+    # the union: every comiss / jae / store triple is setMin on the min lanes and setMax on the max lanes
+    kend = next(k for k, x in enumerate(ins) if k > virt[1] and x[1] == "testb")
+    seg = ins2[k2 + 2: kend]
+    cmps = [x for x in seg if x[1] == "comiss" and "(" not in x[2]]
+    reg0 = {"%xmm6": thr_c.t}
+    mem0 = {}
+    got = execute(seg, {}, {"%rbp": "frame"}, reg0, mem0, pe.bytes_at_va, hooks=noop,
+                  probes={x[0]: x[2].split(",") for x in cmps})
+    mins2, maxs2 = (-0x9, -0x5, -0x1), (0x7, 0xb, 0xf)
+    want = {("frame", a // 4): (o(b) - thr_c).t for a, b in zip(mins, mins2)}
+    want.update({("frame", a // 4): (o(b) + thr_c).t for a, b in zip(maxs, maxs2)})
+    bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
+    dirs = 0
+    for x in cmps:
+        a, b = x[2].split(",")
+        ta, tb = norm(got[("probe", x[0], a)]), norm(got[("probe", x[0], b)])
+        # comiss a,b ; jae skip : the store happens iff b < a.  setMin: b is the new (interpolated) minimum, a the current one;
+        # setMax: a is the new maximum, b the current one.
+        is_min = any(tb == norm((o(m) - thr_c).t) for m in mins2) and "opaque" in str(ta)
+        is_max = any(ta == norm((o(m) + thr_c).t) for m in maxs2) and "opaque" in str(tb)
+        dirs += is_min or is_max
+    good = not bad and dirs == 6 and all(ins[k + 1][1] == "jae" or ins[k + 2][1] == "jae" or ins[k + 3][1] == "jae" or ins[k + 4][1] == "jae"
+                                         for k, x in enumerate(ins) if x in cmps)
+    print(f"updateSingleAabb: second box also -/+ 0.02f, then setMin / setMax lane by lane: {6 - len(bad)} of 6 stores, {dirs} of 6 comparisons"
+          + ("" if good else "  <-- MISMATCH"))
+    ok &= good
+    kbig = next(k for k, x in enumerate(ins) if k > kend and x[1] == "comiss")
+    lim = struct.unpack("<f", pe.bytes_at_va(ins[kbig + 1][0] + int(re.match(r"(-?0x[0-9a-f]+)\(%rip\)", ins[kbig][2]).group(1), 16), 4))[0]
+    print(f"  (found at VA {fn_va:#x}; a non-static body whose box has squared diagonal >= {lim:g} is set to DISABLE_SIMULATION instead "
+          "of being fed to the broadphase: not restated, the extent of such a body is 1e6 units)")
+    return ok
+
+
 def main():
     ok = True
     # 1. ToBtQuaternion(euler): result through rcx (hidden return pointer), euler through rdx
@@ -371,6 +674,7 @@ def main():
     ok &= not bad
     ok &= check_integrate_transform()
     ok &= check_external_force_impulse()
+    ok &= check_box_aabb()
     print("RESULT:", "the restatement has the compiled code's operation order" if ok else "MISMATCH")
     return 0 if ok else 1
 

@@ -265,6 +265,8 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
     def const_of(raw):
         if raw[:4] == b"\x00\x00\x00\x80":
             return ("signmask",)
+        if raw[:4] == b"\xff\xff\xff\x7f":
+            return ("absmask",)
         return ("const", struct.unpack("<f", raw[:4])[0])
 
     def load(op, pc_next):
@@ -317,20 +319,24 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             sp -= int(parts[0][1:], 16)
         elif mn == "push" or (mn == "rex" and ops.startswith("push")):
             sp -= 8
-        elif mn == "mov" and len(parts) == 2 and parts[0] in alias and parts[1].startswith("%r") and not addr(parts[1]):
-            alias[parts[1]] = alias[parts[0]]                 # mov %rcx,%rbx: another name for a result pointer
-        elif mn == "mov" and len(parts) == 2 and parts[0] in in_bases and parts[1].startswith("%r") and not addr(parts[1]):
-            in_bases = dict(in_bases)
-            in_bases[parts[1]] = in_bases[parts[0]]           # ... or for an input pointer
+        elif (mn == "mov" and len(parts) == 2 and (parts[0] in alias or parts[0] in in_bases) and parts[1].startswith("%r")
+              and not addr(parts[1])):
+            if parts[0] in alias:
+                alias[parts[1]] = alias[parts[0]]             # mov %rcx,%rbx: another name for a result pointer
+            if parts[0] in in_bases:
+                in_bases = dict(in_bases)
+                in_bases[parts[1]] = in_bases[parts[0]]       # ... or for an input pointer (an object can be both)
         elif mn == "xor" and parts[0] == parts[1]:
             gpr[parts[0]] = 0
         elif mn == "mov" and len(parts) == 2 and parts[0].startswith("$") and parts[1].startswith("%e"):
             gpr[parts[1]] = int(parts[0][1:], 16)
         elif mn in ("mov", "movl") and len(parts) == 2 and addr(parts[1]) and addr(parts[1])[0] in alias:
             d = addr(parts[1])[1]                             # integer store of a float constant into the result
-            bits = gpr[parts[0]] if parts[0].startswith("%") else int(parts[0][1:], 16)
-            out[d // 4] = ("const", struct.unpack("<f", struct.pack("<I", bits))[0])
-        elif mn in ("mov", "lea", "pop", "ret", "add", "xor", "movslq", "mul", "shr", "inc", "seta", "cmova", "nopw"):
+            bits = gpr.get(parts[0]) if parts[0].startswith("%") else int(parts[0][1:], 16)
+            if isinstance(bits, int):                         # (a pointer store, e.g. the vtable, is not a float result)
+                key = d // 4 if not isinstance(out_base, dict) else (alias[addr(parts[1])[0]], d // 4)
+                out[key] = ("const", struct.unpack("<f", struct.pack("<I", bits & 0xFFFFFFFF))[0])
+        elif mn in ("mov", "lea", "pop", "ret", "add", "xor", "movslq", "mul", "shr", "inc", "seta", "cmova", "nopw", "nop", "nopl", "setbe", "movq", "cmpb", "testb", "movzbl", "imul", "sub"):
             pass                                              # integer bookkeeping: not modelled
         elif mn in ("shufps", "movups", "movl"):
             pass                                              # vector assembly / packed copies: lanes are not modelled
@@ -379,9 +385,11 @@ def execute(ins, in_bases, out_base, reg0=None, stack_args=None, const_reader=No
             for v in ("%xmm1", "%xmm2", "%xmm3", "%xmm4", "%xmm5"):
                 reg[v] = ("opaque", f"clobbered {v} @ {pc:#x}")
         elif mn == "call" and hooks and int(parts[0], 16) in hooks:
-            hooks[int(parts[0], 16)](reg, mem, sp, out)
+            ret = hooks[int(parts[0], 16)](reg, mem, sp, out)
             for v in ("%xmm0", "%xmm1", "%xmm2", "%xmm3", "%xmm4", "%xmm5"):
                 reg[v] = ("opaque", f"clobbered {v} @ {pc:#x}")
+            if ret is not None:                               # a hook may model the callee's float result
+                reg["%xmm0"] = ret
         elif mn == "call":
             tgt = int(parts[0], 16)
             if calls and tgt in calls:

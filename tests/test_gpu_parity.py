@@ -11,7 +11,7 @@ import banggameengine_amd as B
 from banggameengine_amd import synth
 from oracle import pyoracle as po
 
-from helpers import DT, assert_bits_equal, build_oracle, matrix_rel_err, parent_i32, run_oracle, run_world
+from helpers import DT, assert_bits_equal, bits, build_oracle, matrix_rel_err, parent_i32, run_oracle, run_world
 
 pytestmark = pytest.mark.gpu
 
@@ -281,6 +281,56 @@ def test_spinning_bodies_match_golden_and_oracle():
         run_world(w.load(wl), wl, 12, angvel=angvel)
         assert_bits_equal(w.download_bodies()["quat"], ref.bulk_bodies()["quat"], "quaternion (clamped / tiny spin)")
         assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world (clamped / tiny spin)")
+
+
+@pytest.mark.parametrize("variant", ["fused", "normal", "split", "aabbs"])
+def test_bullet_basis_scheme_under_gravity_in_hierarchies(variant):
+    """BGE_TICK_BULLET_BASIS (Bullet's basis round trip for every Dynamic body) in each kernel variant that carries it:
+    fused physics + transforms, with normal matrices, as separate physics / transform ticks (the adapter's call pattern)
+    and physics-only with AABBs.  Bodies hang in depth-4 chains, fall under gravity, a third of them spin.  Everything is
+    compared with the oracle's kOrientBasis bit for bit; and the mode is NOT the default one's result (the round trip
+    moves a non-spinning body's quaternion by an ulp now and then), which is what DESIGN.md 4.2 bounds."""
+    wl = synth.config("chains4", n=6000)
+    rng = np.random.default_rng(5)
+    dyn = wl.body_type == 1
+    angvel = np.zeros((wl.n, 3), np.float32)
+    spin = dyn & (rng.random(wl.n) < 0.33)
+    angvel[spin] = rng.normal(size=(int(spin.sum()), 3)).astype(np.float32) * np.float32(2.0)
+    ticks = 24
+    ref = build_oracle(wl, orient_mode=po.ORIENT_BASIS, aabbs=variant == "aabbs")
+    run_oracle(ref, wl, ticks, angvel=angvel)
+    ideal = run_oracle(build_oracle(wl), wl, ticks, angvel=angvel)
+    with B.World() as w:
+        w.load(wl)
+        if variant == "split":
+            for k in range(ticks):
+                w.tick(dt=DT, flags=B.TICK_PHYSICS | B.TICK_BULLET_BASIS)
+                w.tick(flags=B.TICK_TRANSFORMS)
+                if k == 0:
+                    w.set_velocities(wl.vel, angvel)
+        else:
+            flags = {"fused": B.TICK_ALL, "normal": B.TICK_ALL | B.TICK_NORMAL_MATRICES, "aabbs": B.TICK_ALL | B.TICK_AABBS}[variant]
+            run_world(w, wl, ticks, flags=flags | B.TICK_BULLET_BASIS, angvel=angvel)
+        with pytest.raises(B.BgeError):
+            w.tick(flags=B.TICK_TRANSFORMS | B.TICK_BULLET_BASIS)     # selects how PHYSICS carries orientations
+        pos, euler = w.download_pose()
+        bodies = w.download_bodies()
+        world = w.download_world()
+        normal = w.download_normal() if variant == "normal" else None
+    rb = ref.bulk_bodies()
+    ex = rb["exists"]
+    assert_bits_equal(bodies["quat"][ex], rb["quat"][ex], "quaternion")
+    assert_bits_equal(pos, ref.bulk_pose()[0], "position")
+    assert_bits_equal(euler, ref.bulk_pose()[1], "rotationEuler")
+    assert_bits_equal(world, ref.bulk_world()[0], "world")
+    if variant == "aabbs":
+        assert_bits_equal(bodies["aabb"][ex], rb["aabb"][ex], "aabb")
+    if normal is not None:
+        assert_bits_equal(normal, po.normal_matrices(ref.bulk_world()[0]), "normal matrix")
+    still = dyn & ~spin
+    iq = ideal.bulk_bodies()["quat"]
+    assert (bits(bodies["quat"][still]) != bits(iq[still])).any()
+    assert matrix_rel_err(world, ideal.bulk_world()[0]) < 1e-5
 
 
 def test_demo_scene_fixture():
@@ -567,10 +617,16 @@ def test_long_run_stays_bit_identical():
     assert_bits_equal(got[0], ref.bulk_world()[0], "world")
 
 
-def test_free_bodies_fall_asleep_like_the_oracle():
+@pytest.mark.parametrize("basis", [False, True])
+def test_free_bodies_fall_asleep_like_the_oracle(basis):
     """Bullet's deactivation of free bodies (§8(f) rank 4, the sleeping part): zero gravity, a mix of slow, fast and
     slowly spinning bodies (plus statics / kinematics / plain transforms), compared every few ticks across the 2 s limit:
-    activation state, deactivation timer, pose, velocities and world matrices, all bit for bit."""
+    activation state, deactivation timer, pose, velocities and world matrices, all bit for bit.  Once with the default
+    orientation state and once with BGE_TICK_BULLET_BASIS against the oracle's kOrientBasis — Bullet's own scheme, where
+    every Dynamic body's basis takes the getRotation / integrateTransform / setRotation round trip each step and its
+    rotationEuler is rewritten from it, spinning or not."""
+    mode = po.ORIENT_BASIS if basis else po.ORIENT_IDEAL
+    extra = B.TICK_BULLET_BASIS if basis else 0
     n = 3000
     wl = synth.config("flat10k", n=n)
     rng = np.random.default_rng(11)
@@ -586,15 +642,15 @@ def test_free_bodies_fall_asleep_like_the_oracle():
     angvel[wl.body_type != 1] = 0
     g0 = (0.0, 0.0, 0.0)
 
-    ref = build_oracle(wl)
-    ref.SetPhysicsOptions(0.0, po.ORIENT_IDEAL, True)
+    ref = build_oracle(wl, orient_mode=mode)
+    ref.SetPhysicsOptions(0.0, mode, True)
     with B.World() as w:
         w.load(wl)
 
         def frame(k):
             ref.PhysicsSystemUpdate(DT)
             ref.TransformSystemUpdate()
-            w.tick(dt=DT, gravity=g0, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+            w.tick(dt=DT, gravity=g0, flags=B.TICK_ALL | B.TICK_BROADPHASE | extra)
 
         def compare(k):
             st, tm = w.download_activation()
@@ -640,18 +696,18 @@ def test_free_bodies_fall_asleep_like_the_oracle():
         w.upload_bodies(np.array([1], np.uint8), first=c)
         ref.MarkBodyDirty(c + 1)
         g = (0.0, -9.81, 0.0)
-        ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, True)
+        ref.SetPhysicsOptions(-9.81, mode, True)
         for k in range(262, 266):
             ref.PhysicsSystemUpdate(DT)
             ref.TransformSystemUpdate()
-            w.tick(dt=DT, gravity=g, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+            w.tick(dt=DT, gravity=g, flags=B.TICK_ALL | B.TICK_BROADPHASE | extra)
             st = compare(k)
         assert st[a] == 2 and st[b] == 2 and st[c] == 1
 
         # sleeping switched off (gDeactivationTime == 0): nothing new falls asleep, timers keep running
         w.set_sleeping(0.8, 1.0, 0.0)
         w.upload_bodies(wl.body_type)
-        w.tick(dt=DT, gravity=g0, ticks=300)
+        w.tick(dt=DT, gravity=g0, ticks=300, flags=B.TICK_ALL | extra)
         st, tm = w.download_activation()
         assert not (st[dyn] == 2).any() and tm[dyn].max() > 2.0
 
