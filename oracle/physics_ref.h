@@ -54,7 +54,8 @@
 // PARITY STATUS: "parity unpinned" in the strict sense (Bullet absent; the reference holds no fixtures).  The arithmetic
 // of every step below — pose conversions, integrateTransform, gravity force and impulse, shape margins, getAabb,
 // updateSingleAabb — is checked against the reference's compiled code by oracle/tools/check_bullet_order.py; the
-// deactivation rule was read from the same disassembly; the ORDER of the steps is from Bullet's published code.
+// deactivation rule was read from the same disassembly; the ORDER of the steps is checked there too (check_step_order);
+// only buildIslands' WANTS_DEACTIVATION -> ISLAND_SLEEPING for a lone body is from Bullet's published code alone.
 #pragma once
 
 #include <algorithm>

@@ -619,6 +619,178 @@ def check_update_single_aabb(pe):
     return ok
 
 
+def _find_integrate_transform(pe):
+    """VA of btTransformUtil::integrateTransform: the only code referencing the float 1/48 (see check_integrate_transform)."""
+    rd_va, _, rd_raw, rd_rs = pe.secs[1]
+    i = pe.b.find(struct.pack("<I", 0x3CAAAAAB), rd_raw, rd_raw + rd_rs)
+    refs = _rip_refs(pe, rd_va + i - rd_raw)
+    assert len(refs) == 1, refs
+    return pe.base + _function_start(pe, refs[0])
+
+
+def _find_by_data_float(pe, value, also=None):
+    """Functions that read a float of this value from an initialised-data section other than .rdata (Bullet's tunable
+    globals: gDeactivationTime, gContactBreakingThreshold ...)."""
+    out = set()
+    for sec in pe.secs[2:]:
+        blob = pe.b[sec[2]: sec[2] + sec[3]]
+        for m in re.finditer(re.escape(struct.pack("<f", value)), blob):
+            if m.start() % 4 == 0:
+                out |= {pe.base + _function_start(pe, r) for r in _rip_refs(pe, sec[0] + m.start())}
+    return sorted(out)
+
+
+def check_step_order():
+    """The ORDER of a simulation step.  btDiscreteDynamicsWorld's virtual functions are identified by what they reach:
+      updateActivationState   the function reading gDeactivationTime (.data float 2.0) that walks m_nonStaticRigidBodies
+      its vtable              the .rdata table holding that function's (thunk) address; base = nearest address below it that
+                              code loads with lea (the constructor)
+      internalSingleStepSimulation / stepSimulation
+                              the vtable members that call updateActivationState's slot / internalSingleStepSimulation's slot
+    and every virtual call they make through the same vtable is resolved and classified by the already-pinned functions it
+    reaches within three calls: integrateTransform, updateSingleAabb, updateActivationState; applyGravity / clearForces by
+    their accesses to m_gravity (+0x1f0) / m_totalForce (+0x220)."""
+    from check_bx_order import EXE, Pe
+    pe = Pe(EXE)
+    ok = True
+    integ = _find_integrate_transform(pe)
+    cands = [f for f in _find_by_data_float(pe, 2.0) if any("0x174(" in x[2] for x in _disasm(pe, f, 0x80, multi_ret=True))]
+    uas = [f for f in cands if sum(x[1] == "comiss" for x in _disasm(pe, f, 0x400)) >= 3]
+    assert len(uas) == 1, [hex(c) for c in cands]
+    uas = uas[0]
+    # its vtable slot: the 8-byte address of the function or of its incremental-link thunk, inside .rdata
+    va, _, raw, rs = pe.secs[0]
+    text = pe.b[raw: raw + rs]
+    thunks = [pe.base + va + m.start() for m in re.finditer(b"\xe9", text)
+              if pe.base + va + m.start() + 5 + struct.unpack_from("<i", text, m.start() + 1)[0] == uas and m.start() + 5 <= len(text)]
+    entries = []
+    for t in [uas] + thunks:
+        rd_va, _, rd_raw, rd_rs = pe.secs[1]
+        entries += [pe.base + rd_va + m.start() for m in re.finditer(re.escape(struct.pack("<Q", t)), pe.b[rd_raw: rd_raw + rd_rs])
+                    if m.start() % 8 == 0]
+    assert len(entries) == 1, [hex(e) for e in entries]
+    entry = entries[0]
+    vtable = next(b for b in range(entry, entry - 0x400, -8) if _rip_refs(pe, b - pe.base))
+    slot_uas = entry - vtable
+    members = {}
+    k = 0
+    while True:                                                      # the table ends where the entries stop being code addresses
+        ptr = struct.unpack("<Q", pe.bytes_at_va(vtable + 8 * k, 8))[0]
+        if not (pe.base + va <= ptr < pe.base + va + rs):
+            break
+        members[8 * k] = _resolve(pe, ptr)
+        k += 1
+
+    def calls_of(f, size=0x500):
+        """Calls of a function: ('d', target) direct, ('v', slot) through THIS object's vtable — `mov (%reg),%rax` with reg a
+        copy of the entry %rcx, then `call *slot(%rax)` —, ('?', text) anything else (other objects' virtuals, callbacks)."""
+        out = []
+        this = {"%rcx"}
+        vt_reg_ok = False
+        for n_, x in enumerate(_disasm(pe, f, size)):
+            parts = x[2].split(",")
+            if x[1] == "mov" and len(parts) == 2:
+                if parts[0] in this and re.fullmatch(r"%r\w+", parts[1]) and n_ < 24:
+                    this.add(parts[1])
+                elif parts[1] in this and parts[0] not in this:
+                    this.discard(parts[1])                          # the copy is overwritten (rcx itself is an argument register)
+                if parts[1] == "%rax":
+                    m0 = re.fullmatch(r"\((%r\w+)\)", parts[0])
+                    vt_reg_ok = bool(m0) and m0.group(1) in this
+            if x[1] != "call":
+                continue
+            m = re.match(r"\*(0x[0-9a-f]+)\(%rax\)$", x[2])
+            if m and vt_reg_ok and int(m.group(1), 16) in members:
+                out.append(("v", int(m.group(1), 16)))
+            elif x[2].startswith("0x"):
+                out.append(("d", _resolve(pe, int(x[2], 16))))
+            else:
+                out.append(("?", x[2]))
+            this.discard("%rcx")                                    # volatile across the call
+        return out
+
+    def reaches(f, goal, depth=3, seen=None):
+        seen = seen if seen is not None else set()
+        if f == goal:
+            return True
+        if depth == 0 or f in seen:
+            return False
+        seen.add(f)
+        for kind, t in calls_of(f):
+            t = members[t] if kind == "v" else t
+            if kind != "?" and reaches(t, goal, depth - 1, seen):
+                return True
+        return False
+
+    def touches(f, needle, depth=2):
+        ins = _disasm(pe, f, 0x300)
+        if any(needle in x[2] for x in ins):
+            return True
+        return depth > 0 and any(touches(t, needle, depth - 1) for kind, t in calls_of(f, 0x300) if kind == "d")
+
+    usa = _find_by_data_float(pe, 0.02)
+    rd_va, _, rd_raw, rd_rs = pe.secs[1]
+    big = [rd_va + m.start() for m in re.finditer(re.escape(struct.pack("<f", 1e12)), pe.b[rd_raw: rd_raw + rd_rs]) if m.start() % 4 == 0]
+    big_fns = {pe.base + _function_start(pe, r) for c in big for r in _rip_refs(pe, c)}
+    usa = [f for f in usa if f in big_fns]
+    assert len(usa) == 1, [hex(f) for f in usa]
+    usa = usa[0]
+
+    def classify(slot):
+        f = members[slot]
+        tags = []
+        if f == uas:
+            tags.append("updateActivationState")
+        if reaches(f, integ):
+            tags.append("integrateTransform")
+        if reaches(f, usa):
+            tags.append("updateSingleAabb")
+        return tags
+
+    internal = [f for s_, f in members.items() if ("v", slot_uas) in calls_of(f) and f != uas]
+    assert len(internal) == 1, [hex(f) for f in internal]
+    internal = internal[0]
+    slot_internal = next(s_ for s_, f in members.items() if f == internal)
+    seq = [(t, classify(t)) for kind, t in calls_of(internal) if kind == "v"]
+    tagged = [(hex(t), tags) for t, tags in seq if tags]
+    # (createPredictiveContacts also reaches integrateTransform: it predicts into a local for its CCD test, a no-op at the
+    #  default ccdMotionThreshold of 0; it sits between the prediction and the collision detection)
+    want = [["integrateTransform"], ["integrateTransform"], ["updateSingleAabb"], ["integrateTransform"], ["updateActivationState"]]
+    good = [tags for _, tags in tagged] == want
+    print(f"internalSingleStepSimulation (vtable {vtable:#x}, slot {slot_internal:#x}), virtual calls in order: "
+          + ", ".join(f"{t:#x}" + (f" [{'+'.join(tags)}]" if tags else "") for t, tags in seq))
+    print("  predictUnconstraintMotion (reaches integrateTransform) -> collision detection (reaches updateSingleAabb) -> ... -> "
+          "integrateTransforms (reaches integrateTransform) -> updateActivationState: " + ("as restated" if good else "MISMATCH"))
+    ok &= good
+    # predictUnconstraintMotion: every body that is not static / kinematic (asleep or not): applyDamping, then
+    # predictIntegratedTransform(timeStep, m_interpolationWorldTransform [+0x50])
+    predict = members[seq[0][0]] if not tagged else members[int(tagged[0][0], 16)]
+    ptext = [(x[1], x[2]) for x in _disasm(pe, predict, 0x200)]
+    good = ("testb", "$0x3,0xe8(%rsi)") in ptext and ("lea", "0x50(%rsi),%r8") in ptext and not any("0xf8(" in o for _, o in ptext)
+    print("predictUnconstraintMotion: for every body without STATIC|KINEMATIC flags, whatever its activation state: predicted "
+          "pose into the interpolation transform (+0x50): " + ("as restated" if good else "MISMATCH"))
+    ok &= good
+    # stepSimulation: ... applyGravity; loop { internalSingleStepSimulation; synchronizeMotionStates }; clearForces
+    step = [f for s_, f in members.items() if ("v", slot_internal) in calls_of(f)]
+    assert len(step) == 1, [hex(f) for f in step]
+    sseq = [t for kind, t in calls_of(step[0]) if kind == "v"]
+    k_int = sseq.index(slot_internal)
+    grav = [t for t in sseq[:k_int] if touches(members[t], "0x1f0(%r") and touches(members[t], "0x220(%r")]
+    gtext = [(x[1], x[2]) for t in grav for x in _disasm(pe, members[t], 0x100)]
+    active_only = ("cmp", "$0x2,%edx") in gtext or ("cmp", "$0x2,%ecx") in gtext
+    # clearForces is called through another register (the last virtual call of the function): zero stores to +0x220..+0x238
+    last = [x for x in _disasm(pe, step[0], 0x500) if x[1] in ("call", "jmp") and x[2].startswith("*0x")][-1]
+    cf = members[int(re.match(r"\*(0x[0-9a-f]+)\(", last[2]).group(1), 16)]
+    ctext = [x[2] for x in _disasm(pe, cf, 0x100)]
+    clears = all(any(o.endswith(f",{off:#x}(%rcx)") for o in ctext) for off in (0x220, 0x228, 0x230, 0x238))
+    good = len(grav) == 1 and active_only and clears
+    print(f"stepSimulation (slot {next(s_ for s_, f in members.items() if f == step[0]):#x}): applyGravity (slot {grav[0] if grav else 0:#x}; "
+          "m_totalForce += m_gravity, only for bodies whose state is not ISLAND_SLEEPING / DISABLE_SIMULATION) before the "
+          f"sub-steps, clearForces (slot {last[2]}) after them: " + ("as restated" if good else "MISMATCH"))
+    ok &= good
+    return ok
+
+
 def main():
     ok = True
     # 1. ToBtQuaternion(euler): result through rcx (hidden return pointer), euler through rdx
@@ -675,6 +847,7 @@ def main():
     ok &= check_integrate_transform()
     ok &= check_external_force_impulse()
     ok &= check_box_aabb()
+    ok &= check_step_order()
     print("RESULT:", "the restatement has the compiled code's operation order" if ok else "MISMATCH")
     return 0 if ok else 1
 
