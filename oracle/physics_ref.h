@@ -55,7 +55,8 @@
 // of every step below — pose conversions, integrateTransform, gravity force and impulse, shape margins, getAabb,
 // updateSingleAabb — is checked against the reference's compiled code by oracle/tools/check_bullet_order.py; the
 // deactivation rule was read from the same disassembly; the ORDER of the steps is checked there too (check_step_order);
-// only buildIslands' WANTS_DEACTIVATION -> ISLAND_SLEEPING for a lone body is from Bullet's published code alone.
+// buildIslands' rule (an island without ACTIVE_TAG / DISABLE_DEACTIVATION bodies falls asleep) was compared as text; that a
+// contact-free body is an island of its own is from Bullet's published code alone.
 #pragma once
 
 #include <algorithm>

@@ -788,6 +788,42 @@ def check_step_order():
           "m_totalForce += m_gravity, only for bodies whose state is not ISLAND_SLEEPING / DISABLE_SIMULATION) before the "
           f"sub-steps, clearForces (slot {last[2]}) after them: " + ("as restated" if good else "MISMATCH"))
     ok &= good
+    # btSimulationIslandManager::buildIslands — where a body that wants to sleep is put to sleep.  setActivationState is the
+    # callee updateActivationState uses three times; buildIslands is its caller that passes both ISLAND_SLEEPING (2) and
+    # WANTS_DEACTIVATION (3) and is reached from the solver step (solveConstraints -> buildAndProcessIslands -> buildIslands).
+    sas = [t for kind, t in calls_of(uas) if kind == "d"]
+    sas = max(set(sas), key=sas.count)
+    stext = [(x[1], x[2]) for x in _disasm(pe, sas, 0x40)]
+    good = stext == [("mov", "0xf8(%rcx),%eax"), ("sub", "$0x4,%eax"), ("cmp", "$0x1,%eax"), ("jbe", stext[3][1]),
+                     ("mov", "%edx,0xf8(%rcx)"), ("ret", "")]
+    print("btCollisionObject::setActivationState: unchanged if the state is DISABLE_DEACTIVATION / DISABLE_SIMULATION (4, 5), else "
+          "stored: " + ("as restated" if good else "MISMATCH"))
+    ok &= good
+    callers = set()
+    for m in re.finditer(b"\xe8", text):
+        if m.start() + 5 <= len(text):
+            t = pe.base + va + m.start() + 5 + struct.unpack_from("<i", text, m.start() + 1)[0]
+            if pe.base + va <= t < pe.base + va + rs and _resolve(pe, t) == sas:
+                callers.add(pe.base + _function_start(pe, va + m.start()))
+    bi = []
+    for f in sorted(callers):
+        t_ = [(x[1], x[2]) for x in _disasm(pe, f, 0x500)]
+        if ("mov", "$0x2,%edx") in t_ and ("mov", "$0x3,%edx") in t_ and any(o.endswith(",0xec(%rdx)") for _, o in t_):
+            bi.append((f, t_))
+    assert len(bi) == 1, [hex(f) for f, _ in bi]
+    f, t_ = bi[0]
+    k_state = t_.index(("mov", "0xf8(%rdx),%eax"))
+    good = (t_[k_state - 2][0] == "cmp" and t_[k_state - 2][1].endswith(",0xec(%rdx)")          # getIslandTag() == islandId
+            and t_[k_state + 1: k_state + 5] == [("cmp", "$0x1,%eax"), ("je", t_[k_state + 2][1]), ("cmp", "$0x4,%eax"),
+                                                 ("je", t_[k_state + 2][1])]                       # ACTIVE_TAG or DISABLE_DEACTIVATION
+            and ("cmpl", "$0x2,0xf8(%rsi)") in t_ and ("movl", "$0x0,0xfc(%rsi)") in t_)
+    solver_slots = [t for t, tags in seq if not tags and reaches(members[t], f, 3)]
+    good &= len(solver_slots) == 1 and seq.index((solver_slots[0], [])) > [tags for _, tags in seq].index(["updateSingleAabb"])
+    print(f"buildIslands (VA {f:#x}, reached from slot {solver_slots[0] if solver_slots else 0:#x} = solveConstraints, after the collision "
+          "detection and before integrateTransforms): an island none of whose bodies is ACTIVE_TAG / DISABLE_DEACTIVATION is set to "
+          "ISLAND_SLEEPING; otherwise its sleeping bodies become WANTS_DEACTIVATION with their timer at 0: "
+          + ("as restated" if good else "MISMATCH"))
+    ok &= good
     return ok
 
 
