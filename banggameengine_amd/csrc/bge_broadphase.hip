@@ -48,6 +48,8 @@ struct GridParams {
 constexpr uint32_t kShards = 64;
 constexpr uint32_t kBoundsBlocks = 2048; // grid of k_bp_bounds: 8 workgroups per CU keep enough loads in flight
 constexpr uint32_t kExtentBins = 1024;
+constexpr uint32_t kHistShards = 16;
+constexpr uint32_t kParamsThreads = 1024; // k_bp_params: 16 waves gather, one decides
 __host__ __device__ inline uint32_t extent_bin(float e) { return (__builtin_bit_cast(uint32_t, e) >> 21) & (kExtentBins - 1u); }
 __host__ __device__ inline float extent_bin_upper(uint32_t b) { return __builtin_bit_cast(float, (b + 1u) << 21); }
 
@@ -66,7 +68,10 @@ struct Accum {
     float part_min[kBoundsBlocks][3];
     float part_max[kBoundsBlocks][3];
     uint32_t part_count[kBoundsBlocks];
-    uint32_t extent_hist[kExtentBins]; // bodies per extent bin (bin = float exponent + 2 mantissa bits)
+    // bodies per extent bin (bin = float exponent + 2 mantissa bits), in kHistShards copies: the bodies of a scene share a
+    // few sizes, so every workgroup of k_bp_bounds ends with an atomic on the SAME bin — 2048 of them on one word cost
+    // ~20 us of the kernel's 41 (one word sustains ~10^8 atomics/s); k_bp_params adds the copies up
+    uint32_t extent_hist[kHistShards][kExtentBins];
     uint32_t scan_ticket;              // tile tickets of k_scan_lookback (dispatch order)
     uint32_t scan_error;               // a look-back gave up (never observed; keeps a logic error from hanging the GPU)
 };
@@ -78,17 +83,11 @@ __device__ __forceinline__ uint32_t f2ord(float f)
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ float ord2f(uint32_t o)
-{
-    const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    return __uint_as_float(u);
-}
-
 __device__ __forceinline__ bool is_body(uint32_t f) { return (f & kValid) && (f & kTypeMask) != 0; }
 
 __global__ void k_bp_reset(Accum* acc)
 {
-    for (uint32_t b = threadIdx.x; b < kExtentBins; b += blockDim.x) acc->extent_hist[b] = 0;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < kHistShards * kExtentBins; b += gridDim.x * blockDim.x) (&acc->extent_hist[0][0])[b] = 0;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int a = 0; a < 3; ++a) {
             acc->min_bits[a] = 0xffffffffu;
@@ -119,39 +118,54 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
     // uniform trip count per wave (the aggregation below ballots across all 64 lanes)
     const uint64_t first = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     const uint64_t rounds = (n_slots + stride - 1) / stride;
-    for (uint64_t r = 0; r < rounds; ++r) {
-        const uint64_t s = first + r * stride;
-        uint32_t my_bin = 0;
-        bool have_bin = false;
-        // flags and AABB are loaded together (the AABB of a slot without a body is just not used): one memory round trip
-        // per body instead of two dependent ones
-        const uint64_t sc = s < n_slots ? s : 0;
-        const uint32_t fl = flags[sc];
-        const float2* b = reinterpret_cast<const float2*>(aabb + 6 * sc);
-        const float2 b0 = b[0], b1 = b[1], b2 = b[2]; // min.x min.y | min.z max.x | max.y max.z
-        if (s < n_slots && is_body(fl)) {
-        mn[0] = fminf(mn[0], b0.x);
-        mn[1] = fminf(mn[1], b0.y);
-        mn[2] = fminf(mn[2], b1.x);
-        mx[0] = fmaxf(mx[0], b1.y);
-        mx[1] = fmaxf(mx[1], b2.x);
-        mx[2] = fmaxf(mx[2], b2.y);
-        const float e = fmaxf(fmaxf(b1.y - b0.x, b2.x - b0.y), b2.y - b1.x);
-        my_bin = (e > 0.0f && e < INFINITY) ? extent_bin(e) : 0u;
-        have_bin = true;
-        cnt += 1;
+    // kBoundsUnroll rounds at a time: all their loads are issued before the first histogram update, whose ballots and LDS
+    // atomics the compiler will not move loads across (measured at 4 M bodies: 44 us one round at a time)
+    constexpr int kBoundsUnroll = 4;
+    for (uint64_t r0 = 0; r0 < rounds; r0 += kBoundsUnroll) {
+        uint32_t fl[kBoundsUnroll];
+        float2 b0[kBoundsUnroll], b1[kBoundsUnroll], b2[kBoundsUnroll];
+        bool live[kBoundsUnroll];
+#pragma unroll
+        for (int u = 0; u < kBoundsUnroll; ++u) {
+            const uint64_t s = first + (r0 + u) * stride;
+            live[u] = r0 + u < rounds && s < n_slots;
+            // flags and AABB are loaded together (the AABB of a slot without a body is just not used): one memory round
+            // trip per body instead of two dependent ones
+            const uint64_t sc = live[u] ? s : 0;
+            fl[u] = flags[sc];
+            const float2* b = reinterpret_cast<const float2*>(aabb + 6 * sc);
+            b0[u] = b[0]; // min.x min.y
+            b1[u] = b[1]; // min.z max.x
+            b2[u] = b[2]; // max.y max.z
         }
-        // Histogram update, wave-aggregated: bodies of similar size share a bin, and 64 lanes hammering one LDS
-        // word serialise.  Each round the first pending lane's bin is broadcast, all lanes with that bin retire
-        // together and their leader adds the population count (usually one or two rounds).
-        while (true) {
-            const unsigned long long pending = __ballot(have_bin);
-            if (pending == 0) break;
-            const int leader = __ffsll(static_cast<long long>(pending)) - 1;
-            const uint32_t lead_bin = __shfl(my_bin, leader, 64);
-            const unsigned long long same = __ballot(have_bin && my_bin == lead_bin);
-            if (static_cast<int>(threadIdx.x & 63u) == leader) atomicAdd(&hist[lead_bin], static_cast<uint32_t>(__popcll(same)));
-            if (have_bin && my_bin == lead_bin) have_bin = false;
+#pragma unroll
+        for (int u = 0; u < kBoundsUnroll; ++u) {
+            uint32_t my_bin = 0;
+            bool have_bin = false;
+            if (live[u] && is_body(fl[u])) {
+                mn[0] = fminf(mn[0], b0[u].x);
+                mn[1] = fminf(mn[1], b0[u].y);
+                mn[2] = fminf(mn[2], b1[u].x);
+                mx[0] = fmaxf(mx[0], b1[u].y);
+                mx[1] = fmaxf(mx[1], b2[u].x);
+                mx[2] = fmaxf(mx[2], b2[u].y);
+                const float e = fmaxf(fmaxf(b1[u].y - b0[u].x, b2[u].x - b0[u].y), b2[u].y - b1[u].x);
+                my_bin = (e > 0.0f && e < INFINITY) ? extent_bin(e) : 0u;
+                have_bin = true;
+                cnt += 1;
+            }
+            // Histogram update, wave-aggregated: bodies of similar size share a bin, and 64 lanes hammering one LDS
+            // word serialise.  Each round the first pending lane's bin is broadcast, all lanes with that bin retire
+            // together and their leader adds the population count (usually one or two rounds).
+            while (true) {
+                const unsigned long long pending = __ballot(have_bin);
+                if (pending == 0) break;
+                const int leader = __ffsll(static_cast<long long>(pending)) - 1;
+                const uint32_t lead_bin = __shfl(my_bin, leader, 64);
+                const unsigned long long same = __ballot(have_bin && my_bin == lead_bin);
+                if (static_cast<int>(threadIdx.x & 63u) == leader) atomicAdd(&hist[lead_bin], static_cast<uint32_t>(__popcll(same)));
+                if (have_bin && my_bin == lead_bin) have_bin = false;
+            }
         }
     }
     // wave64 __shfl reductions, then across the 4 waves through LDS, then one set of atomics per workgroup
@@ -184,8 +198,17 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
     }
     for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) {
         const uint32_t h = hist[k];
-        if (h) atomicAdd(&acc->extent_hist[k], h);
+        if (h) atomicAdd(&acc->extent_hist[blockIdx.x % kHistShards][k], h);
     }
+}
+
+// LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the
+// compiler from moving them across the hand-over point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // One wave: pick the cell size that minimises the expected number of AABB tests,
@@ -193,20 +216,31 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
 //            + n_large(c) * n                        (k_bp_large: every large body against everything)
 // over the histogram's bin edges c (a body is "small" when its widest side is < c); then grow the cell
 // until the padded grid fits the table.
-__global__ void __launch_bounds__(64) k_bp_params(Accum* acc, uint32_t max_cells, uint32_t n_bounds_blocks)
+__global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32_t max_cells, uint32_t n_bounds_blocks)
 {
+    constexpr uint32_t kWaves = kParamsThreads / 64;
     __shared__ uint32_t below[kExtentBins + 1]; // exclusive prefix: bodies in bins < b
-    const uint32_t lane = threadIdx.x;
+    __shared__ float red[kWaves][6];
+    __shared__ uint32_t red_cnt[kWaves];
+    const uint32_t lane = threadIdx.x & 63u;
     {
-        // reduce the per-workgroup partial bounds (wave64 __shfl reductions)
+        // Phase 1, all 16 waves: reduce the per-workgroup partial bounds and add up the histogram's copies.  Both are chains
+        // of dependent-latency loads (~1.5 us a round trip): one wave alone spent 15 us here, 1024 threads need two rounds
+        // for the partials and one for the histogram (every thread one bin, its 16 copies in flight together).
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         uint32_t cnt = 0;
-        for (uint32_t b = lane; b < n_bounds_blocks; b += 64) {
+        for (uint32_t b = threadIdx.x; b < n_bounds_blocks; b += kParamsThreads) {
             for (int a = 0; a < 3; ++a) {
                 mn[a] = fminf(mn[a], acc->part_min[b][a]);
                 mx[a] = fmaxf(mx[a], acc->part_max[b][a]);
             }
             cnt += acc->part_count[b];
+        }
+        for (uint32_t b = threadIdx.x; b < kExtentBins; b += kParamsThreads) {
+            uint32_t t = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < kHistShards; ++c) t += acc->extent_hist[c][b];
+            below[b] = t; // the totals, for the moment
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -218,12 +252,33 @@ __global__ void __launch_bounds__(64) k_bp_params(Accum* acc, uint32_t max_cells
         }
         if (lane == 0) {
             for (int a = 0; a < 3; ++a) {
-                acc->min_bits[a] = f2ord(mn[a]);
-                acc->max_bits[a] = f2ord(mx[a]);
+                red[threadIdx.x >> 6][a] = mn[a];
+                red[threadIdx.x >> 6][3 + a] = mx[a];
             }
-            acc->n_bodies = cnt;
+            red_cnt[threadIdx.x >> 6] = cnt;
         }
         __syncthreads();
+        if (threadIdx.x >= 64) return; // one wave from here on: the barriers below are wave-level
+    }
+    float gmn[3], gmx[3]; // every lane of the remaining wave holds the scene bounds and the body count
+    uint32_t n = 0;
+    for (int a = 0; a < 3; ++a) {
+        gmn[a] = INFINITY;
+        gmx[a] = -INFINITY;
+    }
+    for (uint32_t wv = 0; wv < kParamsThreads / 64; ++wv) {
+        for (int a = 0; a < 3; ++a) {
+            gmn[a] = fminf(gmn[a], red[wv][a]);
+            gmx[a] = fmaxf(gmx[a], red[wv][3 + a]);
+        }
+        n += red_cnt[wv];
+    }
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) {
+            acc->min_bits[a] = f2ord(gmn[a]);
+            acc->max_bits[a] = f2ord(gmx[a]);
+        }
+        acc->n_bodies = n;
     }
     {
         // exclusive prefix of the histogram: 16 consecutive bins per lane + a wave64 __shfl_up scan of the lane totals
@@ -231,7 +286,7 @@ __global__ void __launch_bounds__(64) k_bp_params(Accum* acc, uint32_t max_cells
         uint32_t sum = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            h[k] = acc->extent_hist[lane * 16 + k];
+            h[k] = below[lane * 16 + k];
             sum += h[k];
         }
         uint32_t incl = sum;
@@ -248,14 +303,13 @@ __global__ void __launch_bounds__(64) k_bp_params(Accum* acc, uint32_t max_cells
         }
         if (lane == 63) below[kExtentBins] = run;
     }
-    __syncthreads();
-    const uint32_t n = acc->n_bodies;
+    wave_sync();
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     double volume = 1.0;
     if (n) {
         for (int a = 0; a < 3; ++a) {
-            lo[a] = ord2f(acc->min_bits[a]);
-            hi[a] = ord2f(acc->max_bits[a]);
+            lo[a] = gmn[a];
+            hi[a] = gmx[a];
             if (!(lo[a] > -1.0e30f)) lo[a] = -1.0e30f;
             if (!(hi[a] < 1.0e30f)) hi[a] = 1.0e30f;
             volume *= fmax(static_cast<double>(hi[a]) - static_cast<double>(lo[a]), 1.0e-3);
@@ -730,15 +784,6 @@ __device__ __forceinline__ bool in_window(const PairSink& s, const float4& alo, 
 // atomics/s, so one atomic per hit-bearing iteration (the first version) cost 39 ms for 12.6 M pairs.
 constexpr uint32_t kStage = 192;     // 127 carried + 64 new
 constexpr uint32_t kFlush = 128;     // pairs written per global atomic (2 per lane, 1 KiB contiguous)
-
-// LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the
-// compiler from moving them across the hand-over point.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 struct WaveStage {
     uint2* buf;     // LDS, kStage entries owned by this wave
@@ -1237,10 +1282,10 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     const uint32_t scan_blocks = blocks_for(scan_n, kScanBlock);
     const uint32_t slot_blocks = blocks_for(n, 256);
 
-    hipLaunchKernelGGL(k_bp_reset, dim3(1), dim3(256), 0, stream, acc);
+    hipLaunchKernelGGL(k_bp_reset, dim3(kHistShards), dim3(256), 0, stream, acc);
     const uint32_t bounds_blocks = std::min<uint32_t>(slot_blocks, kBoundsBlocks);
     hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
-    hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(64), 0, stream, acc, table_size_, bounds_blocks);
+    hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(kParamsThreads), 0, stream, acc, table_size_, bounds_blocks);
     if (lds_sort_) {
         const uint32_t groups = std::min<uint32_t>(kSortGroups, blocks_for(n, kSortThreads));
         const uint64_t chunk = (n + groups - 1) / groups;
