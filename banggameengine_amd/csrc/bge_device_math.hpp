@@ -243,8 +243,8 @@ __device__ __forceinline__ M3 bt_mat_from_quat(const Q4& q)
     return r;
 }
 
-// btMatrix3x3::getRotation(q), scalar path (oracle/bullet_math.h QuatFromMat; the trace > 0 side is checked against the
-// reference's PhysicsSystem.obj by oracle/tools/check_bullet_order.py, the other side was read from the same code).  The
+// btMatrix3x3::getRotation(q), scalar path (oracle/bullet_math.h QuatFromMat; both sides are checked against the
+// reference's PhysicsSystem.obj by oracle/tools/check_bullet_order.py, the trace <= 0 side for each of its three i).  The
 // run-time indices i, j, k of Bullet's code are spelled out as three cases: no dynamically indexed arrays (scratch).
 __device__ __forceinline__ Q4 bt_quat_from_mat(const M3& a)
 {

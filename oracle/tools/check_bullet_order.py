@@ -181,6 +181,102 @@ def integrate_orientation(q0, w, dt, path):
     return [(x * s).t for x in p]
 
 
+def concretise_indices(ins, start_pc, gpr0):
+    """btMatrix3x3::getRotation indexes the matrix with run-time i, j, k.  For one value of i the integer code that derives
+    j = (i + 1) % 3, k = (i + 2) % 3 and the element offsets is executed CONCRETELY (a dozen mov / lea / mul / shr / sub
+    forms), and every indexed memory operand `disp(base,index,scale)` is rewritten to the plain `disp'(base)` it denotes, so
+    that the float code can then be executed symbolically as usual."""
+    g = dict(gpr0)
+    legacy = {"%eax": "%rax", "%ecx": "%rcx", "%edx": "%rdx", "%esi": "%rsi", "%edi": "%rdi", "%ebx": "%rbx", "%ebp": "%rbp"}
+
+    def reg64(r):
+        m_ = re.fullmatch(r"%r(\d+)[dwb]", r)
+        return f"%r{m_.group(1)}" if m_ else legacy.get(r, r)
+
+    out = []
+    for pc, mn, ops in ins:
+        if pc < start_pc:
+            out.append((pc, mn, ops))
+            continue
+        parts = [p_.strip() for p_ in re.split(r",(?![^(]*\))", ops)] if ops else []
+        m = None
+        new_ops = ops
+        for k_, p_ in enumerate(parts):
+            m = re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+)?,(%\w+),(\d)\)", p_) or re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+),(%\w+)()\)", p_)
+            if m and mn != "lea":
+                disp = int(m.group(1), 16) if m.group(1) else 0
+                base, idx, sc = m.group(2), m.group(3), int(m.group(4) or 1)
+                assert reg64(idx) in g, (hex(pc), ops)
+                parts[k_] = f"{disp + g[reg64(idx)] * sc:#x}({base})"
+                new_ops = ",".join(parts)
+        if mn == "lea":
+            m = re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+)?(?:,(%\w+)(?:,(\d))?)?\)", parts[0])
+            base, idx = m.group(2), m.group(3)
+            if (base is None or reg64(base) in g) and (idx is None or reg64(idx) in g):
+                v = (int(m.group(1), 16) if m.group(1) else 0) + (g[reg64(base)] if base else 0) + (g[reg64(idx)] * int(m.group(4) or 1) if idx else 0)
+                g[reg64(parts[1])] = v & 0xFFFFFFFFFFFFFFFF
+        elif mn in ("mov", "movslq") and len(parts) == 2 and parts[1].startswith("%") and "(" not in parts[1]:
+            if parts[0].startswith("$"):
+                g[reg64(parts[1])] = int(parts[0][1:], 16)
+            elif reg64(parts[0]) in g:
+                g[reg64(parts[1])] = g[reg64(parts[0])]
+                if mn == "movslq":
+                    g[("set", reg64(parts[1]))] = g[reg64(parts[0])]      # remembered: the register is restored later
+            else:
+                g.pop(reg64(parts[1]), None)
+        elif mn == "mul" and reg64(parts[0]) in g and "%rax" in g:     # edx:eax = eax * r32
+            prod = (g["%rax"] & 0xFFFFFFFF) * (g[reg64(parts[0])] & 0xFFFFFFFF)
+            g["%rax"], g["%rdx"] = prod & 0xFFFFFFFF, prod >> 32
+        elif mn == "shr" and len(parts) == 1 and reg64(parts[0]) in g:
+            g[reg64(parts[0])] >>= 1
+        elif mn == "sub" and len(parts) == 2 and reg64(parts[0]) in g and reg64(parts[1]) in g and parts[1] != "%rsp":
+            g[reg64(parts[1])] = (g[reg64(parts[1])] - g[reg64(parts[0])]) & 0xFFFFFFFF
+        out.append((pc, mn, new_ops))
+    return out, g
+
+
+def check_get_rotation_other_side():
+    """btMatrix3x3::getRotation for trace <= 0: the choice of i as text, then the three cases executed symbolically."""
+    name, ins, consts, calls = coff_function(OBJ, "?getRotation@btMatrix3x3@@")
+    text = [(x[1], x[2]) for x in ins]
+    k0 = text.index(("xor", "%r9d,%r9d"))
+    k1 = next(k for k, x in enumerate(text) if k > k0 and x[0] == "lea")
+    sel = [t for t in text[k0:k1] if t[0] not in ("mov",) or t[1].startswith("$")]
+    # xmm3 = m00, xmm2 = m11, xmm4 = m22 (loaded at the top);  i = m00 < m11 ? (m11 < m22 ? 2 : 1) : (m00 < m22 ? 2 : 0)
+    want_sel = [("xor", "%r9d,%r9d"), ("comiss", "%xmm3,%xmm2"), ("jbe", None), ("comiss", "%xmm2,%xmm4"), ("seta", "%r9b"),
+                ("inc", "%r9d"), ("jmp", None), ("comiss", "%xmm3,%xmm4"), ("mov", "$0x2,%eax"), ("cmova", "%eax,%r9d")]
+    ok = len(sel) == len(want_sel) and all(a[0] == b[0] and (b[1] is None or a[1] == b[1]) for a, b in zip(sel, want_sel))
+    top = [t for t in text[:k0] if t[0] == "movss"][:3]
+    ok &= top == [("movss", "(%rcx),%xmm3"), ("movss", "0x14(%rcx),%xmm2"), ("movss", "0x28(%rcx),%xmm4")]
+    print("btMatrix3x3::getRotation, trace <= 0: i = m00 < m11 ? (m11 < m22 ? 2 : 1) : (m00 < m22 ? 2 : 0): "
+          + ("as restated" if ok else "MISMATCH"))
+    jbe_trace = next(x[0] for x in ins if x[1] == "jbe")
+    start = ins[k1][0]
+    m = [[E(("in", "m", 4 * r + c)) for c in range(3)] for r in range(3)]
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        rewritten, g = concretise_indices(ins, start, {"%r9": i})
+        good_idx = g.get(("set", "%r14")) == j and g.get(("set", "%r15")) == k
+        # skip the selection code: it only sets %r9, which is given
+        body = [x for x in rewritten if not (ins[k0][0] <= x[0] < start)]
+        got = execute(body, {"%rcx": "m"}, {"%rdx": "q"}, named_consts=consts, named_calls=calls, take=(jbe_trace,))
+        s_ = fn("sqrtf", ((m[i][i] - m[j][j]) - m[k][k]) + 1.0)
+        s2 = E(("div", ("const", 0.5), s_.t))
+        t = [None] * 4
+        t[i] = (s_ * 0.5).t
+        t[3] = ((m[k][j] - m[j][k]) * s2).t
+        t[j] = ((m[j][i] + m[i][j]) * s2).t
+        t[k] = ((m[k][i] + m[i][k]) * s2).t
+        bad = [c for c in range(4) if norm(got.get(("q", c), ("missing",))) != norm(t[c])]
+        print(f"btMatrix3x3::getRotation, trace <= 0, i = {i} (j = {j}, k = {k} from the compiled modulo code: {'yes' if good_idx else 'NO'}): "
+              f"{4 - len(bad)} of 4 components identical" + ("" if not bad and good_idx else f"  <-- MISMATCH {bad}"))
+        for c in bad[:2]:
+            print("   compiled   :", norm(got.get(("q", c), ("missing",))))
+            print("   restatement:", norm(t[c]))
+        ok &= not bad and good_idx
+    return ok
+
+
 def check_integrate_transform():
     """btTransformUtil::integrateTransform exists once in the exe (symbol-less); it is the only code that references the
     constant 1/48 = 0x3caaaaab of its Taylor branch, which is how it is found."""
@@ -865,9 +961,8 @@ def main():
             print("   compiled   :", norm(got.get(k, ("missing",))))
             print("   restatement:", norm(want[k]))
         ok &= not bad
-    # 4. btMatrix3x3::getRotation(q), the trace > 0 side (the other side indexes the matrix with run-time i, j, k; it was
-    #    read by hand: i = m00 < m11 ? (m11 < m22 ? 2 : 1) : (m00 < m22 ? 2 : 0), s = sqrt(m[i][i] - m[j][j] - m[k][k] + 1),
-    #    t[i] = s / 2, s = 0.5 / s, t[3] = (m[k][j] - m[j][k]) s, t[j] = (m[j][i] + m[i][j]) s, t[k] = (m[k][i] + m[i][k]) s)
+    # 4. btMatrix3x3::getRotation(q), the trace > 0 side (the other side, which indexes the matrix with run-time i, j, k, is
+    #    check_get_rotation_other_side)
     name, ins, consts, calls = coff_function(OBJ, "?getRotation@btMatrix3x3@@")
     ja = [i[0] for i in ins if i[1] == "ja"]
     got = execute(ins, {"%rcx": "m"}, {"%rdx": "q"}, named_consts=consts, named_calls=calls, take=())   # jbe not taken: trace > 0
@@ -880,6 +975,7 @@ def main():
     bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
     print(f"btMatrix3x3::getRotation, trace > 0: {4 - len(bad)} of 4 components identical" + ("" if not bad else f"  <-- MISMATCH {bad}"))
     ok &= not bad
+    ok &= check_get_rotation_other_side()
     ok &= check_integrate_transform()
     ok &= check_external_force_impulse()
     ok &= check_box_aabb()
