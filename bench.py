@@ -55,16 +55,18 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(wl, target_seconds):
-    """Time the reference-faithful CPU path (oracle port, 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(wl, target_seconds, aabbs=False, max_entities=None):
+    """Time the reference-faithful CPU path (oracle port, 1 thread) on a bounded sample of the same workload.
+    (`aabbs`, `max_entities`: used by tools/measure_configs.py, which times the other configurations through this leg.)"""
     from oracle import pyoracle as po
-    n = wl.n
+    n = min(wl.n, max_entities) if max_entities else wl.n
     roots_only = int(wl.bodies_on_roots_only)
     # probe one tick to size the sample, then time `ticks` ticks after one warm tick
-    sec, _ = po.bench_tick(wl.shape, wl.pos_box, roots_only, 0, n, wl.seed, 0, 1)
+    sec, _ = po.bench_tick(wl.shape, wl.pos_box, roots_only, int(aabbs), n, wl.seed, 0, 1)
     ticks = int(max(2, min(120, target_seconds / max(sec, 1e-9))))
-    sec, upd = po.bench_tick(wl.shape, wl.pos_box, roots_only, 0, n, wl.seed, 1, ticks)
+    sec, upd = po.bench_tick(wl.shape, wl.pos_box, roots_only, int(aabbs), n, wl.seed, 1, ticks)
     return {
+        "entities": n, "ticks": ticks,
         "value": upd * ticks / sec,
         "unit": "entity-updates/s",
         "cores": 1,
@@ -75,19 +77,20 @@ def cpu_baseline(wl, target_seconds):
     }
 
 
-def cpu_allcore(wl, target_seconds, threads):
+def cpu_allcore(wl, target_seconds, threads, max_entities=None):
     """BASELINE.md §3 "CPU-opt": the same arithmetic on dense SoA, depth-sorted, all host threads (oracle/soa_ref.h)."""
     from oracle import pyoracle as po
     roots_only = int(wl.bodies_on_roots_only)
-    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, wl.n, wl.seed, 1, 2, threads=threads)
+    n = min(wl.n, max_entities) if max_entities else wl.n
+    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, n, wl.seed, 1, 2, threads=threads)
     ticks = int(max(3, min(400, target_seconds / max(sec / 2, 1e-9))))
-    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, wl.n, wl.seed, 2, ticks, threads=threads)
+    sec, threads = po.bench_tick_soa(wl.shape, wl.pos_box, roots_only, n, wl.seed, 2, ticks, threads=threads)
     return {
-        "value": wl.n * ticks / sec,
+        "value": n * ticks / sec,
         "unit": "entity-updates/s",
         "cores": threads,
         "kind": "port-soa",
-        "sample": f"{wl.n} entities x {ticks} ticks ({wl.name}); dense structure-of-arrays rewrite of the same arithmetic, "
+        "sample": f"{n} entities x {ticks} ticks ({wl.name}); dense structure-of-arrays rewrite of the same arithmetic, "
                   f"OpenMP on {threads} threads — not how the reference works, reported for a hardware-to-hardware reading",
     }
 

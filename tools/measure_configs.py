@@ -21,7 +21,7 @@ import torch  # noqa: E402
 import banggameengine_amd as B  # noqa: E402
 from banggameengine_amd import synth  # noqa: E402
 from banggameengine_amd.world import FIXED_DT  # noqa: E402
-from oracle import pyoracle as po  # noqa: E402
+import bench  # noqa: E402  (the CPU leg goes through bench.py's cpu_baseline / cpu_allcore, the only timed users of oracle/)
 
 CONFIGS = [
     ("configs[0] flat 10k", "flat10k", None, 2000),
@@ -83,17 +83,13 @@ def gpu_rate(name, n, steps, extra=None):
 
 
 def cpu_rate(wl, name, seconds=6.0):
-    n = min(wl.n, 1_000_000)   # bounded sample: the hash-map port runs ~2-10 M updates/s
-    aabb = int(name == "cube4m")
-    sec, _ = po.bench_tick(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), aabb, n, wl.seed, 0, 1)
-    ticks = int(max(2, min(60, seconds / max(sec, 1e-9))))
-    sec, upd = po.bench_tick(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), aabb, n, wl.seed, 1, ticks)
-    out = dict(n=n, ticks=ticks, rate=upd * ticks / sec)
+    aabb = name == "cube4m"
+    # bounded sample: the hash-map port runs ~2-10 M updates/s
+    c = bench.cpu_baseline(wl, seconds, aabbs=aabb, max_entities=1_000_000)
+    out = dict(n=c["entities"], ticks=c["ticks"], rate=c["value"])
     if not aabb:
-        s2, threads = po.bench_tick_soa(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), n, wl.seed, 1, 3)
-        k = int(max(3, min(300, 3.0 / max(s2 / 3, 1e-9))))
-        s2, threads = po.bench_tick_soa(wl.shape, wl.pos_box, int(wl.bodies_on_roots_only), n, wl.seed, 2, k)
-        out.update(soa_rate=n * k / s2, soa_threads=threads)
+        a = bench.cpu_allcore(wl, 3.0, 0, max_entities=1_000_000)
+        out.update(soa_rate=a["value"], soa_threads=a["cores"])
     return out
 
 
