@@ -39,6 +39,13 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// include/bge_world.h promises that no entry point throws: every `int bge_*` function is a function-try-block that ends
+// in this handler list (host containers can throw std::bad_alloc; an exception must not unwind into a C caller).
+#define BGE_CATCH_ALL(name)                                                                              \
+    catch (const std::bad_alloc&) { return fail(BGE_ERR_OOM, "%s: host allocation failed", name); }      \
+    catch (const std::exception& e) { return fail(BGE_ERR_STATE, "%s: unexpected exception: %s", name, e.what()); } \
+    catch (...) { return fail(BGE_ERR_STATE, "%s: unexpected exception", name); }
+
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
         const hipError_t e_ = (expr);                                                                      \
@@ -469,7 +476,7 @@ const char* bge_last_error(void) { return g_last_error.c_str(); }
 uint32_t bge_version(void) { return 0x00010000u; }
 
 int bge_world_create(const bge_world_desc* desc, bge_world** out)
-{
+try {
     if (!out) return fail(BGE_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (desc && desc->struct_size != 0 && desc->struct_size < sizeof(bge_world_desc)) {
@@ -505,6 +512,7 @@ int bge_world_create(const bge_world_desc* desc, bge_world** out)
     *out = w;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_create")
 
 void bge_world_destroy(bge_world* w)
 {
@@ -517,7 +525,7 @@ void bge_world_destroy(bge_world* w)
 }
 
 int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, const uint8_t* has_transform)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (n >= 0xfffffff0ull) return fail(BGE_ERR_INVALID, "too many entities (%llu)", (unsigned long long)n);
     DeviceGuard guard(w->device);
@@ -702,6 +710,7 @@ int bge_world_set_topology(bge_world* w, uint64_t n, const uint32_t* parent, con
     w->pairs_from_slab = false;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_set_topology")
 
 static int upload_trs_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const float* pos3,
                            const float* euler3, const float* scale3)
@@ -728,21 +737,23 @@ static int upload_trs_impl(bge_world* w, uint64_t first, uint64_t count, const u
 
 int bge_world_upload_trs(bge_world* w, uint64_t first, uint64_t count, const float* pos3, const float* euler3,
                          const float* scale3)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     return upload_trs_impl(w, first, count, nullptr, pos3, euler3, scale3);
 }
+BGE_CATCH_ALL("bge_world_upload_trs")
 
 int bge_world_upload_trs_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, const float* pos3,
                                  const float* euler3, const float* scale3)
-{
+try {
     if (int rc = check_range(w, 0, 0)) return rc;
     if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
     return upload_trs_impl(w, 0, count, entity_index, pos3, euler3, scale3);
 }
+BGE_CATCH_ALL("bge_world_upload_trs_indexed")
 
 int bge_world_mark_dirty(bge_world* w, uint64_t first, uint64_t count)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
@@ -751,6 +762,7 @@ int bge_world_mark_dirty(bge_world* w, uint64_t first, uint64_t count)
     w->maybe_dirty = true;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_mark_dirty")
 
 static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const uint8_t* type,
                               const float* mass, const uint8_t* shape, const float* size3, const uint32_t* layer,
@@ -758,19 +770,21 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
 
 int bge_world_upload_bodies(bge_world* w, uint64_t first, uint64_t count, const uint8_t* type, const float* mass,
                             const uint8_t* shape, const float* size3, const uint32_t* layer, const uint32_t* mask)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     return upload_bodies_impl(w, first, count, nullptr, type, mass, shape, size3, layer, mask);
 }
+BGE_CATCH_ALL("bge_world_upload_bodies")
 
 int bge_world_upload_bodies_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, const uint8_t* type,
                                     const float* mass, const uint8_t* shape, const float* size3, const uint32_t* layer,
                                     const uint32_t* mask)
-{
+try {
     if (int rc = check_range(w, 0, 0)) return rc;
     if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
     return upload_bodies_impl(w, 0, count, entity_index, type, mass, shape, size3, layer, mask);
 }
+BGE_CATCH_ALL("bge_world_upload_bodies_indexed")
 
 static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const uint8_t* type,
                               const float* mass, const uint8_t* shape, const float* size3, const uint32_t* layer,
@@ -843,7 +857,7 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
 }
 
 int bge_world_set_velocities(bge_world* w, uint64_t first, uint64_t count, const float* linvel3, const float* angvel3)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (count == 0 || (!linvel3 && !angvel3)) return BGE_OK;
     DeviceGuard guard(w->device);
@@ -858,9 +872,10 @@ int bge_world_set_velocities(bge_world* w, uint64_t first, uint64_t count, const
     HIP_TRY(hipStreamSynchronize(w->stream));
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_set_velocities")
 
 int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float gravity[3], uint32_t flags)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     if ((flags & (BGE_TICK_PHYSICS | BGE_TICK_TRANSFORMS)) == 0) return fail(BGE_ERR_INVALID, "tick flags select nothing");
@@ -1070,14 +1085,16 @@ int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float grav
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_tick_many")
 
 int bge_world_tick(bge_world* w, float dt, const float gravity[3], uint32_t flags)
-{
+try {
     return bge_world_tick_many(w, 1, dt, gravity, flags);
 }
+BGE_CATCH_ALL("bge_world_tick")
 
 int bge_world_profile_enable(bge_world* w, int enable)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     DeviceGuard guard(w->device);
     if (enable && w->prof_events.empty()) {
@@ -1093,9 +1110,10 @@ int bge_world_profile_enable(bge_world* w, int enable)
     w->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_profile_enable")
 
 int bge_world_profile_read(bge_world* w, double* tick_kernel_ms, uint64_t* ticks)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     DeviceGuard guard(w->device);
     if (int rc = fold_profile(w)) return rc;
@@ -1105,26 +1123,29 @@ int bge_world_profile_read(bge_world* w, double* tick_kernel_ms, uint64_t* ticks
     w->prof_ticks_carry = 0;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_profile_read")
 
 int bge_world_sync(bge_world* w)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     DeviceGuard guard(w->device);
     HIP_TRY(hipStreamSynchronize(w->stream));
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_sync")
 
 int bge_world_download_world(bge_world* w, uint64_t first, uint64_t count, float* out16)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (!out16) return fail(BGE_ERR_INVALID, "out16 is NULL");
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
     return download_rows(w, first, count, 16, w->world.p, out16);
 }
+BGE_CATCH_ALL("bge_world_download_world")
 
 int bge_world_download_world_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, float* out16)
-{
+try {
     if (int rc = check_range(w, 0, 0)) return rc;
     if (count == 0) return BGE_OK;
     if (!entity_index || !out16) return fail(BGE_ERR_INVALID, "NULL argument");
@@ -1133,9 +1154,10 @@ int bge_world_download_world_indexed(bge_world* w, uint64_t count, const uint32_
     if (int rc = stage_index(w, count, entity_index, &di)) return rc;
     return download_rows(w, 0, count, 16, w->world.p, out16, di);
 }
+BGE_CATCH_ALL("bge_world_download_world_indexed")
 
 int bge_world_download_pose_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, float* pos3, float* euler3)
-{
+try {
     if (int rc = check_range(w, 0, 0)) return rc;
     if (count == 0) return BGE_OK;
     if (!entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
@@ -1150,9 +1172,10 @@ int bge_world_download_pose_indexed(bge_world* w, uint64_t count, const uint32_t
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_download_pose_indexed")
 
 int bge_world_download_normal(bge_world* w, uint64_t first, uint64_t count, float* out16)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (!out16) return fail(BGE_ERR_INVALID, "out16 is NULL");
     if (!w->normal.p) return fail(BGE_ERR_STATE, "no tick with BGE_TICK_NORMAL_MATRICES has run");
@@ -1160,9 +1183,10 @@ int bge_world_download_normal(bge_world* w, uint64_t first, uint64_t count, floa
     DeviceGuard guard(w->device);
     return download_rows(w, first, count, 16, w->normal.p, out16);
 }
+BGE_CATCH_ALL("bge_world_download_normal")
 
 int bge_world_download_pose(bge_world* w, uint64_t first, uint64_t count, float* pos3, float* euler3)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
@@ -1174,10 +1198,11 @@ int bge_world_download_pose(bge_world* w, uint64_t first, uint64_t count, float*
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_download_pose")
 
 int bge_world_download_bodies(bge_world* w, uint64_t first, uint64_t count, float* linvel3, float* angvel3, float* quat4,
                               float* aabb6)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
@@ -1195,9 +1220,10 @@ int bge_world_download_bodies(bge_world* w, uint64_t first, uint64_t count, floa
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_download_bodies")
 
 int bge_world_download_activation(bge_world* w, uint64_t first, uint64_t count, uint8_t* state, float* time)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
@@ -1224,9 +1250,10 @@ int bge_world_download_activation(bge_world* w, uint64_t first, uint64_t count, 
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_download_activation")
 
 int bge_world_set_sleeping(bge_world* w, float linear_threshold, float angular_threshold, float seconds)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!(linear_threshold >= 0.0f) || !(angular_threshold >= 0.0f) || !(seconds >= 0.0f))
         return fail(BGE_ERR_INVALID, "sleeping thresholds must be >= 0");
@@ -1236,10 +1263,11 @@ int bge_world_set_sleeping(bge_world* w, float linear_threshold, float angular_t
     w->drop_graph();
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_set_sleeping")
 
 // Page-locked host memory: transfers to and from it run at the full PCIe rate (~55 GB/s against ~10 GB/s pageable).
 int bge_host_alloc(uint64_t bytes, void** out)
-{
+try {
     if (!out) return fail(BGE_ERR_INVALID, "NULL argument");
     *out = nullptr;
     void* p = nullptr;
@@ -1249,17 +1277,19 @@ int bge_host_alloc(uint64_t bytes, void** out)
     *out = p;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_host_alloc")
 
 int bge_host_free(void* p)
-{
+try {
     if (!p) return BGE_OK;
     const hipError_t e = hipHostFree(p);
     if (e != hipSuccess) return fail(BGE_ERR_HIP, "hipHostFree: %s", hipGetErrorString(e));
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_host_free")
 
 int bge_world_download_dirty(bge_world* w, uint64_t first, uint64_t count, uint8_t* dirty)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (!dirty) return fail(BGE_ERR_INVALID, "dirty is NULL");
     if (count == 0) return BGE_OK;
@@ -1271,9 +1301,10 @@ int bge_world_download_dirty(bge_world* w, uint64_t first, uint64_t count, uint8
     HIP_TRY(hipStreamSynchronize(w->stream));
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_download_dirty")
 
 int bge_world_dirty_count(bge_world* w, uint64_t* out)
-{
+try {
     if (!w || !out) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     DeviceGuard guard(w->device);
@@ -1285,9 +1316,10 @@ int bge_world_dirty_count(bge_world* w, uint64_t* out)
     *out = v;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_dirty_count")
 
 int bge_world_pairs(bge_world* w, uint32_t* pairs2, uint64_t cap, uint64_t* total)
-{
+try {
     if (!w || !total) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     DeviceGuard guard(w->device);
@@ -1296,6 +1328,7 @@ int bge_world_pairs(bge_world* w, uint32_t* pairs2, uint64_t cap, uint64_t* tota
     if (rc != BGE_OK) return fail(rc, "pair download failed: %s", bp.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_pairs")
 
 // ---------------------------------------------------------------- sharded broadphase (bge_route.hip)
 namespace {
@@ -1319,7 +1352,7 @@ int refresh_global_of_slot(bge_world* w)
 } // namespace
 
 int bge_world_set_global_ids(bge_world* w, uint64_t first, uint64_t count, const uint32_t* ids)
-{
+try {
     if (int rc = check_range(w, first, count)) return rc;
     if (count && !ids) return fail(BGE_ERR_INVALID, "ids is NULL");
     if (w->global_id_host.size() < w->flat.n_entities) {
@@ -1331,9 +1364,10 @@ int bge_world_set_global_ids(bge_world* w, uint64_t first, uint64_t count, const
     w->global_of_slot_stale = true;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_set_global_ids")
 
 int bge_world_aabb_bounds(bge_world* w, float mn[3], float mx[3], uint64_t* n_bodies)
-{
+try {
     if (!w || !mn || !mx) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     DeviceGuard guard(w->device);
@@ -1341,9 +1375,10 @@ int bge_world_aabb_bounds(bge_world* w, float mn[3], float mx[3], uint64_t* n_bo
     if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_aabb_bounds")
 
 int bge_world_axis_histogram(bge_world* w, uint32_t axis, float lo, float hi, uint32_t bins, uint64_t* hist)
-{
+try {
     if (!w || !hist) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     DeviceGuard guard(w->device);
@@ -1351,9 +1386,10 @@ int bge_world_axis_histogram(bge_world* w, uint32_t axis, float lo, float hi, ui
     if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_axis_histogram")
 
 int bge_balanced_cuts(const uint64_t* hist, uint32_t bins, float lo, float hi, uint32_t nranks, float* cuts)
-{
+try {
     if (!hist || !cuts || bins == 0 || nranks == 0) return fail(BGE_ERR_INVALID, "bad argument");
     uint64_t total = 0;
     for (uint32_t b = 0; b < bins; ++b) total += hist[b];
@@ -1372,9 +1408,10 @@ int bge_balanced_cuts(const uint64_t* hist, uint32_t bins, float lo, float hi, u
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_balanced_cuts")
 
 int bge_world_bp_route(bge_world* w, uint32_t axis, uint32_t nranks, const float* cuts, uint64_t* counts)
-{
+try {
     if (!w || !counts) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     if (nranks > 1 && !cuts) return fail(BGE_ERR_INVALID, "cuts is NULL");
@@ -1384,9 +1421,10 @@ int bge_world_bp_route(bge_world* w, uint32_t axis, uint32_t nranks, const float
     if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_bp_route")
 
 int bge_world_bp_pack(bge_world* w, void* send_device)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     DeviceGuard guard(w->device);
@@ -1395,9 +1433,10 @@ int bge_world_bp_pack(bge_world* w, void* send_device)
     if (rc != BGE_OK) return fail(rc, "%s", w->router.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_bp_pack")
 
 int bge_world_bp_find(bge_world* w, const void* records_device, uint64_t n_records, uint32_t axis, float window_lo, float window_hi)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (n_records && !records_device) return fail(BGE_ERR_INVALID, "records_device is NULL");
     if (axis > 2) return fail(BGE_ERR_INVALID, "axis %u", axis);
@@ -1420,11 +1459,12 @@ int bge_world_bp_find(bge_world* w, const void* records_device, uint64_t n_recor
     w->pairs_from_slab = true;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_bp_find")
 
 // The whole exchange over the world's RCCL communicator: common bounds (one all-reduce), uniform cuts along `axis`,
 // counts (one all-gather), records (one grouped send/recv per peer), slab search.
 int bge_world_bp_exchange(bge_world* w, uint32_t axis)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     if (!w->comm.ready()) return fail(BGE_ERR_STATE, "bge_world_comm_init has not been called");
@@ -1484,10 +1524,11 @@ int bge_world_bp_exchange(bge_world* w, uint32_t axis)
     const float whi = me + 1 == N ? INFINITY : cuts[me + 1];
     return bge_world_bp_find(w, w->bp_recv.p, n_recv, axis, wlo, whi);
 }
+BGE_CATCH_ALL("bge_world_bp_exchange")
 
 int bge_world_upload_triggers(bge_world* w, uint64_t count, const uint32_t* entity_index, const uint8_t* shape, const float* size3,
                               const uint32_t* layer, const uint32_t* mask, const uint8_t* one_shot, const uint8_t* active)
-{
+try {
     if (int rc = check_range(w, 0, 0)) return rc;
     if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
     std::unordered_map<uint32_t, size_t> old_index;
@@ -1523,9 +1564,10 @@ int bge_world_upload_triggers(bge_world* w, uint64_t count, const uint32_t* enti
     w->triggers_device_stale = true;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_upload_triggers")
 
 int bge_world_trigger_events(bge_world* w, bge_trigger_event* out, uint64_t cap, uint64_t* total)
-{
+try {
     if (!w || !total) return fail(BGE_ERR_INVALID, "NULL argument");
     *total = w->trigger_events.size();
     if (out) {
@@ -1535,9 +1577,10 @@ int bge_world_trigger_events(bge_world* w, bge_trigger_event* out, uint64_t cap,
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_trigger_events")
 
 int bge_world_trigger_active(bge_world* w, uint64_t count, const uint32_t* entity_index, uint8_t* active)
-{
+try {
     if (!w || (count && (!entity_index || !active))) return fail(BGE_ERR_INVALID, "NULL argument");
     std::unordered_map<uint32_t, bool> state;
     for (const bge_world::Trigger& t : w->triggers) state[t.entity] = t.component_active;
@@ -1547,9 +1590,10 @@ int bge_world_trigger_active(bge_world* w, uint64_t count, const uint32_t* entit
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_trigger_active")
 
 int bge_world_pack_roots(bge_world* w, void* dst_device)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     DeviceGuard guard(w->device);
@@ -1557,9 +1601,10 @@ int bge_world_pack_roots(bge_world* w, void* dst_device)
     HIP_TRY(bge::launch_pack_roots(w->stream, w->flat.root_slots.size(), w->root_slots.as<uint32_t>(), w->world.as<float>(), dst));
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_pack_roots")
 
 int bge_world_device_array(bge_world* w, int which, void** device_ptr, uint64_t* elements)
-{
+try {
     if (!w || !device_ptr) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     uint64_t n = 0;
@@ -1584,18 +1629,20 @@ int bge_world_device_array(bge_world* w, int which, void** device_ptr, uint64_t*
     if (elements) *elements = n;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_device_array")
 
 int bge_comm_unique_id(void* out128)
-{
+try {
     if (!out128) return fail(BGE_ERR_INVALID, "out128 is NULL");
     std::string err;
     const int rc = bge::RootComm::unique_id(out128, err);
     if (rc != BGE_OK) return fail(rc, "%s", err.c_str());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_comm_unique_id")
 
 int bge_world_comm_init(bge_world* w, int nranks, int rank, const void* id128, uint64_t rows_per_rank)
-{
+try {
     if (!w || !id128) return fail(BGE_ERR_INVALID, "NULL argument");
     if (nranks <= 0 || rank < 0 || rank >= nranks) return fail(BGE_ERR_INVALID, "rank %d of %d", rank, nranks);
     DeviceGuard guard(w->device);
@@ -1603,9 +1650,10 @@ int bge_world_comm_init(bge_world* w, int nranks, int rank, const void* id128, u
     if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_comm_init")
 
 int bge_world_gather_roots(bge_world* w, void** table_device)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     if (!w->comm.ready()) return fail(BGE_ERR_STATE, "bge_world_comm_init has not been called");
@@ -1623,9 +1671,10 @@ int bge_world_gather_roots(bge_world* w, void** table_device)
     if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_gather_roots")
 
 int bge_world_download_gathered(bge_world* w, float* out, uint64_t floats)
-{
+try {
     if (!w || !out) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->comm.ready()) return fail(BGE_ERR_STATE, "bge_world_comm_init has not been called");
     DeviceGuard guard(w->device);
@@ -1650,9 +1699,10 @@ int bge_world_download_gathered(bge_world* w, float* out, uint64_t floats)
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_download_gathered")
 
 int bge_world_comm_set_mode(bge_world* w, int mode)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (mode != BGE_GATHER_ALLGATHER && mode != BGE_GATHER_DIRECT) return fail(BGE_ERR_INVALID, "unknown gather mode %d", mode);
     DeviceGuard guard(w->device);
@@ -1660,24 +1710,27 @@ int bge_world_comm_set_mode(bge_world* w, int mode)
     w->comm.set_mode(mode);
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_comm_set_mode")
 
 int bge_world_comm_wait(bge_world* w)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     DeviceGuard guard(w->device);
     const int rc = w->comm.wait(w->stream);
     if (rc != BGE_OK) return fail(rc, "%s", w->comm.error());
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_comm_wait")
 
 int bge_world_comm_destroy(bge_world* w)
-{
+try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     DeviceGuard guard(w->device);
     (void)hipStreamSynchronize(w->stream);
     w->comm.destroy();
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_comm_destroy")
 
 static void fill_info(const bge::Flattened& f, bge_world_info* info)
 {
@@ -1693,17 +1746,18 @@ static void fill_info(const bge::Flattened& f, bge_world_info* info)
 }
 
 int bge_world_get_info(bge_world* w, bge_world_info* info)
-{
+try {
     if (!w || !info) return fail(BGE_ERR_INVALID, "NULL argument");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     fill_info(w->flat, info);
     for (uint8_t t : w->body_type_host) info->n_bodies += t != BGE_BODY_NONE ? 1 : 0;
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_world_get_info")
 
 int bge_flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, uint32_t* slot_of_entity,
                          uint8_t* level_of_entity, uint32_t* pass_of_entity, bge_world_info* info)
-{
+try {
     if (n >= 0xfffffff0ull) return fail(BGE_ERR_INVALID, "too many entities");
     bge::Flattened f;
     try {
@@ -1720,10 +1774,11 @@ int bge_flatten_topology(uint64_t n, const uint32_t* parent, const uint8_t* has_
     if (info) fill_info(f, info);
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_flatten_topology")
 
 int bge_partition_subtrees(uint64_t n, const uint32_t* parent, const uint8_t* has_transform, uint32_t nranks,
                            uint32_t* rank_of_entity, uint64_t* nodes_per_rank)
-{
+try {
     if (!rank_of_entity || nranks == 0) return fail(BGE_ERR_INVALID, "bad arguments");
     try {
         bge::partition_subtrees(n, parent, has_transform, nranks, rank_of_entity, nodes_per_rank);
@@ -1732,5 +1787,6 @@ int bge_partition_subtrees(uint64_t n, const uint32_t* parent, const uint8_t* ha
     }
     return BGE_OK;
 }
+BGE_CATCH_ALL("bge_partition_subtrees")
 
 } // extern "C"
