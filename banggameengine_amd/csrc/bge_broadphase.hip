@@ -670,32 +670,151 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_coarse(uint64_t n_slots, 
     }
 }
 
-template <bool COMPACT>
-__global__ void __launch_bounds__(kFineThreads) k_sort_fine(const Accum* __restrict__ acc, uint32_t shift, uint32_t n_buckets, uint32_t n_groups,
-                                                   const uint32_t* __restrict__ offsets, const float4* __restrict__ coarse,
-                                                   float4* __restrict__ sorted, uint32_t* __restrict__ cell_start)
+// Pass A1, transposing variant (32-byte records): the same result as k_sort_coarse<true> — every record in its bucket, at a
+// position inside the range the matrix scan reserved for this workgroup — but written out in BUCKET ORDER.  k_sort_coarse
+// stores each record straight from the thread that loaded it: 4 M scattered 32-byte writes, which cost 65 of its ~110 us
+// (measured against linear writes).  Here a workgroup keeps a pass of 8192 slots in REGISTERS (8 records per
+// thread), counts and ranks them by bucket in LDS, passes them through an LDS window ordered by rank and writes the window
+// out with consecutive lanes on consecutive float4s: a (workgroup, bucket) run of ~15 records becomes one ~480-byte write.
+constexpr uint32_t kCoarsePerThread = 8;
+constexpr uint32_t kCoarseWindow = 4096; // records in the LDS window (128 KiB); one workgroup per CU (it needs ~100 VGPRs anyway)
+__global__ void __launch_bounds__(kSortThreads, 1)
+    k_sort_coarse_t(uint64_t n_slots, uint64_t chunk, const uint32_t* __restrict__ flags, const float* __restrict__ aabb,
+                    const Accum* __restrict__ acc, uint32_t shift, uint32_t n_buckets, const uint32_t* __restrict__ offsets,
+                    const uint32_t* __restrict__ class_of_slot, const uint32_t* __restrict__ entity_of_slot,
+                    float4* __restrict__ coarse)
+{
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* lcur = lds_u32;                       // [n_buckets] counts -> exclusive prefix -> running cursor
+    uint32_t* goff = lds_u32 + n_buckets;           // [n_buckets] this workgroup's next free position in each bucket
+    uint32_t* wave_tot = goff + n_buckets;          // [16]
+    float4* window = reinterpret_cast<float4*>(wave_tot + 16 + ((16u - ((2u * n_buckets + 16u) & 3u)) & 3u)); // 16-byte aligned
+    __shared__ uint32_t s_total;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t k = tid; k < n_buckets; k += kSortThreads) goff[k] = offsets[static_cast<uint64_t>(k) * gridDim.x + blockIdx.x];
+    const GridParams g = acc->grid;
+    const uint64_t begin = blockIdx.x * chunk, end = min(begin + chunk, n_slots);
+    // entries of lcur / goff this thread owns in the scan: `per` consecutive ones
+    const uint32_t per = (n_buckets + kSortThreads - 1u) / kSortThreads; // <= 5
+
+    for (uint64_t pass = begin; pass < end; pass += static_cast<uint64_t>(kCoarsePerThread) * kSortThreads) {
+        // 1. this thread's records, in registers
+        float4 rlo[kCoarsePerThread], rhi[kCoarsePerThread];
+        uint32_t bkt[kCoarsePerThread];
+#pragma unroll
+        for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+            const uint64_t s = pass + static_cast<uint64_t>(k) * kSortThreads + tid;
+            bkt[k] = 0xffffffffu;
+            rlo[k] = make_float4(0, 0, 0, 0);
+            rhi[k] = rlo[k];
+            if (s < end) {
+                const uint32_t f = flags[s];
+                const float2* bp = reinterpret_cast<const float2*>(aabb + 6 * s);
+                const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+                const uint32_t ent = entity_of_slot[s];
+                const uint32_t cls = class_of_slot[s];
+                const float b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+                if (is_body(f) && !body_is_large(g, b)) {
+                    bkt[k] = cell_of(g, b[0], b[1], b[2]) >> shift;
+                    rlo[k] = make_float4(b[0], b[1], b[2], __uint_as_float(ent));
+                    rhi[k] = make_float4(b[3], b[4], b[5], __uint_as_float((cls & 255u) | (bkt[k] << 8))); // bucket rides along
+                }
+            }
+        }
+        // 2. count per bucket
+        for (uint32_t k = tid; k < n_buckets; k += kSortThreads) lcur[k] = 0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kCoarsePerThread; ++k)
+            if (bkt[k] != 0xffffffffu) atomicAdd(&lcur[bkt[k]], 1u);
+        __syncthreads();
+        // 3. exclusive prefix over the buckets (consecutive entries per thread, wave scan, wave totals)
+        uint32_t cnt[5];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) {
+            const uint32_t e = tid * per + k;
+            cnt[k] = (k < per && e < n_buckets) ? lcur[e] : 0u;
+            sum += cnt[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= static_cast<uint32_t>(off)) incl += t;
+        }
+        if (lane == 63u) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t wv = 0; wv < wave; ++wv) base += wave_tot[wv];
+        if (tid == kSortThreads - 1u) s_total = base + incl;
+        uint32_t run = base + incl - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) {
+            const uint32_t e = tid * per + k;
+            if (k < per && e < n_buckets) lcur[e] = run;
+            run += cnt[k];
+        }
+        __syncthreads();
+        const uint32_t n_local = s_total;
+        // 4. rank of every record inside the pass (bucket-major); afterwards lcur[b] is the END of bucket b's local range
+        uint32_t rank[kCoarsePerThread];
+#pragma unroll
+        for (uint32_t k = 0; k < kCoarsePerThread; ++k) rank[k] = bkt[k] != 0xffffffffu ? atomicAdd(&lcur[bkt[k]], 1u) : 0xffffffffu;
+        __syncthreads();
+        // 5. through the window, in rank order
+        for (uint32_t w0 = 0; w0 < n_local; w0 += kCoarseWindow) {
+#pragma unroll
+            for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+                const uint32_t r = rank[k] - w0; // wraps for ranks below the window and for 0xffffffff
+                if (r < kCoarseWindow && rank[k] != 0xffffffffu) {
+                    window[2u * r] = rlo[k];
+                    window[2u * r + 1u] = rhi[k];
+                }
+            }
+            __syncthreads();
+            const uint32_t n_win = min(kCoarseWindow, n_local - w0);
+            for (uint32_t u = tid; u < 2u * n_win; u += kSortThreads) {
+                const uint32_t t = u >> 1;
+                float4 v = window[u];
+                const uint32_t tag = __float_as_uint(window[2u * t + 1u].w);
+                const uint32_t b = tag >> 8;
+                const uint32_t lstart = b ? lcur[b - 1u] : 0u;
+                const uint64_t gpos = static_cast<uint64_t>(goff[b]) + (w0 + t - lstart);
+                if (u & 1u) v.w = __uint_as_float(tag & 255u);
+                coarse[2ull * gpos + (u & 1u)] = v;
+            }
+            __syncthreads();
+        }
+        // 6. the next pass of this workgroup continues behind these records
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) {
+            const uint32_t e = tid * per + k;
+            if (k < per && e < n_buckets) goff[e] += cnt[k];
+        }
+        __syncthreads();
+    }
+}
+
+// Pass B of the LDS sort for ONE bucket, two sweeps over its coarse records: histogram over the bucket's cells, scan ->
+// cell_start, then every record to its cell's cursor.  `hist` holds 1 << shift words of LDS.
+template <uint32_t THREADS, bool COMPACT>
+__device__ __forceinline__ void fine_two_sweeps(uint32_t* hist, uint32_t* wave_tot, const GridParams& g, uint32_t cpb, uint32_t cell0,
+                                                uint32_t begin, uint32_t end, const float4* __restrict__ coarse,
+                                                float4* __restrict__ sorted, uint32_t* __restrict__ cell_start)
 {
     constexpr uint32_t RS = COMPACT ? 2u : 3u;
-    extern __shared__ uint32_t hist[]; // 1 << shift counters, then cursors
-    __shared__ uint32_t wave_tot[kFineThreads / 64];
-    const uint32_t cpb = 1u << shift;
-    const uint32_t bucket = blockIdx.x;
-    const GridParams g = acc->grid;
-    const uint32_t n_sorted = g.n_bodies - acc->n_large;
-    const uint32_t begin = offsets[static_cast<uint64_t>(bucket) * n_groups];
-    const uint32_t end = bucket + 1u < n_buckets ? offsets[static_cast<uint64_t>(bucket + 1u) * n_groups] : n_sorted;
-    const uint32_t cell0 = bucket << shift;
-    if (cell0 > g.n_cells + 2u) return; // beyond the cells in use: no records, and nobody reads cell_start there
-    for (uint32_t k = threadIdx.x; k < cpb; k += kFineThreads) hist[k] = 0;
+    for (uint32_t k = threadIdx.x; k < cpb; k += THREADS) hist[k] = 0;
     __syncthreads();
 #pragma unroll 4
-    for (uint32_t r = begin + threadIdx.x; r < end; r += kFineThreads) {
+    for (uint32_t r = begin + threadIdx.x; r < end; r += THREADS) {
         const float4 lo = coarse[static_cast<uint64_t>(RS) * r];
         atomicAdd(&hist[cell_of(g, lo.x, lo.y, lo.z) - cell0], 1u);
     }
     __syncthreads();
-    // exclusive scan of the cell counts: cpb / kFineThreads consecutive cells per thread
-    const uint32_t per = cpb / kFineThreads;
+    // exclusive scan of the cell counts: cpb / THREADS consecutive cells per thread
+    const uint32_t per = cpb / THREADS;
     uint32_t sum = 0;
     for (uint32_t k = 0; k < per; ++k) sum += hist[threadIdx.x * per + k];
     uint32_t incl = sum;
@@ -715,16 +834,123 @@ __global__ void __launch_bounds__(kFineThreads) k_sort_fine(const Accum* __restr
         run += cnt;
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < cpb; k += kFineThreads) cell_start[cell0 + k] = begin + hist[k];
+    for (uint32_t k = threadIdx.x; k < cpb; k += THREADS) cell_start[cell0 + k] = begin + hist[k];
     __syncthreads(); // (cursors are read by the atomics below; keep the plain reads above ahead of them)
 #pragma unroll 2
-    for (uint32_t r = begin + threadIdx.x; r < end; r += kFineThreads) {
+    for (uint32_t r = begin + threadIdx.x; r < end; r += THREADS) {
         const float4 lo = coarse[static_cast<uint64_t>(RS) * r];
         const float4 hi = coarse[static_cast<uint64_t>(RS) * r + 1];
         const uint32_t p = begin + atomicAdd(&hist[cell_of(g, lo.x, lo.y, lo.z) - cell0], 1u);
         sorted[static_cast<uint64_t>(RS) * p] = lo;
         sorted[static_cast<uint64_t>(RS) * p + 1] = hi;
         if (!COMPACT) sorted[3ull * p + 2] = coarse[3ull * r + 2];
+    }
+}
+
+template <bool COMPACT>
+__global__ void __launch_bounds__(kFineThreads) k_sort_fine(const Accum* __restrict__ acc, uint32_t shift, uint32_t n_buckets, uint32_t n_groups,
+                                                   const uint32_t* __restrict__ offsets, const float4* __restrict__ coarse,
+                                                   float4* __restrict__ sorted, uint32_t* __restrict__ cell_start)
+{
+    extern __shared__ uint32_t hist[]; // 1 << shift counters, then cursors
+    __shared__ uint32_t wave_tot[kFineThreads / 64];
+    const uint32_t cpb = 1u << shift;
+    const uint32_t bucket = blockIdx.x;
+    const GridParams g = acc->grid;
+    const uint32_t n_sorted = g.n_bodies - acc->n_large;
+    const uint32_t begin = offsets[static_cast<uint64_t>(bucket) * n_groups];
+    const uint32_t end = bucket + 1u < n_buckets ? offsets[static_cast<uint64_t>(bucket + 1u) * n_groups] : n_sorted;
+    const uint32_t cell0 = bucket << shift;
+    if (cell0 > g.n_cells + 2u) return; // beyond the cells in use: no records, and nobody reads cell_start there
+    fine_two_sweeps<kFineThreads, COMPACT>(hist, wave_tot, g, cpb, cell0, begin, end, coarse, sorted, cell_start);
+}
+
+// Pass B, one-sweep variant (32-byte records): a bucket of up to 8192 records — the usual case, a bucket is 4096 cells — is
+// read ONCE into registers (1024 threads x 8 records), counted and ranked by cell in LDS, passed through an LDS window in
+// rank order and written out as one contiguous stream.  k_sort_fine reads every record twice (the second sweep does not
+// hit L2: profiles/README.md) and stores each one from the thread that happens to hold it.  Bigger buckets (everything in
+// one spot) take the two-sweep path, in the same launch.
+__global__ void __launch_bounds__(kSortThreads, 1)
+    k_sort_fine_t(const Accum* __restrict__ acc, uint32_t shift, uint32_t n_buckets, uint32_t n_groups,
+                  const uint32_t* __restrict__ offsets, const float4* __restrict__ coarse, float4* __restrict__ sorted,
+                  uint32_t* __restrict__ cell_start, uint32_t window_records)
+{
+    extern __shared__ uint32_t hist[]; // 1 << shift counters / cursors, then the record window (16-byte aligned: 4 << shift bytes)
+    __shared__ uint32_t wave_tot[kSortThreads / 64];
+    const uint32_t cpb = 1u << shift;
+    float4* window = reinterpret_cast<float4*>(hist + cpb);
+    const uint32_t bucket = blockIdx.x;
+    const GridParams g = acc->grid;
+    const uint32_t n_sorted = g.n_bodies - acc->n_large;
+    const uint32_t begin = offsets[static_cast<uint64_t>(bucket) * n_groups];
+    const uint32_t end = bucket + 1u < n_buckets ? offsets[static_cast<uint64_t>(bucket + 1u) * n_groups] : n_sorted;
+    const uint32_t cell0 = bucket << shift;
+    if (cell0 > g.n_cells + 2u) return;
+    const uint32_t n_rec = end - begin;
+    if (n_rec > kCoarsePerThread * kSortThreads) { // workgroup-uniform
+        fine_two_sweeps<kSortThreads, true>(hist, wave_tot, g, cpb, cell0, begin, end, coarse, sorted, cell_start);
+        return;
+    }
+    const uint32_t tid = threadIdx.x;
+    float4 rlo[kCoarsePerThread], rhi[kCoarsePerThread];
+    uint32_t cell[kCoarsePerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+        const uint32_t r = k * kSortThreads + tid;
+        cell[k] = 0xffffffffu;
+        rlo[k] = make_float4(0, 0, 0, 0);
+        rhi[k] = rlo[k];
+        if (r < n_rec) {
+            rlo[k] = coarse[2ull * (begin + r)];
+            rhi[k] = coarse[2ull * (begin + r) + 1];
+            cell[k] = cell_of(g, rlo[k].x, rlo[k].y, rlo[k].z) - cell0;
+        }
+    }
+    for (uint32_t k = tid; k < cpb; k += kSortThreads) hist[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kCoarsePerThread; ++k)
+        if (cell[k] != 0xffffffffu) atomicAdd(&hist[cell[k]], 1u);
+    __syncthreads();
+    const uint32_t per = cpb / kSortThreads;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; ++k) sum += hist[tid * per + k];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if ((tid & 63u) >= static_cast<uint32_t>(off)) incl += t;
+    }
+    const uint32_t wave = tid >> 6;
+    if ((tid & 63u) == 63u) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t k = 0; k < wave; ++k) run += wave_tot[k];
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t cnt = hist[tid * per + k];
+        hist[tid * per + k] = run;
+        run += cnt;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < cpb; k += kSortThreads) cell_start[cell0 + k] = begin + hist[k];
+    __syncthreads();
+    uint32_t rank[kCoarsePerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kCoarsePerThread; ++k) rank[k] = cell[k] != 0xffffffffu ? atomicAdd(&hist[cell[k]], 1u) : 0xffffffffu;
+    for (uint32_t w0 = 0; w0 < n_rec; w0 += window_records) {
+#pragma unroll
+        for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+            const uint32_t r = rank[k] - w0;
+            if (r < window_records && rank[k] != 0xffffffffu) {
+                window[2u * r] = rlo[k];
+                window[2u * r + 1u] = rhi[k];
+            }
+        }
+        __syncthreads();
+        const uint32_t n_win = min(window_records, n_rec - w0);
+        float4* dst = sorted + 2ull * (begin + w0);
+        for (uint32_t u = tid; u < 2u * n_win; u += kSortThreads) dst[u] = window[u];
+        __syncthreads();
     }
 }
 
@@ -1228,6 +1454,9 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
     scan_epoch_ = 0;
     if (const char* e = std::getenv("BGE_BP_SCAN")) three_kernel_scan_ = std::atoi(e) == 3; // A/B: BGE_BP_SCAN=3 keeps the three-kernel scan
     if (const char* e = std::getenv("BGE_BP_PAIRS")) block_pairs_ = std::string(e) == "block";  // A/B: workgroup-granular pair search
+    sort_groups_ = kSortGroups;
+    if (const char* e = std::getenv("BGE_BP_SORT_GROUPS")) sort_groups_ = std::min<uint32_t>(kSortGroups, std::max(1, std::atoi(e))); // tests: several passes per workgroup at small n
+    if (const char* e = std::getenv("BGE_BP_COARSE")) transposed_coarse_ = std::string(e) != "scatter"; // A/B: per-thread scattered record writes
     if (const char* e = std::getenv("BGE_BP_RECORDS")) full_records_ = std::atoi(e) == 48;  // A/B: BGE_BP_RECORDS=48 keeps full records
     BP_TRY(hipMalloc(&sorted_slot_, std::max<uint64_t>(n_slots, 1) * 4));  // body rank inside its cell
     BP_TRY(hipMalloc(&sorted_aabb_, std::max<uint64_t>(n_slots, 1) * 48));
@@ -1249,6 +1478,26 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
         BP_TRY(hipMalloc(&sort_status_, (entries / kScanTile + 2) * 8));
         BP_TRY(hipMemset(sort_status_, 0, (entries / kScanTile + 2) * 8));
         BP_TRY(hipMalloc(&coarse_, std::max<uint64_t>(n_slots, 1) * 48));
+        // the transposing coarse pass wants 2 x buckets words + a 128 KiB window of LDS: more than the 64 KiB a kernel gets
+        // without asking, and more than some devices have
+        const size_t lds = (2 * static_cast<size_t>(sort_buckets_) + 16 + 4) * 4 + static_cast<size_t>(kCoarseWindow) * 32;
+        int dev = 0, lds_max = 0;
+        BP_TRY(hipGetDevice(&dev));
+        BP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        // k_sort_fine_t: 4 << shift bytes of counters + as large a window as fits (multiples of 1024 records, at most 4096)
+        const size_t fine_counters = (static_cast<size_t>(1) << sort_shift_) * 4;
+        fine_window_ = 0;
+        if (static_cast<size_t>(lds_max) > fine_counters + 1024) {
+            fine_window_ = static_cast<uint32_t>(std::min<size_t>(4096, ((static_cast<size_t>(lds_max) - fine_counters - 1024) / 32) / 1024 * 1024));
+        }
+        if (lds > static_cast<size_t>(lds_max) || fine_window_ == 0 ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_coarse_t), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fine_t), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(fine_counters + static_cast<size_t>(fine_window_) * 32)) != hipSuccess) {
+            (void)hipGetLastError();
+            transposed_coarse_ = false;
+        }
     }
     return BGE_OK;
 }
@@ -1287,7 +1536,7 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
     hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(kParamsThreads), 0, stream, acc, table_size_, bounds_blocks);
     if (lds_sort_) {
-        const uint32_t groups = std::min<uint32_t>(kSortGroups, blocks_for(n, kSortThreads));
+        const uint32_t groups = std::min<uint32_t>(sort_groups_, blocks_for(n, kSortThreads));
         const uint64_t chunk = (n + groups - 1) / groups;
         uint32_t* matrix = static_cast<uint32_t*>(sort_matrix_);
         uint32_t* offsets = static_cast<uint32_t*>(sort_offsets_);
@@ -1300,7 +1549,13 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
         hipLaunchKernelGGL(k_scan_lookback, dim3(blocks_for(n_scan, kScanTile)), dim3(256), 0, stream, matrix, offsets,
                            static_cast<unsigned long long*>(sort_status_), acc, n_scan, scan_epoch_, 0u);
         const size_t fine_lds = (static_cast<size_t>(1) << sort_shift_) * 4;
-        if (compact_records) {
+        if (compact_records && transposed_coarse_) {
+            const size_t lds = (2 * static_cast<size_t>(sort_buckets_) + 16 + 4) * 4 + static_cast<size_t>(kCoarseWindow) * 32;
+            hipLaunchKernelGGL(k_sort_coarse_t, dim3(groups), dim3(kSortThreads), lds, stream, n, chunk, w.flags, w.aabb, acc, sort_shift_,
+                               sort_buckets_, offsets, palette->class_of_slot, entity_of_slot, coarse);
+            hipLaunchKernelGGL(k_sort_fine_t, dim3(sort_buckets_), dim3(kSortThreads), fine_lds + static_cast<size_t>(fine_window_) * 32, stream, acc,
+                               sort_shift_, sort_buckets_, groups, offsets, coarse, sorted, cell_start, fine_window_);
+        } else if (compact_records) {
             hipLaunchKernelGGL(k_sort_coarse<true>, dim3(groups), dim3(kSortThreads), 0, stream, n, chunk, w.flags, w.aabb, acc, sort_shift_,
                                sort_buckets_, offsets, w.group, w.mask, palette->class_of_slot, entity_of_slot, coarse);
             hipLaunchKernelGGL(k_sort_fine<true>, dim3(sort_buckets_), dim3(kFineThreads), fine_lds, stream, acc, sort_shift_, sort_buckets_, groups,

@@ -823,6 +823,7 @@ def test_pinned_host_buffers_and_identity_layout_downloads():
     {"BGE_BP_SORT": "atomic"},                              # the global-atomic counting sort (tables beyond 32 M cells)
     {"BGE_BP_SORT": "atomic", "BGE_BP_SCAN": "3"},          # ... with the three-kernel scan
     {"BGE_BP_RECORDS": "48"},                               # full records (more than 255 filter classes; slab search)
+    {"BGE_BP_COARSE": "scatter"},                           # coarse pass with per-thread scattered writes (32-byte records)
     {"BGE_BP_PAIRS": "block"},                              # workgroup-granular pair search
     {"BGE_BP_PAIRS": "block", "BGE_BP_RECORDS": "48", "BGE_BP_SORT": "atomic"},
 ])
@@ -851,6 +852,34 @@ def test_every_broadphase_code_path_gives_the_same_pairs(env, monkeypatch):
         run_world(w, wl, 2, flags=B.TICK_ALL | B.TICK_BROADPHASE)
         got = w.pairs(cap=64 * n)
     assert np.array_equal(got, ref.pairs("sweep"))
+
+
+@pytest.mark.parametrize("coarse", ["transposed", "scatter"])
+def test_coarse_sort_with_several_passes_per_workgroup(coarse, monkeypatch):
+    """The coarse pass of the LDS sort when a workgroup's chunk exceeds one pass of 8192 slots (production: more than
+    4.2 M slots per world; here BGE_BP_SORT_GROUPS=3 gives 3 workgroups x 3 passes at 70 k bodies): the bucket-ordered
+    write-out (k_sort_coarse_t: records in registers, ranks and an LDS window) and the scattered one, against the
+    oracle's pair set."""
+    monkeypatch.setenv("BGE_BP_SORT_GROUPS", "3")
+    if coarse == "scatter":
+        monkeypatch.setenv("BGE_BP_COARSE", "scatter")
+    n = 70_000
+    wl = _cube(n, 68.0, seed=21)
+    rng = np.random.default_rng(2)
+    wl.body_type = rng.choice([0, 1, 1, 1, 2, 255], n).astype(np.uint8)
+    layer = rng.choice([1, 2, 4], n).astype(np.uint32)
+    mask = rng.choice([0xFFFFFFFF, 3, 6], n).astype(np.uint32)
+    kw = dict(layer=layer, mask=mask)
+    ref = run_oracle(build_oracle(wl, aabbs=True, **kw), wl, 2)
+    want = ref.pairs("sweep")
+    with B.World(pair_capacity=16 * n) as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, **kw)
+        run_world(w, wl, 2, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+        got = w.pairs(cap=16 * n)
+    assert len(want) > n // 2
+    assert np.array_equal(got, want)
 
 
 def test_more_than_255_filter_classes_fall_back_to_full_records():
