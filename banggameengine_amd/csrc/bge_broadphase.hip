@@ -676,14 +676,23 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_coarse(uint64_t n_slots, 
 // (measured against linear writes).  Here a workgroup keeps a pass of 8192 slots in REGISTERS (8 records per
 // thread), counts and ranks them by bucket in LDS, passes them through an LDS window ordered by rank and writes the window
 // out with consecutive lanes on consecutive float4s: a (workgroup, bucket) run of ~15 records becomes one ~480-byte write.
-constexpr uint32_t kCoarsePerThread = 8;
-constexpr uint32_t kCoarseWindow = 4096; // records in the LDS window (128 KiB); one workgroup per CU (it needs ~100 VGPRs anyway)
+template <bool COMPACT>
+struct SortT {
+    static constexpr uint32_t RS = COMPACT ? 2u : 3u;          // float4 per record
+    static constexpr uint32_t PT = COMPACT ? 8u : 4u;          // records a thread holds in registers
+    static constexpr uint32_t kPass = PT * kSortThreads;       // records per pass of a workgroup
+    static constexpr uint32_t kWindow = COMPACT ? 4096u : 2048u; // records in the coarse pass's LDS window (128 / 96 KiB)
+};
+template <bool COMPACT>
 __global__ void __launch_bounds__(kSortThreads, 1)
     k_sort_coarse_t(uint64_t n_slots, uint64_t chunk, const uint32_t* __restrict__ flags, const float* __restrict__ aabb,
                     const Accum* __restrict__ acc, uint32_t shift, uint32_t n_buckets, const uint32_t* __restrict__ offsets,
+                    const uint32_t* __restrict__ group, const uint32_t* __restrict__ mask,
                     const uint32_t* __restrict__ class_of_slot, const uint32_t* __restrict__ entity_of_slot,
                     float4* __restrict__ coarse)
 {
+    using T = SortT<COMPACT>;
+    constexpr uint32_t RS = T::RS, PT = T::PT;
     extern __shared__ uint32_t lds_u32[];
     uint32_t* lcur = lds_u32;                       // [n_buckets] counts -> exclusive prefix -> running cursor
     uint32_t* goff = lds_u32 + n_buckets;           // [n_buckets] this workgroup's next free position in each bucket
@@ -698,27 +707,35 @@ __global__ void __launch_bounds__(kSortThreads, 1)
     // entries of lcur / goff this thread owns in the scan: `per` consecutive ones
     const uint32_t per = (n_buckets + kSortThreads - 1u) / kSortThreads; // <= 5
 
-    for (uint64_t pass = begin; pass < end; pass += static_cast<uint64_t>(kCoarsePerThread) * kSortThreads) {
+    for (uint64_t pass = begin; pass < end; pass += T::kPass) {
         // 1. this thread's records, in registers
-        float4 rlo[kCoarsePerThread], rhi[kCoarsePerThread];
-        uint32_t bkt[kCoarsePerThread];
+        float4 rec[PT][RS];
+        uint32_t bkt[PT];
 #pragma unroll
-        for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+        for (uint32_t k = 0; k < PT; ++k) {
             const uint64_t s = pass + static_cast<uint64_t>(k) * kSortThreads + tid;
             bkt[k] = 0xffffffffu;
-            rlo[k] = make_float4(0, 0, 0, 0);
-            rhi[k] = rlo[k];
+#pragma unroll
+            for (uint32_t q = 0; q < RS; ++q) rec[k][q] = make_float4(0, 0, 0, 0);
             if (s < end) {
                 const uint32_t f = flags[s];
                 const float2* bp = reinterpret_cast<const float2*>(aabb + 6 * s);
                 const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
                 const uint32_t ent = entity_of_slot[s];
-                const uint32_t cls = class_of_slot[s];
+                const uint32_t extra = COMPACT ? class_of_slot[s] : group[s];
+                const uint32_t msk = COMPACT ? 0u : mask[s];
                 const float b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
                 if (is_body(f) && !body_is_large(g, b)) {
-                    bkt[k] = cell_of(g, b[0], b[1], b[2]) >> shift;
-                    rlo[k] = make_float4(b[0], b[1], b[2], __uint_as_float(ent));
-                    rhi[k] = make_float4(b[3], b[4], b[5], __uint_as_float((cls & 255u) | (bkt[k] << 8))); // bucket rides along
+                    const uint32_t c = cell_of(g, b[0], b[1], b[2]);
+                    bkt[k] = c >> shift;
+                    rec[k][0] = make_float4(b[0], b[1], b[2], __uint_as_float(ent));
+                    if (COMPACT) {
+                        rec[k][1] = make_float4(b[3], b[4], b[5], __uint_as_float((extra & 255u) | (bkt[k] << 8))); // the bucket rides along
+                    } else {
+                        rec[k][1] = make_float4(b[3], b[4], b[5], __uint_as_float(c)); // the bucket is c >> shift
+                        rec[k][RS - 1u] = make_float4(__uint_as_float(extra), __uint_as_float(msk), __uint_as_float((f & kTypeMask) == 1u ? 1u : 0u),
+                                                      __uint_as_float(static_cast<uint32_t>(s)));
+                    }
                 }
             }
         }
@@ -726,7 +743,7 @@ __global__ void __launch_bounds__(kSortThreads, 1)
         for (uint32_t k = tid; k < n_buckets; k += kSortThreads) lcur[k] = 0;
         __syncthreads();
 #pragma unroll
-        for (uint32_t k = 0; k < kCoarsePerThread; ++k)
+        for (uint32_t k = 0; k < PT; ++k)
             if (bkt[k] != 0xffffffffu) atomicAdd(&lcur[bkt[k]], 1u);
         __syncthreads();
         // 3. exclusive prefix over the buckets (consecutive entries per thread, wave scan, wave totals)
@@ -759,31 +776,31 @@ __global__ void __launch_bounds__(kSortThreads, 1)
         __syncthreads();
         const uint32_t n_local = s_total;
         // 4. rank of every record inside the pass (bucket-major); afterwards lcur[b] is the END of bucket b's local range
-        uint32_t rank[kCoarsePerThread];
+        uint32_t rank[PT];
 #pragma unroll
-        for (uint32_t k = 0; k < kCoarsePerThread; ++k) rank[k] = bkt[k] != 0xffffffffu ? atomicAdd(&lcur[bkt[k]], 1u) : 0xffffffffu;
+        for (uint32_t k = 0; k < PT; ++k) rank[k] = bkt[k] != 0xffffffffu ? atomicAdd(&lcur[bkt[k]], 1u) : 0xffffffffu;
         __syncthreads();
         // 5. through the window, in rank order
-        for (uint32_t w0 = 0; w0 < n_local; w0 += kCoarseWindow) {
+        for (uint32_t w0 = 0; w0 < n_local; w0 += T::kWindow) {
 #pragma unroll
-            for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+            for (uint32_t k = 0; k < PT; ++k) {
                 const uint32_t r = rank[k] - w0; // wraps for ranks below the window and for 0xffffffff
-                if (r < kCoarseWindow && rank[k] != 0xffffffffu) {
-                    window[2u * r] = rlo[k];
-                    window[2u * r + 1u] = rhi[k];
+                if (r < T::kWindow && rank[k] != 0xffffffffu) {
+#pragma unroll
+                    for (uint32_t q = 0; q < RS; ++q) window[RS * r + q] = rec[k][q];
                 }
             }
             __syncthreads();
-            const uint32_t n_win = min(kCoarseWindow, n_local - w0);
-            for (uint32_t u = tid; u < 2u * n_win; u += kSortThreads) {
-                const uint32_t t = u >> 1;
+            const uint32_t n_win = min(T::kWindow, n_local - w0);
+            for (uint32_t u = tid; u < RS * n_win; u += kSortThreads) {
+                const uint32_t t = u / RS, part = u - t * RS;
                 float4 v = window[u];
-                const uint32_t tag = __float_as_uint(window[2u * t + 1u].w);
-                const uint32_t b = tag >> 8;
+                const uint32_t tag = __float_as_uint(window[RS * t + 1u].w);
+                const uint32_t b = COMPACT ? tag >> 8 : tag >> shift;
                 const uint32_t lstart = b ? lcur[b - 1u] : 0u;
                 const uint64_t gpos = static_cast<uint64_t>(goff[b]) + (w0 + t - lstart);
-                if (u & 1u) v.w = __uint_as_float(tag & 255u);
-                coarse[2ull * gpos + (u & 1u)] = v;
+                if (COMPACT && part == 1u) v.w = __uint_as_float(tag & 255u);
+                coarse[static_cast<uint64_t>(RS) * gpos + part] = v;
             }
             __syncthreads();
         }
@@ -870,11 +887,14 @@ __global__ void __launch_bounds__(kFineThreads) k_sort_fine(const Accum* __restr
 // rank order and written out as one contiguous stream.  k_sort_fine reads every record twice (the second sweep does not
 // hit L2: profiles/README.md) and stores each one from the thread that happens to hold it.  Bigger buckets (everything in
 // one spot) take the two-sweep path, in the same launch.
+template <bool COMPACT>
 __global__ void __launch_bounds__(kSortThreads, 1)
     k_sort_fine_t(const Accum* __restrict__ acc, uint32_t shift, uint32_t n_buckets, uint32_t n_groups,
                   const uint32_t* __restrict__ offsets, const float4* __restrict__ coarse, float4* __restrict__ sorted,
                   uint32_t* __restrict__ cell_start, uint32_t window_records)
 {
+    using T = SortT<COMPACT>;
+    constexpr uint32_t RS = T::RS, PT = T::PT;
     extern __shared__ uint32_t hist[]; // 1 << shift counters / cursors, then the record window (16-byte aligned: 4 << shift bytes)
     __shared__ uint32_t wave_tot[kSortThreads / 64];
     const uint32_t cpb = 1u << shift;
@@ -887,29 +907,29 @@ __global__ void __launch_bounds__(kSortThreads, 1)
     const uint32_t cell0 = bucket << shift;
     if (cell0 > g.n_cells + 2u) return;
     const uint32_t n_rec = end - begin;
-    if (n_rec > kCoarsePerThread * kSortThreads) { // workgroup-uniform
-        fine_two_sweeps<kSortThreads, true>(hist, wave_tot, g, cpb, cell0, begin, end, coarse, sorted, cell_start);
+    if (n_rec > T::kPass) { // workgroup-uniform
+        fine_two_sweeps<kSortThreads, COMPACT>(hist, wave_tot, g, cpb, cell0, begin, end, coarse, sorted, cell_start);
         return;
     }
     const uint32_t tid = threadIdx.x;
-    float4 rlo[kCoarsePerThread], rhi[kCoarsePerThread];
-    uint32_t cell[kCoarsePerThread];
+    float4 rec[PT][RS];
+    uint32_t cell[PT];
 #pragma unroll
-    for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+    for (uint32_t k = 0; k < PT; ++k) {
         const uint32_t r = k * kSortThreads + tid;
         cell[k] = 0xffffffffu;
-        rlo[k] = make_float4(0, 0, 0, 0);
-        rhi[k] = rlo[k];
+#pragma unroll
+        for (uint32_t q = 0; q < RS; ++q) rec[k][q] = make_float4(0, 0, 0, 0);
         if (r < n_rec) {
-            rlo[k] = coarse[2ull * (begin + r)];
-            rhi[k] = coarse[2ull * (begin + r) + 1];
-            cell[k] = cell_of(g, rlo[k].x, rlo[k].y, rlo[k].z) - cell0;
+#pragma unroll
+            for (uint32_t q = 0; q < RS; ++q) rec[k][q] = coarse[static_cast<uint64_t>(RS) * (begin + r) + q];
+            cell[k] = cell_of(g, rec[k][0].x, rec[k][0].y, rec[k][0].z) - cell0;
         }
     }
     for (uint32_t k = tid; k < cpb; k += kSortThreads) hist[k] = 0;
     __syncthreads();
 #pragma unroll
-    for (uint32_t k = 0; k < kCoarsePerThread; ++k)
+    for (uint32_t k = 0; k < PT; ++k)
         if (cell[k] != 0xffffffffu) atomicAdd(&hist[cell[k]], 1u);
     __syncthreads();
     const uint32_t per = cpb / kSortThreads;
@@ -934,22 +954,22 @@ __global__ void __launch_bounds__(kSortThreads, 1)
     __syncthreads();
     for (uint32_t k = tid; k < cpb; k += kSortThreads) cell_start[cell0 + k] = begin + hist[k];
     __syncthreads();
-    uint32_t rank[kCoarsePerThread];
+    uint32_t rank[PT];
 #pragma unroll
-    for (uint32_t k = 0; k < kCoarsePerThread; ++k) rank[k] = cell[k] != 0xffffffffu ? atomicAdd(&hist[cell[k]], 1u) : 0xffffffffu;
+    for (uint32_t k = 0; k < PT; ++k) rank[k] = cell[k] != 0xffffffffu ? atomicAdd(&hist[cell[k]], 1u) : 0xffffffffu;
     for (uint32_t w0 = 0; w0 < n_rec; w0 += window_records) {
 #pragma unroll
-        for (uint32_t k = 0; k < kCoarsePerThread; ++k) {
+        for (uint32_t k = 0; k < PT; ++k) {
             const uint32_t r = rank[k] - w0;
             if (r < window_records && rank[k] != 0xffffffffu) {
-                window[2u * r] = rlo[k];
-                window[2u * r + 1u] = rhi[k];
+#pragma unroll
+                for (uint32_t q = 0; q < RS; ++q) window[RS * r + q] = rec[k][q];
             }
         }
         __syncthreads();
         const uint32_t n_win = min(window_records, n_rec - w0);
-        float4* dst = sorted + 2ull * (begin + w0);
-        for (uint32_t u = tid; u < 2u * n_win; u += kSortThreads) dst[u] = window[u];
+        float4* dst = sorted + static_cast<uint64_t>(RS) * (begin + w0);
+        for (uint32_t u = tid; u < RS * n_win; u += kSortThreads) dst[u] = window[u];
         __syncthreads();
     }
 }
@@ -1480,21 +1500,27 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
         BP_TRY(hipMalloc(&coarse_, std::max<uint64_t>(n_slots, 1) * 48));
         // the transposing coarse pass wants 2 x buckets words + a 128 KiB window of LDS: more than the 64 KiB a kernel gets
         // without asking, and more than some devices have
-        const size_t lds = (2 * static_cast<size_t>(sort_buckets_) + 16 + 4) * 4 + static_cast<size_t>(kCoarseWindow) * 32;
+        const size_t base_lds = (2 * static_cast<size_t>(sort_buckets_) + 16 + 4) * 4;
+        const size_t lds_c[2] = {base_lds + SortT<false>::kWindow * 48, base_lds + SortT<true>::kWindow * 32};
         int dev = 0, lds_max = 0;
         BP_TRY(hipGetDevice(&dev));
         BP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-        // k_sort_fine_t: 4 << shift bytes of counters + as large a window as fits (multiples of 1024 records, at most 4096)
+        // k_sort_fine_t: 4 << shift bytes of counters + as large a window as fits (multiples of 1024 records, at most one pass)
         const size_t fine_counters = (static_cast<size_t>(1) << sort_shift_) * 4;
-        fine_window_ = 0;
-        if (static_cast<size_t>(lds_max) > fine_counters + 1024) {
-            fine_window_ = static_cast<uint32_t>(std::min<size_t>(4096, ((static_cast<size_t>(lds_max) - fine_counters - 1024) / 32) / 1024 * 1024));
+        bool fits = lds_c[0] <= static_cast<size_t>(lds_max) && lds_c[1] <= static_cast<size_t>(lds_max);
+        for (int c = 0; c < 2; ++c) {
+            const size_t rec_bytes = c ? 32 : 48, pass = c ? SortT<true>::kPass : SortT<false>::kPass;
+            fine_window_[c] = 0;
+            if (static_cast<size_t>(lds_max) > fine_counters + 1024) {
+                fine_window_[c] = static_cast<uint32_t>(std::min<size_t>(pass, ((static_cast<size_t>(lds_max) - fine_counters - 1024) / rec_bytes) / 1024 * 1024));
+            }
+            fits = fits && fine_window_[c] != 0;
         }
-        if (lds > static_cast<size_t>(lds_max) || fine_window_ == 0 ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_coarse_t), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_fine_t), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(fine_counters + static_cast<size_t>(fine_window_) * 32)) != hipSuccess) {
+        auto ask = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess; };
+        if (!fits || !ask(reinterpret_cast<const void*>(&k_sort_coarse_t<true>), lds_c[1]) ||
+            !ask(reinterpret_cast<const void*>(&k_sort_coarse_t<false>), lds_c[0]) ||
+            !ask(reinterpret_cast<const void*>(&k_sort_fine_t<true>), fine_counters + static_cast<size_t>(fine_window_[1]) * 32) ||
+            !ask(reinterpret_cast<const void*>(&k_sort_fine_t<false>), fine_counters + static_cast<size_t>(fine_window_[0]) * 48)) {
             (void)hipGetLastError();
             transposed_coarse_ = false;
         }
@@ -1549,12 +1575,21 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
         hipLaunchKernelGGL(k_scan_lookback, dim3(blocks_for(n_scan, kScanTile)), dim3(256), 0, stream, matrix, offsets,
                            static_cast<unsigned long long*>(sort_status_), acc, n_scan, scan_epoch_, 0u);
         const size_t fine_lds = (static_cast<size_t>(1) << sort_shift_) * 4;
-        if (compact_records && transposed_coarse_) {
-            const size_t lds = (2 * static_cast<size_t>(sort_buckets_) + 16 + 4) * 4 + static_cast<size_t>(kCoarseWindow) * 32;
-            hipLaunchKernelGGL(k_sort_coarse_t, dim3(groups), dim3(kSortThreads), lds, stream, n, chunk, w.flags, w.aabb, acc, sort_shift_,
-                               sort_buckets_, offsets, palette->class_of_slot, entity_of_slot, coarse);
-            hipLaunchKernelGGL(k_sort_fine_t, dim3(sort_buckets_), dim3(kSortThreads), fine_lds + static_cast<size_t>(fine_window_) * 32, stream, acc,
-                               sort_shift_, sort_buckets_, groups, offsets, coarse, sorted, cell_start, fine_window_);
+        if (transposed_coarse_) {
+            const uint32_t* no_u32 = nullptr;
+            const size_t base_lds = (2 * static_cast<size_t>(sort_buckets_) + 16 + 4) * 4;
+            if (compact_records) {
+                hipLaunchKernelGGL(k_sort_coarse_t<true>, dim3(groups), dim3(kSortThreads), base_lds + SortT<true>::kWindow * 32, stream, n, chunk,
+                                   w.flags, w.aabb, acc, sort_shift_, sort_buckets_, offsets, no_u32, no_u32, palette->class_of_slot,
+                                   entity_of_slot, coarse);
+                hipLaunchKernelGGL(k_sort_fine_t<true>, dim3(sort_buckets_), dim3(kSortThreads), fine_lds + static_cast<size_t>(fine_window_[1]) * 32,
+                                   stream, acc, sort_shift_, sort_buckets_, groups, offsets, coarse, sorted, cell_start, fine_window_[1]);
+            } else {
+                hipLaunchKernelGGL(k_sort_coarse_t<false>, dim3(groups), dim3(kSortThreads), base_lds + SortT<false>::kWindow * 48, stream, n, chunk,
+                                   w.flags, w.aabb, acc, sort_shift_, sort_buckets_, offsets, w.group, w.mask, no_u32, entity_of_slot, coarse);
+                hipLaunchKernelGGL(k_sort_fine_t<false>, dim3(sort_buckets_), dim3(kSortThreads), fine_lds + static_cast<size_t>(fine_window_[0]) * 48,
+                                   stream, acc, sort_shift_, sort_buckets_, groups, offsets, coarse, sorted, cell_start, fine_window_[0]);
+            }
         } else if (compact_records) {
             hipLaunchKernelGGL(k_sort_coarse<true>, dim3(groups), dim3(kSortThreads), 0, stream, n, chunk, w.flags, w.aabb, acc, sort_shift_,
                                sort_buckets_, offsets, w.group, w.mask, palette->class_of_slot, entity_of_slot, coarse);

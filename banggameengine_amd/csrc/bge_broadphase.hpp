@@ -60,7 +60,7 @@ private:
     void *sort_matrix_ = nullptr, *sort_offsets_ = nullptr, *sort_status_ = nullptr, *coarse_ = nullptr;
     bool block_pairs_ = false;
     uint32_t sort_groups_ = 512;    // chunk workgroups of the coarse passes (BGE_BP_SORT_GROUPS lowers it: tests)
-    uint32_t fine_window_ = 0;      // records in k_sort_fine_t's LDS window
+    uint32_t fine_window_[2] = {0, 0}; // records in k_sort_fine_t's LDS window: [0] 48-byte records, [1] 32-byte records
     bool transposed_coarse_ = true; // k_sort_coarse_t (bucket-ordered write-out) instead of k_sort_coarse<true>; BGE_BP_COARSE=scatter for A/B
     void* sorted_slot_ = nullptr; // uint32[n_slots]
     void* sorted_aabb_ = nullptr; // float4[n_slots][3] sorted records

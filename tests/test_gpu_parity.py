@@ -854,7 +854,7 @@ def test_every_broadphase_code_path_gives_the_same_pairs(env, monkeypatch):
     assert np.array_equal(got, ref.pairs("sweep"))
 
 
-@pytest.mark.parametrize("coarse", ["transposed", "scatter"])
+@pytest.mark.parametrize("coarse", ["transposed", "scatter", "transposed-48"])
 def test_coarse_sort_with_several_passes_per_workgroup(coarse, monkeypatch):
     """The coarse pass of the LDS sort when a workgroup's chunk exceeds one pass of 8192 slots (production: more than
     4.2 M slots per world; here BGE_BP_SORT_GROUPS=3 gives 3 workgroups x 3 passes at 70 k bodies): the bucket-ordered
@@ -863,6 +863,8 @@ def test_coarse_sort_with_several_passes_per_workgroup(coarse, monkeypatch):
     monkeypatch.setenv("BGE_BP_SORT_GROUPS", "3")
     if coarse == "scatter":
         monkeypatch.setenv("BGE_BP_COARSE", "scatter")
+    if coarse == "transposed-48":
+        monkeypatch.setenv("BGE_BP_RECORDS", "48")   # 48-byte records: 4 per thread, 4096 per pass
     n = 70_000
     wl = _cube(n, 68.0, seed=21)
     rng = np.random.default_rng(2)
