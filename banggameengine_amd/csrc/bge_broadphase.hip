@@ -85,23 +85,6 @@ __device__ __forceinline__ uint32_t f2ord(float f)
 }
 __device__ __forceinline__ bool is_body(uint32_t f) { return (f & kValid) && (f & kTypeMask) != 0; }
 
-__global__ void k_bp_reset(Accum* acc)
-{
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < kHistShards * kExtentBins; b += gridDim.x * blockDim.x) (&acc->extent_hist[0][0])[b] = 0;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (int a = 0; a < 3; ++a) {
-            acc->min_bits[a] = 0xffffffffu;
-            acc->max_bits[a] = 0u;
-        }
-        acc->n_bodies = 0;
-        acc->n_large = 0;
-        acc->n_pairs = 0;
-        acc->n_pairs_kept = 0;
-        acc->scan_ticket = 0;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < kShards) acc->shard_count[threadIdx.x][0] = 0;
-}
-
 __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint32_t* __restrict__ flags,
                                                    const float* __restrict__ aabb, Accum* acc)
 {
@@ -239,8 +222,19 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
         for (uint32_t b = threadIdx.x; b < kExtentBins; b += kParamsThreads) {
             uint32_t t = 0;
 #pragma unroll
-            for (uint32_t c = 0; c < kHistShards; ++c) t += acc->extent_hist[c][b];
+            for (uint32_t c = 0; c < kHistShards; ++c) {
+                t += acc->extent_hist[c][b];
+                acc->extent_hist[c][b] = 0; // consumed: ready for the next run's k_bp_bounds (there is no reset kernel)
+            }
             below[b] = t; // the totals, for the moment
+        }
+        // the counters the REST of this run accumulates into (every kernel that touches them is launched after this one)
+        if (threadIdx.x < kShards) acc->shard_count[threadIdx.x][0] = 0;
+        if (threadIdx.x == kShards) {
+            acc->n_large = 0;
+            acc->n_pairs = 0;
+            acc->n_pairs_kept = 0;
+            acc->scan_ticket = 0;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -1557,7 +1551,6 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     const uint32_t scan_blocks = blocks_for(scan_n, kScanBlock);
     const uint32_t slot_blocks = blocks_for(n, 256);
 
-    hipLaunchKernelGGL(k_bp_reset, dim3(kHistShards), dim3(256), 0, stream, acc);
     const uint32_t bounds_blocks = std::min<uint32_t>(slot_blocks, kBoundsBlocks);
     hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
     hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(kParamsThreads), 0, stream, acc, table_size_, bounds_blocks);
@@ -1645,7 +1638,7 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     } else {
         hipLaunchKernelGGL((k_bp_pairs<false, false>), pair_grid, dim3(256), 0, stream, acc, cell_start, sorted, no_table, sink);
     }
-    hipLaunchKernelGGL(k_bp_large, dim3(std::min<uint32_t>(slot_blocks, 4096)), dim3(256), 0, stream, n, acc, large_list,
+    hipLaunchKernelGGL(k_bp_large, dim3(std::min<uint32_t>(slot_blocks, 1024)), dim3(256), 0, stream, n, acc, large_list,
                        body_cell, w.aabb, w.flags, w.group, w.mask, entity_of_slot, sink);
     // The pairs now sit in 64 shard slices; the compact list is built on demand (compact()): a tick whose pairs nobody
     // downloads does not pay the 49 us copy (4 M bodies, 12.6 M pairs).
