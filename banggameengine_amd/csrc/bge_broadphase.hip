@@ -72,6 +72,9 @@ struct Accum {
     // few sizes, so every workgroup of k_bp_bounds ends with an atomic on the SAME bin — 2048 of them on one word cost
     // ~20 us of the kernel's 41 (one word sustains ~10^8 atomics/s); k_bp_params adds the copies up
     uint32_t extent_hist[kHistShards][kExtentBins];
+    // widest extent seen in each bin (float bits; extents are positive), same copies: the cell size is the widest SMALL
+    // body, not the upper edge of its bin — edges are 19-25 % apart and the number of AABB tests grows with the cube of the cell
+    uint32_t extent_max[kHistShards][kExtentBins];
     uint32_t scan_ticket;              // tile tickets of k_scan_lookback (dispatch order)
     uint32_t scan_error;               // a look-back gave up (never observed; keeps a logic error from hanging the GPU)
 };
@@ -89,9 +92,13 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
                                                    const float* __restrict__ aabb, Accum* acc)
 {
     __shared__ uint32_t hist[kExtentBins];
+    __shared__ uint32_t hmax[kExtentBins];
     __shared__ float red[4][6];
     __shared__ uint32_t red_cnt[4];
-    for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) hist[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) {
+        hist[k] = 0;
+        hmax[k] = 0;
+    }
     __syncthreads();
 
     float mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -134,6 +141,7 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
                 mx[2] = fmaxf(mx[2], b2[u].y);
                 const float e = fmaxf(fmaxf(b1[u].y - b0[u].x, b2[u].x - b0[u].y), b2[u].y - b1[u].x);
                 my_bin = (e > 0.0f && e < INFINITY) ? extent_bin(e) : 0u;
+                if (e > 0.0f && e < INFINITY) atomicMax(&hmax[my_bin], __float_as_uint(e)); // (lanes of a bin serialise: ~64 cycles)
                 have_bin = true;
                 cnt += 1;
             }
@@ -181,7 +189,10 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
     }
     for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) {
         const uint32_t h = hist[k];
-        if (h) atomicAdd(&acc->extent_hist[blockIdx.x % kHistShards][k], h);
+        if (h) {
+            atomicAdd(&acc->extent_hist[blockIdx.x % kHistShards][k], h);
+            if (hmax[k]) atomicMax(&acc->extent_max[blockIdx.x % kHistShards][k], hmax[k]);
+        }
     }
 }
 
@@ -203,6 +214,7 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
 {
     constexpr uint32_t kWaves = kParamsThreads / 64;
     __shared__ uint32_t below[kExtentBins + 1]; // exclusive prefix: bodies in bins < b
+    __shared__ uint32_t binmax[kExtentBins];    // widest extent in the bin (float bits)
     __shared__ float red[kWaves][6];
     __shared__ uint32_t red_cnt[kWaves];
     const uint32_t lane = threadIdx.x & 63u;
@@ -220,13 +232,16 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
             cnt += acc->part_count[b];
         }
         for (uint32_t b = threadIdx.x; b < kExtentBins; b += kParamsThreads) {
-            uint32_t t = 0;
+            uint32_t t = 0, m = 0;
 #pragma unroll
             for (uint32_t c = 0; c < kHistShards; ++c) {
                 t += acc->extent_hist[c][b];
+                m = max(m, acc->extent_max[c][b]);
                 acc->extent_hist[c][b] = 0; // consumed: ready for the next run's k_bp_bounds (there is no reset kernel)
+                acc->extent_max[c][b] = 0;
             }
             below[b] = t; // the totals, for the moment
+            binmax[b] = m;
         }
         // the counters the REST of this run accumulates into (every kernel that touches them is launched after this one)
         if (threadIdx.x < kShards) acc->shard_count[threadIdx.x][0] = 0;
@@ -333,11 +348,18 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
             best_bin = ob;
         }
     }
+    // the widest body below the chosen edge: it, not the edge, sets the cell size
+    best_bin = __shfl(best_bin, 0, 64);
+    uint32_t widest = 0;
+    for (uint32_t b = lane; b <= best_bin && b < kExtentBins; b += 64) widest = max(widest, binmax[b]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) widest = max(widest, static_cast<uint32_t>(__shfl_xor(widest, off, 64)));
     if (lane != 0) return;
 
     GridParams g;
     g.n_bodies = n;
-    float cell = n ? extent_bin_upper(best_bin) : 1.0f;
+    // small_limit = cell * (1 - 2^-20) must not fall below the widest small body: cell = widest * (1 + 2^-19)
+    float cell = n ? (widest ? __uint_as_float(widest) * 1.0000019073486328f : extent_bin_upper(best_bin)) : 1.0f;
     cell = fminf(fmaxf(cell, 1.0e-6f), 1.0e30f);
     // padded grid must fit the table; grow the cell until it does
     uint32_t dx = 4, dy = 4, dz = 4;
