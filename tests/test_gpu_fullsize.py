@@ -9,8 +9,9 @@ import pytest
 import banggameengine_amd as B
 from banggameengine_amd import synth
 from oracle import np_oracle as npo
+from oracle import pyoracle as po
 
-from helpers import DT, assert_bits_equal, run_world
+from helpers import DT, assert_bits_equal, build_oracle, run_oracle, run_world
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +45,23 @@ def test_full_size_bitwise(name, n, ticks):
     want_world = npo.resolve_world(wl.parent, pos, euler, wl.scale)
     assert_bits_equal(world, want_world, "world")
     del world, want_world
+
+
+def test_bullet_basis_scheme_full_size_against_the_cpp_oracle():
+    """BGE_TICK_BULLET_BASIS at configs[1]'s size: 1 M flat Dynamic bodies, 6 ticks, against the hash-map C++ oracle in its
+    kOrientBasis mode (a few seconds of CPU): quaternion, position, rotationEuler and every world matrix bit for bit."""
+    wl = synth.config("flat1m")
+    ticks = 6
+    ref = run_oracle(build_oracle(wl, orient_mode=po.ORIENT_BASIS), wl, ticks)
+    with B.World() as w:
+        run_world(w.load(wl), wl, ticks, flags=B.TICK_ALL | B.TICK_BULLET_BASIS)
+        pos, euler = w.download_pose()
+        quat = w.download_bodies()["quat"]
+        world = w.download_world()
+    assert_bits_equal(quat, ref.bulk_bodies()["quat"], "quaternion")
+    assert_bits_equal(pos, ref.bulk_pose()[0], "position")
+    assert_bits_equal(euler, ref.bulk_pose()[1], "rotationEuler")
+    assert_bits_equal(world, ref.bulk_world()[0], "world")
 
 
 def test_slab_broadphase_full_size_equals_single_world():
