@@ -884,6 +884,35 @@ def check_step_order():
           "m_totalForce += m_gravity, only for bodies whose state is not ISLAND_SLEEPING / DISABLE_SIMULATION) before the "
           f"sub-steps, clearForces (slot {last[2]}) after them: " + ("as restated" if good else "MISMATCH"))
     ok &= good
+    # btRigidBody::updateDeactivation + wantsSleeping, inlined into updateActivationState: the two speed tests and the timer as
+    # expression trees (m_linearVelocity +0x1b0, m_angularVelocity +0x1c0, sleeping thresholds +0x25c / +0x260,
+    # m_deactivationTime +0xfc), the state logic as text
+    uins = _disasm(pe, uas, 0x400)
+    utext = [(x[1], x[2]) for x in uins]
+    cm = [k for k, x in enumerate(uins) if x[1] == "comiss"]
+    k_first = next(k for k, x in enumerate(uins) if x[1] == "movss" and x[2].startswith("0x1b4("))
+    body = uins[k_first: cm[1] + 1]
+    got = execute(body, {"%rbx": "rb"}, "%none", {}, {}, pe.bytes_at_va,
+                  probes={uins[cm[0]][0]: ["%xmm3", "%xmm2"], uins[cm[1]][0]: ["%xmm3", "%xmm2"]})
+    rb = lambda off: E(("in", "rb", off // 4))
+    len2 = lambda o: ((rb(o) * rb(o) + rb(o + 4) * rb(o + 4)) + rb(o + 8) * rb(o + 8)).t
+    want = [(len2(0x1B0), (rb(0x25C) * rb(0x25C)).t), (len2(0x1C0), (rb(0x260) * rb(0x260)).t)]
+    good = all(norm(got[("probe", uins[cm[k]][0], "%xmm3")]) == norm(want[k][0]) and
+               norm(got[("probe", uins[cm[k]][0], "%xmm2")]) == norm(want[k][1]) for k in range(2))
+    good &= uins[cm[0]][2] == "%xmm2,%xmm3" and uins[cm[0] + 1][1] == "jae" and uins[cm[1] + 1][1] == "jae"   # slow iff len2 < thr^2
+    k_add = next(k for k, x in enumerate(uins) if k > cm[1] and x[1] == "addss")
+    good &= utext[k_add - 1] == ("movaps", "%xmm6,%xmm0") and utext[k_add] == ("addss", "0xfc(%rbx),%xmm0") and \
+        utext[k_add + 1] == ("movss", "%xmm0,0xfc(%rbx)")                                                  # time = timeStep + time
+    # state logic: states 2 / 4 skip the timer; otherwise-not-slow: time = 0, setActivationState(0)
+    good &= ("sub", "$0x2,%eax") in utext and ("test", "$0xfffffffd,%eax") in utext
+    # wantsSleeping: state 4 never; gDisableDeactivation / gDeactivationTime == 0 never; states 2, 3 yes; else time > gDeactivationTime
+    k_time = next(k for k, x in enumerate(uins) if x[1] == "comiss" and x[2].startswith("0xfc("))
+    good &= utext[k_time + 1][0] == "jae" and ("cmp", "$0x4,%ecx") in utext and ("ucomiss", "%xmm7,%xmm0") in utext
+    # sleeping: both velocities zeroed (two 16-byte stores of zero)
+    good &= ("movups", "%xmm0,0x1c0(%rbx)") in utext and ("movups", "%xmm1,0x1b0(%rbx)") in utext
+    print("updateActivationState: slow iff (vx^2 + vy^2) + vz^2 < thr * thr for both velocities (else time = 0), time = dt + time, "
+          "sleeping wanted iff state 2 / 3 or gDeactivationTime < time, a sleeper's velocities zeroed: " + ("as restated" if good else "MISMATCH"))
+    ok &= good
     # btSimulationIslandManager::buildIslands — where a body that wants to sleep is put to sleep.  setActivationState is the
     # callee updateActivationState uses three times; buildIslands is its caller that passes both ISLAND_SLEEPING (2) and
     # WANTS_DEACTIVATION (3) and is reached from the solver step (solveConstraints -> buildAndProcessIslands -> buildIslands).
