@@ -884,6 +884,19 @@ def check_step_order():
           "m_totalForce += m_gravity, only for bodies whose state is not ISLAND_SLEEPING / DISABLE_SIMULATION) before the "
           f"sub-steps, clearForces (slot {last[2]}) after them: " + ("as restated" if good else "MISMATCH"))
     ok &= good
+    # btRigidBody::applyGravity (the callee of the world's applyGravity loop): m_totalForce += m_gravity * m_linearFactor
+    # (m_linearFactor +0x1e0 is (1, 1, 1): nothing in the reference sets it), skipped for static / kinematic bodies
+    if grav:
+        callee = [t for kind, t in calls_of(members[grav[0]]) if kind == "d"]
+        ag = _disasm(pe, callee[0], 0x100)
+        got = execute(ag, {"%rcx": "rb"}, {"%rcx": "rb"}, {}, {}, pe.bytes_at_va)
+        rb_ = lambda off: E(("in", "rb", off // 4))
+        bad = [k for k in range(3) if norm(got.get(("rb", (0x220 + 4 * k) // 4), ("missing",))) !=
+               norm((rb_(0x1E0 + 4 * k) * rb_(0x1F0 + 4 * k) + rb_(0x220 + 4 * k)).t)]
+        good = not bad and (ag[0][1], ag[0][2]) == ("testb", "$0x3,0xe8(%rcx)")
+        print(f"btRigidBody::applyGravity: totalForce = linearFactor * gravity + totalForce, not for STATIC|KINEMATIC: {3 - len(bad)} of 3 identical"
+              + ("" if good else "  <-- MISMATCH"))
+        ok &= good
     # btRigidBody::updateDeactivation + wantsSleeping, inlined into updateActivationState: the two speed tests and the timer as
     # expression trees (m_linearVelocity +0x1b0, m_angularVelocity +0x1c0, sleeping thresholds +0x25c / +0x260,
     # m_deactivationTime +0xfc), the state logic as text
