@@ -41,6 +41,10 @@
 // With dt == fixedStep (src/core/Application.cpp:326, PhysicsSystem.h:77) that is exactly one
 // sub-step per tick; the caller passes that dt.
 //
+// Angular velocity: nothing in the reference sets one, so ω = 0 for every reachable body and the solver's gyroscopic
+// impulse (BT_ENABLE_GYROSCOPIC_FORCE_IMPLICIT_BODY, Bullet's default flag) is exactly zero.  Seeding ω (bulk_set_velocity)
+// is a test extension: ω then stays constant here, which is NOT what Bullet does for anisotropic inertia.
+//
 // Orientation state.  Bullet keeps a 3x3 basis and converts basis -> quaternion -> basis every
 // step.  Three modes are implemented so the choice the GPU path makes can be quantified:
 //   kOrientIdeal   (default, what the GPU path implements): state is a quaternion; a body whose
