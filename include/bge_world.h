@@ -157,6 +157,8 @@ BGE_API int bge_world_upload_bodies_indexed(bge_world* world, uint64_t count, co
 /*
  * Extension (no reference API): overwrite linear / angular velocity without touching dirty flags.
  * The reference's bodies only ever gain velocity from gravity and contacts; synthetic workloads seed it.
+ * An angular velocity then stays constant: Bullet's gyroscopic impulse (zero at rest, hence zero for every body the
+ * reference can create without contacts) is not part of the path.
  */
 BGE_API int bge_world_set_velocities(bge_world* world, uint64_t first, uint64_t count, const float* linvel3,
                                      const float* angvel3);
