@@ -277,8 +277,11 @@ __device__ __forceinline__ Q4 bt_quat_from_mat(const M3& a)
 }
 
 // Transform::rotationEuler written by SyncRigidBodiesFromPhysics: {pitch, yaw, roll} of getEulerZYX
-__device__ __forceinline__ F3 bt_transform_euler_from_mat(const M3& a)
+// (the reference reads worldTransform.getRotation() and builds btMatrix3x3(rotation) before getEulerZYX: the basis takes a
+//  getRotation -> setRotation round trip first, oracle/bullet_math.h TransformEulerFromMat)
+__device__ __forceinline__ F3 bt_transform_euler_from_mat(const M3& basis)
 {
+    const M3 a = bt_mat_from_quat(bt_quat_from_mat(basis));
     float yaw, pitch, roll;
     if (__builtin_fabsf(a.m[2][0]) >= 1.0f) {
         yaw = 0.0f;

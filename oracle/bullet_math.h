@@ -193,10 +193,16 @@ inline void EulerZYXFromMat(const Mat3& a, float& yaw, float& pitch, float& roll
 
 // What SyncRigidBodiesFromPhysics stores into Transform::rotationEuler
 // (src/physics/PhysicsSystem.cpp:943-947): {x: pitch, y: yaw, z: roll}
+// The reference does not take the euler angles from the body's basis directly: it reads
+//   rotation = worldTransform.getRotation();  btMatrix3x3(rotation).getEulerZYX(yaw, pitch, roll);
+// i.e. basis -> quaternion (getRotation) -> matrix (setRotation) -> angles.  The compiled function calls exactly
+// getRotation, setRotation, getEulerZYX in that order (relocations of ?SyncRigidBodiesFromPhysics@ in PhysicsSystem.obj,
+// oracle/tools/check_bullet_order.py); the round trip moves the matrix by an ulp now and then.
 inline Vec3 TransformEulerFromMat(const Mat3& a)
 {
+    const Mat3 m = MatFromQuat(QuatFromMat(a));
     float yaw, pitch, roll;
-    EulerZYXFromMat(a, yaw, pitch, roll);
+    EulerZYXFromMat(m, yaw, pitch, roll);
     return Vec3{pitch, yaw, roll};
 }
 

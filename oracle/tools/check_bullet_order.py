@@ -1017,6 +1017,14 @@ def main():
     bad = [k for k in want if norm(got.get(k, ("missing",))) != norm(want[k])]
     print(f"btMatrix3x3::getRotation, trace > 0: {4 - len(bad)} of 4 components identical" + ("" if not bad else f"  <-- MISMATCH {bad}"))
     ok &= not bad
+    # 4b. how the reference reads the angles back (src/physics/PhysicsSystem.cpp:937-947): NOT getEulerZYX of the body's basis
+    #     but worldTransform.getRotation() -> btMatrix3x3(rotation) [= setRotation] -> getEulerZYX: the call order in the object
+    _, _, rel = coff_section(OBJ, "?SyncRigidBodiesFromPhysics@PhysicsSystem@@")
+    order = [rel[o].split("@")[0].lstrip("?") for o in sorted(rel) if "btMatrix3x3" in rel[o]]
+    good = order == ["getRotation", "setRotation", "getEulerZYX"]
+    print("SyncRigidBodiesFromPhysics: basis -> getRotation -> setRotation -> getEulerZYX (the angles come from the round-tripped "
+          "matrix): " + ("as restated" if good else f"MISMATCH {order}"))
+    ok &= good
     ok &= check_get_rotation_other_side()
     ok &= check_integrate_transform()
     ok &= check_external_force_impulse()
