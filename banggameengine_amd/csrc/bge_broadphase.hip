@@ -5,23 +5,29 @@
 // history-free core of Bullet's pair cache (see oracle/broadphase_ref.h for the exact specification):
 //   AABBs overlap (non-strict) AND (groupA & maskB) && (groupB & maskA) AND not both Static.
 //
-// Per tick, all on the world's stream, no host round trip:
-//   1. k_bp_bounds   wave64 __shfl reductions of the scene bounds + LDS histogram of AABB extents
-//   2. k_bp_params   one wave derives the grid: the cell size that minimises the expected number of AABB tests
-//                    given the histogram of body extents (grown until the padded grid fits the table);
-//                    bodies wider than a cell are "large" and handled by step 7
-//   3. k_bp_count    cell index of each body's AABB min corner; atomic histogram, the returned value is the
-//                    body's rank inside its cell (so the scatter needs no second atomic)
-//   4. scan          exclusive prefix sum of the histogram (3 small kernels)
-//   5. k_bp_scatter  bodies sorted by cell into 48-byte records (min xyz | entity, max xyz | cell, filter words)
-//   6. k_bp_pairs    every body scans the 5 contiguous runs of the 14 "forward" neighbour cells, staged through
-//                    LDS per workgroup; overlapping pairs are ballot-compacted per wave into an LDS staging
-//                    buffer and written 256 at a time behind one global atomic
-//   7. k_bp_large    large bodies against everything
-//   8. k_bp_compact  the 64 shard slices of the pair list -> one compact list + totals
-// A small body's AABB is narrower than one cell (by a 2^-20 margin that dominates the f64 rounding of the
-// cell coordinates), so two overlapping small bodies sit in cells that differ by at most one per axis; scanning only forward neighbours (and, inside the own cell, only later records) reports
-// each pair once.  The kernels are bound by L2/Infinity-Cache traffic of the sorted records, not by HBM.
+// Per tick, all on the world's stream, no host round trip (DESIGN.md 4.3 has the measurements behind every choice):
+//   1. k_bp_bounds      scene bounds (wave64 __shfl reductions -> per-workgroup partials) + per extent bin, in LDS, the
+//                       number of bodies and the widest one (flushed to 16 copies of the global arrays)
+//   2. k_bp_params      one workgroup derives the grid: the bin edge that minimises the expected number of AABB tests, then
+//                       cell = the widest body below that edge (grown until the padded grid fits the table); bodies wider
+//                       than a cell are "large" (step 7).  It also re-arms the accumulators (there is no reset kernel)
+//   3. k_sort_hist      two-level counting sort by cell, level 1: per chunk workgroup an LDS histogram over coarse buckets
+//                       of 4096 cells -> bucket x workgroup matrix;  k_scan_lookback: single-pass scan of the matrix
+//   4. k_sort_coarse_t  every record to its bucket: 8192 records per workgroup held in registers, ranked in LDS, written out
+//                       through an LDS window in contiguous runs
+//   5. k_sort_fine_t    one workgroup per bucket: LDS histogram over its cells -> cell_start, records in cell order, read once
+//                       and written as one stream (two-sweep path for buckets beyond one register pass)
+//                       [tables beyond 32 M cells, BGE_BP_SORT=atomic: k_bp_count / scan / k_bp_scatter with global atomics]
+//   6. k_bp_pairs_wave  one wave owns 64 consecutive sorted bodies; for each of the 5 contiguous runs that cover the 14
+//                       "forward" neighbour cells the candidates are staged in wave-private LDS; hits are ballot-compacted
+//                       into an LDS staging buffer and written 128 at a time behind one atomic on one of 64 counters
+//   7. k_bp_large       large bodies against everything
+//   8. k_bp_compact     (on demand) the 64 shard slices of the pair list -> one compact list + totals
+// Sorted records are 32 bytes (min xyz | entity, max xyz | filter class) or, for the slab search and more than 255 filter
+// classes, 48 bytes (... | cell, group | mask | static | slot).
+// A small body's AABB is narrower than one cell (by a 2^-20 margin that dominates the f64 rounding of the cell
+// coordinates), so two overlapping small bodies sit in cells that differ by at most one per axis; scanning only forward
+// neighbours (and, inside the own cell, only later records) reports each pair once.
 #include "bge_broadphase.hpp"
 
 #include <hip/hip_runtime.h>
