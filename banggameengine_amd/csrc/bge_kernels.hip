@@ -10,6 +10,9 @@
 //          group) run without any workgroup barrier; block tiles use one barrier per level
 //   AABB   the per-body AABB Bullet feeds its broadphase (current pose U predicted pose, +0.02)
 //   NORMAL the render feed's per-entity normal matrix transpose(inverse(world)) (src/render/Renderer.cpp:633-636)
+//   BASIS  Bullet's own orientation bookkeeping for every Dynamic body (BGE_TICK_BULLET_BASIS): basis -> getRotation ->
+//          integrateTransform -> setRotation each step, rotationEuler rewritten from it; without it a body with zero angular
+//          velocity keeps its orientation and euler triple
 //
 // Memory plan (all streams indexed by slot, 256 consecutive slots per workgroup):
 //   reads   flags 4 B (body type, dirty bits, level, in-tile parent index, mass class), pos/euler/scale 12 B
