@@ -1240,7 +1240,8 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
 // workgroup version above spent its time waiting — two __syncthreads per staged chunk behind dependent cell_start and
 // record loads — not moving bytes: shrinking the records from 48 to 32 bytes left its 355 us untouched.
 #ifndef BGE_WAVE_CHUNK
-#define BGE_WAVE_CHUNK 96
+#define BGE_WAVE_CHUNK 88 /* 8 workgroups per CU (64 VGPRs, 12 B scratch) with 32-byte records; measured at 4 M bodies, step time:
+                             96 -> 583 us (7 per CU), 88 -> 577, 80 -> 586, 72 -> 604 (more rows need a second chunk) */
 #endif
 constexpr uint32_t kWaveChunk = BGE_WAVE_CHUNK; // records per staged chunk and wave (a row's union range is ~70 records at 0.7 bodies per cell)
 // workgroups per CU the LDS footprint allows (wave chunk regions + 6 KiB pair staging + 2 KiB filter table)
