@@ -1095,7 +1095,12 @@ __device__ __forceinline__ void emit_pairs(const PairSink& sink, WaveStage& st, 
 
 __device__ __forceinline__ bool overlap(const float4& alo, const float4& ahi, const float4& blo, const float4& bhi)
 {
-    return alo.x <= bhi.x && ahi.x >= blo.x && alo.y <= bhi.y && ahi.y >= blo.y && alo.z <= bhi.z && ahi.z >= blo.z;
+    // All six comparisons, no short circuit: for `&&` the compiler builds a cascade of exec-mask branches (one per axis, the
+    // far corner fetched lazily) that costs more issue slots than it saves — measured at 4 M bodies, step 576 -> 566 us.
+    const int x = static_cast<int>(alo.x <= bhi.x) & static_cast<int>(ahi.x >= blo.x);
+    const int y = static_cast<int>(alo.y <= bhi.y) & static_cast<int>(ahi.y >= blo.y);
+    const int z = static_cast<int>(alo.z <= bhi.z) & static_cast<int>(ahi.z >= blo.z);
+    return (x & y & z) != 0;
 }
 
 __device__ __forceinline__ bool filter_ok(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ group,
