@@ -1252,7 +1252,10 @@ constexpr uint32_t kWaveChunk = BGE_WAVE_CHUNK; // records per staged chunk and 
 // workgroups per CU the LDS footprint allows (wave chunk regions + 6 KiB pair staging + 2 KiB filter table)
 constexpr uint32_t kWaveResidentCompact = (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + 6144u + 2048u + 96u) > 8u ? 8u : (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + 6144u + 2048u + 96u);
 constexpr uint32_t kWaveResidentFull = (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + 6144u + 64u) > 8u ? 8u : (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + 6144u + 64u);
-template <bool WINDOW, bool COMPACT>
+// SMALL (with COMPACT): at most 32 filter classes in the scene — the usual case.  Instead of the (group, mask, static) table
+// the workgroup keeps one 32-bit word per class, bit c = "may pair with class c"; a lane holds its own class's word and the
+// filter of a candidate is one shift instead of two dependent LDS reads and a dozen bit operations.
+template <bool WINDOW, bool COMPACT, bool SMALL = false>
 __global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveResidentFull) k_bp_pairs_wave(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, const uint4* __restrict__ filter_table,
                                                        PairSink sink)
@@ -1260,11 +1263,20 @@ __global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveRes
     constexpr uint32_t RS = COMPACT ? 2u : 3u; // float4 per record
     __shared__ float4 cand_all[4][RS * kWaveChunk];
     __shared__ uint2 stage_lds[4][kStage];
-    __shared__ uint2 s_tab[COMPACT ? 256 : 1];      // (group, mask) per filter class
-    __shared__ uint32_t s_static[COMPACT ? 8 : 1];  // static bit per filter class
+    __shared__ uint2 s_tab[(COMPACT && !SMALL) ? 256 : 1];      // (group, mask) per filter class
+    __shared__ uint32_t s_static[(COMPACT && !SMALL) ? 8 : 1];  // static bit per filter class
+    __shared__ uint32_t s_compat[SMALL ? 32 : 1];               // SMALL: classes a class may pair with
 
     const GridParams g = acc->grid;
-    if (COMPACT) {
+    if (SMALL) {
+        if (threadIdx.x < 32u) {
+            const uint4 a = filter_table[threadIdx.x];
+            uint32_t m = 0;
+            for (uint32_t c = 0; c < 32u; ++c) m |= filter_tab(a, filter_table[c]) ? 1u << c : 0u; // (unused entries are zero: never pair)
+            s_compat[threadIdx.x] = m;
+        }
+        __syncthreads();
+    } else if (COMPACT) {
         const uint4 e = filter_table[threadIdx.x];
         s_tab[threadIdx.x] = make_uint2(e.x, e.y);
         const unsigned long long sm = __ballot(e.z != 0u);
@@ -1303,7 +1315,12 @@ __global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveRes
             const uint2 gm = s_tab[cls & 255u];
             return make_uint4(gm.x, gm.y, (s_static[(cls & 255u) >> 5] >> (cls & 31u)) & 1u, 0u);
         };
-        if (COMPACT && active) own = class_entry(__float_as_uint(hi.w));
+        uint32_t own_compat = 0;
+        if (SMALL) {
+            if (active) own_compat = s_compat[__float_as_uint(hi.w) & 31u];
+        } else if (COMPACT && active) {
+            own = class_entry(__float_as_uint(hi.w));
+        }
 
 #pragma unroll 1
         for (int row = 0; row < 5; ++row) {
@@ -1348,12 +1365,14 @@ __global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveRes
                         const float4 alo = cand[k0], ahi = cand[k0 + 1u];
                         const float4 blo = cand[k1], bhi = cand[k1 + 1u];
                         if (overlap(lo, hi, alo, ahi)) {
-                            hit0 = (COMPACT ? filter_tab(own, class_entry(__float_as_uint(ahi.w))) : filter_rec(fi, cand[k0 + RS - 1u])) &&
+                            hit0 = (SMALL ? ((own_compat >> (__float_as_uint(ahi.w) & 31u)) & 1u) != 0u
+                                          : (COMPACT ? filter_tab(own, class_entry(__float_as_uint(ahi.w))) : filter_rec(fi, cand[k0 + RS - 1u]))) &&
                                    (!WINDOW || in_window(sink, lo, alo));
                             e0j = __float_as_uint(alo.w);
                         }
                         if (two && overlap(lo, hi, blo, bhi)) {
-                            hit1 = (COMPACT ? filter_tab(own, class_entry(__float_as_uint(bhi.w))) : filter_rec(fi, cand[k1 + RS - 1u])) &&
+                            hit1 = (SMALL ? ((own_compat >> (__float_as_uint(bhi.w) & 31u)) & 1u) != 0u
+                                          : (COMPACT ? filter_tab(own, class_entry(__float_as_uint(bhi.w))) : filter_rec(fi, cand[k1 + RS - 1u]))) &&
                                    (!WINDOW || in_window(sink, lo, blo));
                             e1j = __float_as_uint(blo.w);
                         }
@@ -1504,6 +1523,7 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
     if (const char* e = std::getenv("BGE_BP_PAIRS")) block_pairs_ = std::string(e) == "block";  // A/B: workgroup-granular pair search
     sort_groups_ = kSortGroups;
     if (const char* e = std::getenv("BGE_BP_SORT_GROUPS")) sort_groups_ = std::min<uint32_t>(kSortGroups, std::max(1, std::atoi(e))); // tests: several passes per workgroup at small n
+    if (const char* e = std::getenv("BGE_BP_FILTER")) small_palette_ = std::string(e) != "table"; // A/B and tests: keep the (group, mask) table
     if (const char* e = std::getenv("BGE_BP_COARSE")) transposed_coarse_ = std::string(e) != "scatter"; // A/B: per-thread scattered record writes
     if (const char* e = std::getenv("BGE_BP_RECORDS")) full_records_ = std::atoi(e) == 48;  // A/B: BGE_BP_RECORDS=48 keeps full records
     BP_TRY(hipMalloc(&sorted_slot_, std::max<uint64_t>(n_slots, 1) * 4));  // body rank inside its cell
@@ -1660,6 +1680,8 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
         const dim3 wgrid(std::min<uint32_t>(blocks_for(n, 256), (compact_records ? kWaveResidentCompact : kWaveResidentFull) * 256));
         if (window) {
             hipLaunchKernelGGL((k_bp_pairs_wave<true, false>), wgrid, dim3(256), 0, stream, acc, cell_start, sorted, no_table, sink);
+        } else if (compact_records && palette->n_classes <= 32u && small_palette_) {
+            hipLaunchKernelGGL((k_bp_pairs_wave<false, true, true>), wgrid, dim3(256), 0, stream, acc, cell_start, sorted, palette->table, sink);
         } else if (compact_records) {
             hipLaunchKernelGGL((k_bp_pairs_wave<false, true>), wgrid, dim3(256), 0, stream, acc, cell_start, sorted, palette->table, sink);
         } else {

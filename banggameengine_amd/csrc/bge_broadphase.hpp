@@ -19,7 +19,8 @@ struct PairWindow {
 // Collision-filter palette of the world (null pointers: full 48-byte records carrying group and mask).
 struct FilterPalette {
     const uint32_t* class_of_slot; // [slots]
-    const uint4* table;            // [256] (group, mask, static, 0)
+    const uint4* table;            // [256] (group, mask, static, 0), unused entries zero
+    uint32_t n_classes = 256;      // entries in use
 };
 
 class Broadphase {
@@ -61,6 +62,7 @@ private:
     bool block_pairs_ = false;
     uint32_t sort_groups_ = 512;    // chunk workgroups of the coarse passes (BGE_BP_SORT_GROUPS lowers it: tests)
     uint32_t fine_window_[2] = {0, 0}; // records in k_sort_fine_t's LDS window: [0] 48-byte records, [1] 32-byte records
+    bool small_palette_ = true;     // wave search: one compatibility word per class when the palette has <= 32 classes
     bool transposed_coarse_ = true; // k_sort_coarse_t (bucket-ordered write-out) instead of k_sort_coarse<true>; BGE_BP_COARSE=scatter for A/B
     void* sorted_slot_ = nullptr; // uint32[n_slots]
     void* sorted_aabb_ = nullptr; // float4[n_slots][3] sorted records

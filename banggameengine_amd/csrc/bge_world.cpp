@@ -1062,7 +1062,8 @@ try {
                 w->filter_table_stale = false;
             }
             const bge::FilterPalette palette{w->filter_overflow ? nullptr : w->filter_class.as<uint32_t>(),
-                                             w->filter_overflow ? nullptr : w->filter_table.as<uint4>()};
+                                             w->filter_overflow ? nullptr : w->filter_table.as<uint4>(),
+                                             static_cast<uint32_t>(w->filter_palette.size())};
             rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
                                    w->entity_of_slot.as<uint32_t>(), nullptr, &palette);
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());

@@ -824,6 +824,7 @@ def test_pinned_host_buffers_and_identity_layout_downloads():
     {"BGE_BP_SORT": "atomic", "BGE_BP_SCAN": "3"},          # ... with the three-kernel scan
     {"BGE_BP_RECORDS": "48"},                               # full records (more than 255 filter classes; slab search)
     {"BGE_BP_COARSE": "scatter"},                           # coarse pass with per-thread scattered writes (32-byte records)
+    {"BGE_BP_FILTER": "table"},                             # wave search with the (group, mask, static) table (what > 32 filter classes use)
     {"BGE_BP_PAIRS": "block"},                              # workgroup-granular pair search
     {"BGE_BP_PAIRS": "block", "BGE_BP_RECORDS": "48", "BGE_BP_SORT": "atomic"},
 ])
