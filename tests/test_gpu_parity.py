@@ -885,6 +885,30 @@ def test_coarse_sort_with_several_passes_per_workgroup(coarse, monkeypatch):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("layers", [16, 17])
+def test_filter_palette_at_the_32_class_boundary(layers):
+    """16 layers x {Static, Dynamic} = exactly 32 filter classes: the pair search keeps one 32-bit compatibility word per
+    class; 17 layers = 34 classes: it uses the (group, mask, static) table.  Same oracle pair set either side."""
+    n = 5000
+    wl = _cube(n, 26.0, seed=13)
+    rng = np.random.default_rng(4)
+    wl.body_type = rng.choice([0, 1], n).astype(np.uint8)                      # Static / Dynamic
+    layer = (np.uint32(1) << (np.arange(n) % layers).astype(np.uint32)).astype(np.uint32)
+    mask = np.full(n, (1 << layers) - 1, np.uint32)
+    mask = np.where((np.arange(n) % layers) % 2 == 0, np.uint32((1 << layers) - 1), np.uint32(0x15555)).astype(np.uint32)
+    kw = dict(layer=layer, mask=mask)
+    ref = run_oracle(build_oracle(wl, aabbs=True, **kw), wl, 2)
+    want = ref.pairs("sweep")
+    with B.World(pair_capacity=64 * n) as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, **kw)
+        run_world(w, wl, 2, flags=B.TICK_ALL | B.TICK_BROADPHASE)
+        got = w.pairs(cap=64 * n)
+    assert len(want) > 1000
+    assert np.array_equal(got, want)
+
+
 def test_more_than_255_filter_classes_fall_back_to_full_records():
     n = 4000
     wl = _cube(n, 24.0, seed=3)
