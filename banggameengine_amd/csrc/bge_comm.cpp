@@ -38,12 +38,19 @@ Rccl& rccl()
 {
     static Rccl r = [] {
         Rccl x;
+        std::string last;
+        // BGE_RCCL_SONAME replaces the search list (deployments with a private RCCL build; the tests point it at a
+        // name that does not exist to exercise the BGE_ERR_UNSUPPORTED path)
+        const char* forced = std::getenv("BGE_RCCL_SONAME");
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            x.handle = dlopen(forced ? forced : name, RTLD_NOW | RTLD_GLOBAL);
             if (x.handle) break;
+            const char* e = dlerror(); // dlerror() clears the message: read it exactly once per failure
+            if (e) last = e;
+            if (forced) break;
         }
         if (!x.handle) {
-            x.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "unknown");
+            x.why = std::string("cannot load librccl: ") + (last.empty() ? "unknown" : last);
             return x;
         }
         x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.handle, "ncclGetUniqueId"));

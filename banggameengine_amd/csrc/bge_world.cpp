@@ -77,6 +77,21 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// A DevBuf that frees itself: temporaries of one call (an early HIP_TRY return must not leak them).
+struct TmpBuf : DevBuf {
+    TmpBuf() = default;
+    TmpBuf(const TmpBuf&) = delete;
+    TmpBuf& operator=(const TmpBuf&) = delete;
+    TmpBuf(TmpBuf&& o) noexcept
+    {
+        p = o.p;
+        bytes = o.bytes;
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    ~TmpBuf() { release(); }
+};
+
 // Collider size -> AABB half extents in the collider's frame.
 // Box: btBoxShape ctor (implicit = he - 0.04), setSafeMargin (margin = min(0.04, 0.1*min he) through
 // btBoxShape::setMargin), btTransformAabb adds the margin back.  Capsule (up axis Y): (r, r+h/2, r).
@@ -543,15 +558,15 @@ try {
     struct Carry {
         DevBuf* buf;
         uint32_t width;
-        DevBuf tmp;
+        TmpBuf tmp;
     };
     std::vector<Carry> carries;
-    DevBuf old_flags_tmp;
+    TmpBuf old_flags_tmp;
     if (n_keep) {
         for (auto [buf, width] : std::initializer_list<std::pair<DevBuf*, uint32_t>>{
                  {&w->pos, 3}, {&w->euler, 3}, {&w->scale, 3}, {&w->world, 16}, {&w->vel, 3}, {&w->angvel, 3},
                  {&w->quat, 4}, {&w->inv_mass, 1}, {&w->deact, 1}, {&w->filter_class, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6}}) {
-            carries.push_back(Carry{buf, width, DevBuf{}});
+            carries.push_back(Carry{buf, width, TmpBuf{}});
         }
         for (Carry& c : carries) {
             HIP_TRY(c.tmp.ensure(n_keep * c.width * 4));
@@ -670,7 +685,7 @@ try {
         for (uint64_t i = 0; i < n_keep; ++i) {
             if (keep_mask[i]) carry_map[i] = nf.slot_of_entity[i];
         }
-        DevBuf map_dev;
+        TmpBuf map_dev;
         HIP_TRY(map_dev.ensure(n_keep * 4));
         HIP_TRY(hipMemcpyAsync(map_dev.p, carry_map.data(), n_keep * 4, hipMemcpyHostToDevice, w->stream));
         for (Carry& c : carries) {
@@ -995,7 +1010,16 @@ try {
     bool nt_out = static_cast<double>(w->flat.n_slots) * ((flags & BGE_TICK_NORMAL_MATRICES) ? 204.0 : 140.0) > kNtThresholdBytes;
     if (const char* e = std::getenv("BGE_NT_STORES")) nt_out = std::atoi(e) != 0;
     for (uint32_t t = first_eager; t < ticks; ++t) {
-        if (!phys && !w->maybe_dirty && !(flags & BGE_TICK_NORMAL_MATRICES)) continue; // TransformSystem::Update with nothing dirty: a no-op scan
+        if (!phys && !w->maybe_dirty && !(flags & BGE_TICK_NORMAL_MATRICES)) {
+            // TransformSystem::Update with nothing dirty: a no-op scan — only the kernel launches are skipped.  The
+            // collective is NOT: a peer rank may have dirty transforms and issue its gather, and a rank that stayed
+            // away would leave it hanging (and let the ranks' ring frame counters drift apart).  The unchanged roots are
+            // packed from the world array and gathered like any other frame.
+            if (flags & BGE_TICK_GATHER_ROOTS) {
+                if (int rc = bge_world_gather_roots(w, nullptr)) return rc;
+            }
+            continue;
+        }
         bge::TickParams p{};
         p.dt = dt;
         p.gx = gravity ? gravity[0] : 0.0f;

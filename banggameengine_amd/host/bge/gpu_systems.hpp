@@ -315,6 +315,7 @@ private:
                 is_free_.push_back(0);
                 written_.push_back(0);
                 last_pose_.resize(last_pose_.size() + 6, 0.0f);
+                last_scale_.resize(last_scale_.size() + 3, 0.0f);
             }
             ids_[i] = kv.first;
             last_ids_[i] = kv.first; // survives the entity: an Exit event may name a body that was destroyed
@@ -354,9 +355,13 @@ private:
             if (!t.dirty) continue;
             const uint32_t i = index_of_[kv.first];
             if (written_[i] && std::memcmp(&t.position, &last_pose_[6 * static_cast<size_t>(i)], 12) == 0 &&
-                std::memcmp(&t.rotationEuler, &last_pose_[6 * static_cast<size_t>(i) + 3], 12) == 0) {
+                std::memcmp(&t.rotationEuler, &last_pose_[6 * static_cast<size_t>(i) + 3], 12) == 0 &&
+                std::memcmp(&t.scale, &last_scale_[3 * static_cast<size_t>(i)], 12) == 0) {
                 continue; // dirty only because the physics write-back marked it: the device already has these values
             }
+            // (the scale is compared too: a scale edit + MarkDirty between PhysicsSystem::Update and
+            //  TransformSystem::Update must reach the device — the reference recomputes `local` from it in that frame)
+            std::memcpy(&last_scale_[3 * static_cast<size_t>(i)], &t.scale, 12);
             index_list_.push_back(i);
             const float* p = &t.position.x;
             stage_.insert(stage_.end(), p, p + 9); // position, rotationEuler, scale are contiguous (Transform.h:14-16)
@@ -433,6 +438,7 @@ private:
     std::unordered_map<Id, uint32_t> retired_;  // last index of ids that lost their Transform
     std::vector<BodyState> body_;
     std::vector<float> last_pose_;              // position + euler the physics write-back stored (6 floats per index)
+    std::vector<float> last_scale_;             // scale as last uploaded (3 floats per index)
     std::vector<float> stage_, repack_;
     // Destination of the downloads: page-locked (bge_host_alloc), so the copies run at the PCIe rate instead of the
     // pageable ~10 GB/s; grow-only.

@@ -109,8 +109,14 @@ class Workload:
         return {FLAT: 140.0, CHAINS4: 113.0, SUBTREE64: (140.0 + 63 * 104.0) / 64.0}[self.shape]
 
 
+DEFAULT_N = {"flat10k": 10_000, "flat1m": 1_000_000, "chains4": 1_000_000, "cube4m": 4_000_000,
+             "chains4_shard": 2_000_000, "subtree64": 2_000_000}
+
+
 def config(name: str, n: int | None = None, first: int = 0) -> Workload:
     """The BASELINE.json configurations by name."""
+    if n is None and name in DEFAULT_N:
+        n = DEFAULT_N[name]
     if name == "flat10k":      # configs[0]
         return Workload(name, FLAT, n or 10_000, 0xBA5E0001, first=first)
     if name == "flat1m":       # configs[1]

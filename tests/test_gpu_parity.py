@@ -258,6 +258,26 @@ def test_native_root_gather_single_rank(fused, mode):
     assert not table[0, len(roots):, :15].any()
 
 
+def test_transform_tick_with_nothing_dirty_still_gathers():
+    """a TRANSFORMS | GATHER_ROOTS tick on a rank where nothing is dirty skipped the whole frame — including
+    its ncclAllGather, which a peer with a dirty transform would still issue (mismatched collective = hang).  The kernel
+    launches may be skipped, the collective may not: here the FIRST gather the communicator ever sees comes from such a
+    tick, so the table can only hold the roots if it was issued."""
+    wl = synth.config("subtree64", n=64 * 300)
+    roots = np.flatnonzero(wl.parent == 0xFFFFFFFF)
+    with B.World() as w:
+        w.load(wl)
+        w.tick(dt=DT)                                   # bodies created, transforms resolved: nothing is dirty now ...
+        w.tick(dt=DT, flags=B.TICK_TRANSFORMS)
+        assert w.dirty_count() == 0
+        w.comm_init(1, 0, B.World.comm_unique_id(), len(roots))
+        w.tick(dt=DT, flags=B.TICK_TRANSFORMS | B.TICK_GATHER_ROOTS, ticks=3)   # ... so these three frames launch no kernel
+        table = w.download_gathered(1, len(roots))       # raises "nothing has been gathered yet" if they skipped the gather
+        world = w.download_world()
+        w.comm_destroy()
+    assert_bits_equal(table[0], world[roots], "roots gathered by an idle transform tick")
+
+
 def test_spinning_bodies_match_golden_and_oracle():
     """Angular path: exponential-map orientation, safeNormalize, euler write-back every tick."""
     z = np.load(os.path.join(GOLD, "physics_cases.npz"))

@@ -142,6 +142,28 @@ def test_no_gpu_fails_loudly():
     assert "no CPU path" in str(e.value)
 
 
+def test_missing_rccl_is_reported_not_crashed():
+    """bge_comm.cpp loads librccl at run time; on a host without it the communicator entry points must return
+    BGE_ERR_UNSUPPORTED with the loader's message (the message was built from a second dlerror() call,
+    which returns NULL -> std::string(nullptr) -> abort).  BGE_RCCL_SONAME points the loader at a name that does not
+    exist; a fresh process, because the library handle is resolved once."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import banggameengine_amd as B\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "rc = B.lib().bge_comm_unique_id(buf)\n"
+        "print(rc, B.lib().bge_last_error().decode())\n" % ROOT)
+    env = dict(os.environ, BGE_RCCL_SONAME="/nonexistent/librccl-not-here.so")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-1500:]
+    rc, msg = p.stdout.decode().strip().split(" ", 1)
+    assert int(rc) == -5  # BGE_ERR_UNSUPPORTED
+    assert "cannot load librccl" in msg and "librccl-not-here" in msg
+
+
 def test_flatten_invariants_property_based():
     """hypothesis: arbitrary parent arrays (forward and backward links, cycles, self-parents, missing Transforms)."""
     from hypothesis import given, settings, strategies as st
