@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
         const uint32_t type = f & kTypeMask;
         if (valid && type != 0) {
             const bool dynamic = type == 2u;
-            const bool repose = (f & (kTDirty | kBDirty)) != 0;
+            // (p.no_repose: a later sub-step of the same stepSimulation call — the teleport rule ran before the first one)
+            const bool repose = p.no_repose == 0u && (f & (kTDirty | kBDirty)) != 0;
             bool spin = (f & kSpin) != 0;
             // BASIS (BGE_TICK_BULLET_BASIS): Bullet's own orientation scheme.  Its state is the 3x3 basis, which every step
             // goes basis -> getRotation -> exponential map -> safeNormalize -> setRotation for EVERY non-static body, spinning
@@ -413,6 +414,48 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
     if (f != f0) w.flags[slot] = f;
 }
 
+// PhysicsSystem::Update with a stepSimulation that runs no sub-step (Bullet's accumulator, src/physics/PhysicsSystem.cpp:855-863:
+// m_localTime has not reached fixedStep yet).  What still happens around the step: EnsureRigidBody /
+// SyncKinematicBodiesToPhysics re-pose every body whose Transform or RigidBody is dirty and zero a Dynamic one's
+// velocities (:952-989); SyncRigidBodiesFromPhysics writes every Dynamic body's pose back and marks its Transform dirty
+// (:916-950).  Position needs no copy (Transform::position and the body origin share storage); rotationEuler is rewritten
+// when the body was re-posed, or always in Bullet's own orientation scheme (BASIS).
+template <bool BASIS>
+__global__ void __launch_bounds__(256) k_pose_only(WorldView w, uint64_t n_slots)
+{
+    const uint64_t slot64 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (slot64 >= n_slots) return;
+    const uint32_t slot = static_cast<uint32_t>(slot64);
+    const uint32_t f0 = w.flags[slot];
+    uint32_t f = f0;
+    const uint32_t type = f & kTypeMask;
+    if (!(f & kValid) || type == 0) return;
+    const bool dynamic = type == 2u;
+    const bool repose = (f & (kTDirty | kBDirty)) != 0;
+    Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
+    if (repose) {
+        q = bt_quat_from_transform_euler(ld3(w.euler, slot));
+        st4(w.quat, slot, q);
+        if (dynamic) {
+            const F3 zero{0.0f, 0.0f, 0.0f};
+            st3(w.vel, slot, zero);
+            if (f & kSpin) {
+                st3(w.angvel, slot, zero);
+                f &= ~kSpin;
+            }
+        }
+    }
+    if (dynamic) {
+        if (repose || BASIS) {
+            if (!repose) q = ld4(w.quat, slot);
+            st3(w.euler, slot, bt_transform_euler_from_mat(bt_mat_from_quat(q)));
+        }
+        f |= kTDirty; // transform->MarkDirty()
+    }
+    f &= ~kBDirty;
+    if (f != f0) w.flags[slot] = f;
+}
+
 // ------------------------------------------------------------------ component scatter / gather (entity order <-> slots)
 // stage holds `count` rows of `width` 32-bit words for entities [first, first+count).
 // `index` (nullable) selects entities explicitly: row i belongs to entity index[i] instead of first + i.
@@ -674,6 +717,14 @@ hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams&
     else if (phys) BGE_LAUNCH(true, false, false, false);
     else if (xform) BGE_LAUNCH(false, true, false, false);
 #undef BGE_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_pose_only(hipStream_t stream, const WorldView& w, uint64_t n_slots, bool bullet_basis)
+{
+    if (n_slots == 0) return hipSuccess;
+    if (bullet_basis) hipLaunchKernelGGL(k_pose_only<true>, grid_for(n_slots, 256), dim3(256), 0, stream, w, n_slots);
+    else hipLaunchKernelGGL(k_pose_only<false>, grid_for(n_slots, 256), dim3(256), 0, stream, w, n_slots);
     return hipGetLastError();
 }
 

@@ -55,10 +55,16 @@ struct TickParams {
     uint32_t tile_begin;
     uint32_t nt_out; // non-temporal stores for world / normal matrices (working set larger than the Infinity Cache)
     float* root_out; // when non-null: roots also write their world matrix (compact, 12 floats) to root_out[root_index] (send buffer of the gather)
+    uint32_t no_repose; // this tick is the 2nd..nth sub-step of ONE stepSimulation call (bge_world_step_simulation): dirty flags
+                        // do not re-pose bodies — SyncKinematicBodiesToPhysics ran once, before the first sub-step
 };
 
 // flags: bit0 physics, bit1 transforms, bit2 / bit5 aabb, bit4 normal matrices (bge_tick_flags)
 hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams& p, uint32_t n_tiles, uint32_t flags);
+
+// PhysicsSystem::Update around a stepSimulation call that runs ZERO sub-steps (accumulated time < fixedStep): re-pose dirty
+// bodies, write Dynamic poses back, mark them dirty — no integration (bge_world_step_simulation)
+hipError_t launch_pose_only(hipStream_t stream, const WorldView& w, uint64_t n_slots, bool bullet_basis);
 
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits,

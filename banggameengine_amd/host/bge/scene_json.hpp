@@ -10,9 +10,12 @@
 //   rigidBody             ApplyRigidBodyFromJson (:234-271): "type" static|dynamic|kinematic (default Static),
 //                         mass (Dynamic: default 1, else 0), friction, restitution, layer, mask (numbers or strings
 //                         parsed with base auto-detection)
+//   trigger               ApplyTriggerFromJson (:273-301): shape / size as for colliders, "layer" (default: the component's
+//                         own value, or 1 << 2 when that is 0), "mask", "oneShot", "active" (default TRUE whatever the
+//                         component held); only on scene types that have AddTriggerVolume
 //   children[] / parent   nested children are parented to the enclosing entity unless they carry a "parent" key;
 //                         "parent" strings (an entity's "name" or "id") are resolved after all entities exist (:727-738)
-// Everything else in the file (resources, meshRenderer, trigger, …) is outside the world tick and ignored.
+// Everything else in the file (resources, meshRenderer, …) is outside the world tick and ignored.
 // Templated on the scene type like gpu_systems.hpp: works on bge::Scene and on the reference's Scene.
 // nlohmann_json (the reference's parser) is not available here, so a small strict JSON reader is included.
 #pragma once
@@ -23,6 +26,7 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -296,6 +300,13 @@ inline uint32_t read_uint(const json::Value& parent, const char* key, uint32_t f
     }
     return fallback;
 }
+inline bool read_bool(const json::Value& parent, const char* key, bool fallback)
+{
+    const json::Value* v = parent.find(key);
+    return v && v->kind == json::Value::Bool ? v->b : fallback; // (nlohmann's value() throws on a non-bool; here it is ignored)
+}
+template <class S, class = void> struct can_add_trigger : std::false_type {};
+template <class S> struct can_add_trigger<S, std::void_t<decltype(std::declval<S&>().AddTriggerVolume(0u))>> : std::true_type {};
 inline std::string read_string(const json::Value& parent, const char* key, const std::string& fallback)
 {
     const json::Value* v = parent.find(key);
@@ -403,6 +414,28 @@ bool LoadSceneFromJsonText(const std::string& text, SceneT& scene, std::string* 
                     b->layer = detail::read_uint(*rj, "layer", b->layer);
                     b->mask = detail::read_uint(*rj, "mask", b->mask);
                     b->dirty = true;
+                }
+            }
+            if constexpr (detail::can_add_trigger<SceneT>::value) {
+                if (const json::Value* tj = e.find("trigger"); tj && tj->kind == json::Value::Object) {
+                    if (auto* tv = scene.AddTriggerVolume(id)) {
+                        const std::string shape = detail::lower(detail::read_string(*tj, "shape", "box"));
+                        using ShapeT = decltype(tv->shape);
+                        tv->shape = static_cast<ShapeT>(shape == "capsule" ? 1 : 0);
+                        if (shape != "capsule") {
+                            detail::read_vec3(*tj, "size", tv->size);
+                        } else {
+                            const float radius = detail::read_float(*tj, "radius", tv->size.x);
+                            const float height = detail::read_float(*tj, "height", tv->size.y * 2.0f);
+                            tv->size.x = radius;
+                            tv->size.y = height * 0.5f;
+                        }
+                        tv->layer = detail::read_uint(*tj, "layer", tv->layer ? tv->layer : (1u << 2)); // kDefaultTriggerLayer
+                        tv->mask = detail::read_uint(*tj, "mask", tv->mask);
+                        tv->oneShot = detail::read_bool(*tj, "oneShot", tv->oneShot);
+                        tv->active = detail::read_bool(*tj, "active", true);
+                        tv->dirty = true;
+                    }
                 }
             }
             if (const json::Value* pj = e.find("parent"); pj && pj->kind == json::Value::String) {

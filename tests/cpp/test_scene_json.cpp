@@ -5,6 +5,8 @@
 // component must agree field for field; a richer synthetic scene covers nested children, "parent" by id and by name,
 // rotationEulerDeg, capsules, string layers, partial vectors.  With --gpu the loaded scenes are ticked through the GPU
 // adapter and the oracle and compared bit for bit.
+#include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -16,6 +18,7 @@
 #include "../../oracle/physics_ref.h"
 
 static int g_failures = 0;
+static size_t g_events = 0;
 #define CHECK(cond, ...)                                     \
     do {                                                     \
         if (!(cond)) {                                       \
@@ -43,6 +46,8 @@ static const char* kSynthetic = R"JSON({
      "rigidBody": {"type": "kinematic", "mass": 55}},
     {"transform": {"position": [0, -1, 0]}, "collider": {"shape": "sphere"}, "rigidBody": {}},
     {"name": "Orphan", "parent": "does-not-exist", "transform": {}},
+    {"name": "Gate", "transform": {"position": [10, 2, -3]}, "trigger": {"size": [4, 4, 4], "mask": "0x3", "oneShot": true}},
+    {"name": "Silo", "transform": {"position": [3, 1, 3]}, "trigger": {"shape": "capsule", "radius": 2.0, "height": 6.0, "layer": 0, "active": false}},
     42
   ]
 })JSON";
@@ -69,6 +74,16 @@ template <class A, class B> static void CompareStores(A& ref, B& gpu, const char
                   kv.second.friction == g->friction && kv.second.layer == g->layer && kv.second.mask == g->mask,
               "%s: rigid body fields of %u", what, kv.first);
     }
+    CHECK(ref.GetTriggerVolumes().size() == gpu.GetTriggerVolumes().size(), "%s: trigger counts", what);
+    for (auto& kv : ref.GetTriggerVolumes()) {
+        auto* g = gpu.GetTriggerVolume(kv.first);
+        CHECK(g != nullptr, "%s: trigger of %u missing", what, kv.first);
+        if (!g) continue;
+        CHECK(static_cast<int>(kv.second.shape) == static_cast<int>(g->shape) && std::memcmp(&kv.second.size, &g->size, 12) == 0 &&
+                  kv.second.layer == g->layer && kv.second.mask == g->mask && kv.second.oneShot == g->oneShot &&
+                  kv.second.active == g->active,
+              "%s: trigger fields of %u", what, kv.first);
+    }
     for (auto& kv : ref.GetColliders()) {
         auto* g = gpu.GetCollider(kv.first);
         CHECK(g != nullptr, "%s: collider of %u missing", what, kv.first);
@@ -91,11 +106,21 @@ static void RunCase(const std::string& text, const char* what, bool gpu)
     std::printf("%s: %zu entities with a Transform, %zu rigid bodies\n", what, scene.GetTransformCount(), scene.GetRigidBodies().size());
     if (!gpu) return;
     orc::RefPhysicsSystem refPhysics;
+    refPhysics.computeAabbs = true; // the ghost overlaps come from the fed body AABBs
     bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
     const double dt = static_cast<double>(0.0083333333f);
     for (int k = 0; k < 5; ++k) {
         refPhysics.Update(ref, dt);
         gpuPhysics.Update(scene, dt);
+        {
+            std::vector<std::array<uint32_t, 3>> a, b;
+            for (const auto& e : refPhysics.LastTriggerEvents()) a.push_back({static_cast<uint32_t>(e.type), e.trigger, e.other});
+            for (const auto& e : gpuPhysics.TriggerEvents(scene)) b.push_back({static_cast<uint32_t>(e.type), e.trigger, e.other});
+            std::sort(a.begin(), a.end());
+            std::sort(b.begin(), b.end());
+            CHECK(a == b, "%s: trigger events of tick %d differ (%zu vs %zu)", what, k, a.size(), b.size());
+            g_events += a.size();
+        }
         orc::RefTransformSystemUpdate(ref);
         bge::GpuTransformSystem<bge::Scene>::Update(scene);
         CompareStores(ref, scene, what, true);
@@ -121,6 +146,20 @@ int main(int argc, char** argv)
     ss << f.rdbuf();
     CHECK(!ss.str().empty(), "cannot read %s", argv[1]);
     RunCase(ss.str(), "demo.json", gpu);
+    {
+        // the shipped scene's trigger (assets/scenes/demo.json:92-107)
+        bge::Scene s;
+        std::unordered_map<std::string, uint32_t> keys;
+        std::string err;
+        CHECK(bge::LoadSceneFromJsonText(ss.str(), s, &err, &keys), "demo.json: %s", err.c_str());
+        const auto* cp = s.GetTriggerVolume(keys["checkpoint"]);
+        CHECK(cp != nullptr, "demo.json: the checkpoint's trigger volume");
+        if (cp) {
+            CHECK(static_cast<int>(cp->shape) == 0 && cp->size.x == 1.5f && cp->size.y == 1.5f && cp->size.z == 1.5f && cp->layer == 4u &&
+                      cp->mask == 0xffffffffu && !cp->oneShot && cp->active && cp->dirty,
+                  "demo.json: checkpoint trigger fields");
+        }
+    }
 
     // values of the synthetic scene, checked explicitly once (the two stores were already compared)
     {
@@ -140,7 +179,17 @@ int main(int argc, char** argv)
         CHECK(static_cast<int>(s.GetCollider(pole)->shape) == 1 && s.GetCollider(pole)->size.x == 0.25f && s.GetCollider(pole)->size.y == 1.5f,
               "capsule radius / height");
         CHECK(s.GetRigidBody(pole)->mass == 0.0f && static_cast<int>(s.GetRigidBody(pole)->type) == 2, "kinematic bodies carry no mass");
-        CHECK(s.GetTransformCount() == 9, "entity count %zu", s.GetTransformCount());
+        CHECK(s.GetTransformCount() == 11, "entity count %zu", s.GetTransformCount());
+        // ApplyTriggerFromJson (SceneLoader.cpp:273-301)
+        const auto* gate = s.GetTriggerVolume(keys["Gate"]);
+        const auto* silo = s.GetTriggerVolume(keys["Silo"]);
+        CHECK(gate && silo && s.GetTriggerVolumes().size() == 2, "trigger volumes ingested");
+        if (gate && silo) {
+            CHECK(static_cast<int>(gate->shape) == 0 && gate->size.x == 4.0f && gate->layer == 4u && gate->mask == 3u && gate->oneShot && gate->active,
+                  "box trigger: default layer 1 << 2, string mask, oneShot, active by default");
+            CHECK(static_cast<int>(silo->shape) == 1 && silo->size.x == 2.0f && silo->size.y == 3.0f && silo->layer == 0u && !silo->active && !silo->oneShot,
+                  "capsule trigger: radius / height, explicit layer 0 is kept (EnsureTrigger maps it to 4), inactive");
+        }
         std::string bad;
         CHECK(!bge::LoadSceneFromJsonText("{\"entities\": [", s, &bad) && !bad.empty(), "malformed JSON must be reported");
         CHECK(!bge::LoadSceneFromJsonText("{\"entities\": 3}", s, &bad), "'entities' must be an array");
