@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -137,6 +138,7 @@ struct bge_world {
     std::vector<uint8_t> body_type_host; // bge_body_type per entity index as last uploaded (BGE_BODY_NONE = no body)
     bool has_topology = false;
     bool maybe_dirty = true;
+    float local_time = 0.0f; // btDiscreteDynamicsWorld::m_localTime (bge_world_step_simulation)
 
     // device arrays
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
@@ -889,8 +891,24 @@ try {
 }
 BGE_CATCH_ALL("bge_world_set_velocities")
 
+namespace {
+// How one enqueued tick relates to PhysicsSystem::Update's stepSimulation call (bge_world_step_simulation):
+struct SubStep {
+    bool no_repose = false;    // a later sub-step of the same call: the teleport rule ran before the first one
+    bool ghosts_posed = false; // the trigger ghosts were posed (and their activation rule applied) before the first sub-step
+};
+int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], uint32_t flags, SubStep sub);
+} // namespace
+
 int bge_world_tick_many(bge_world* w, uint32_t ticks, float dt, const float gravity[3], uint32_t flags)
 try {
+    return tick_impl(w, ticks, dt, gravity, flags, SubStep{});
+}
+BGE_CATCH_ALL("bge_world_tick_many")
+
+namespace {
+int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], uint32_t flags, SubStep sub)
+{
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     if ((flags & (BGE_TICK_PHYSICS | BGE_TICK_TRANSFORMS)) == 0) return fail(BGE_ERR_INVALID, "tick flags select nothing");
@@ -948,7 +966,7 @@ try {
     // launches on one stream), so it is off by default.
     uint32_t first_eager = 0;
     const bool use_graph = std::getenv("BGE_USE_GRAPH") != nullptr;
-    if (use_graph && !w->graph_disabled && phys && ticks >= 2 * bge_world::kGraphTicks && w->profiling != 2 &&
+    if (use_graph && !sub.no_repose && !w->graph_disabled && phys && ticks >= 2 * bge_world::kGraphTicks && w->profiling != 2 &&
         !(flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS | BGE_TICK_GATHER_ROOTS)) && w->flat.n_tiles_ticked <= bge_world::kGraphMaxTiles &&
         w->flat.n_tiles_ticked > 0) {
         const bool same = w->graph_exec && w->graph_flags == flags && w->graph_dt == dt && w->graph_g[0] == gravity[0] &&
@@ -1026,9 +1044,10 @@ try {
         p.gy = gravity ? gravity[1] : 0.0f;
         p.gz = gravity ? gravity[2] : 0.0f;
         p.nt_out = nt_out ? 1u : 0u;
+        p.no_repose = sub.no_repose ? 1u : 0u;
         w->fill_sleep(p);
         const bool with_triggers = (flags & BGE_TICK_BROADPHASE) && !w->triggers.empty();
-        if (with_triggers) {
+        if (with_triggers && !sub.ghosts_posed) {
             ensure_triggers(w);
             if (w->triggers_device_stale) {
                 if (int rc = sync_triggers_to_device(w)) return rc;
@@ -1110,7 +1129,91 @@ try {
     }
     return BGE_OK;
 }
-BGE_CATCH_ALL("bge_world_tick_many")
+} // namespace
+
+// Bullet's btDiscreteDynamicsWorld::stepSimulation(timeStep, maxSubSteps, fixedTimeStep) around the world's ticks, as
+// PhysicsSystem::StepSimulation calls it (src/physics/PhysicsSystem.cpp:855-863): the clock m_localTime accumulates
+// timeStep; floor(m_localTime / fixedTimeStep) sub-steps are due and ALL of them are taken off the clock, but at most
+// maxSubSteps are simulated; maxSubSteps == 0 is Bullet's variable-step mode (one step of timeStep, none when it is ~0).
+// All arithmetic in binary32, as in the reference's single-precision Bullet build.
+int bge_world_step_simulation(bge_world* w, double dt, int max_sub_steps, float fixed_step, const float gravity[3],
+                              uint32_t flags, int* sub_steps)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!(flags & BGE_TICK_PHYSICS)) return fail(BGE_ERR_INVALID, "bge_world_step_simulation needs BGE_TICK_PHYSICS");
+    if (max_sub_steps < 0) return fail(BGE_ERR_INVALID, "max_sub_steps %d < 0", max_sub_steps);
+    if (max_sub_steps > 0 && !(fixed_step > 0.0f)) return fail(BGE_ERR_INVALID, "fixed_step must be positive");
+    const float time_step = static_cast<float>(dt); // stepSimulation(static_cast<btScalar>(dt), ...), PhysicsSystem.cpp:863
+    int due = 0;
+    float step = fixed_step;
+    if (max_sub_steps > 0) {
+        w->local_time = w->local_time + time_step;
+        if (w->local_time >= fixed_step) {
+            due = static_cast<int>(w->local_time / fixed_step);
+            w->local_time = w->local_time - static_cast<float>(due) * fixed_step;
+        }
+    } else {
+        // variable time step: m_localTime = m_latencyMotionStateInterpolation ? 0 : timeStep (not observable here);
+        // btFuzzyZero(timeStep) ? 0 : 1 sub-step of timeStep
+        step = time_step;
+        due = std::fabs(time_step) < 1.1920928955078125e-07f ? 0 : 1;
+        max_sub_steps = 1;
+    }
+    if (sub_steps) *sub_steps = due; // what stepSimulation returns (and LogStats prints as "substeps")
+    const int run = std::min(due, max_sub_steps);
+    const bool triggers = (flags & BGE_TICK_BROADPHASE) && !w->triggers.empty();
+    SubStep sub{};
+    if (triggers) {
+        if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+        // EnsureTrigger / SyncTriggersToPhysics pose the ghosts from the Transforms as they are BEFORE stepSimulation
+        DeviceGuard guard(w->device);
+        ensure_triggers(w);
+        if (w->triggers_device_stale) {
+            if (int rc = sync_triggers_to_device(w)) return rc;
+        }
+        HIP_TRY(bge::launch_trigger_aabb(w->stream, static_cast<uint32_t>(w->triggers.size()), w->trigger_view(), w->view));
+        sub.ghosts_posed = true;
+    }
+    if (run == 0) {
+        // no sub-step: no collision detection, no integration — but the calls around stepSimulation still run
+        if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+        DeviceGuard guard(w->device);
+        HIP_TRY(bge::launch_pose_only(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
+                                      (flags & BGE_TICK_BULLET_BASIS) != 0));
+        w->maybe_dirty = true;
+        if (triggers) {
+            // the ghosts' pair caches did not change: ProcessTriggerEvents sees last call's overlaps again -> Stay
+            for (bge_world::Trigger& t : w->triggers) {
+                if (!t.runtime_active) continue;
+                for (uint32_t other : t.overlaps) w->trigger_events.push_back(bge_trigger_event{1u, t.entity, other});
+            }
+        }
+        const uint32_t rest = flags & (BGE_TICK_TRANSFORMS | BGE_TICK_NORMAL_MATRICES | BGE_TICK_GATHER_ROOTS);
+        if (rest & BGE_TICK_TRANSFORMS) return tick_impl(w, 1, step, gravity, rest, sub);
+        if (rest & BGE_TICK_GATHER_ROOTS) return bge_world_gather_roots(w, nullptr); // the collective is never skipped
+        return BGE_OK;
+    }
+    // sub-steps before the last one: physics only (AABBs, pairs, world matrices and the gather are observable only after
+    // the call); the teleport rule belongs to the first
+    const uint32_t inner = flags & (BGE_TICK_PHYSICS | BGE_TICK_BULLET_BASIS);
+    if (run >= 2) {
+        if (int rc = tick_impl(w, 1, step, gravity, inner, sub)) return rc;
+        sub.no_repose = true;
+        if (run > 2) {
+            if (int rc = tick_impl(w, static_cast<uint32_t>(run - 2), step, gravity, inner, sub)) return rc;
+        }
+    }
+    return tick_impl(w, 1, step, gravity, flags, sub);
+}
+BGE_CATCH_ALL("bge_world_step_simulation")
+
+int bge_world_reset_clock(bge_world* w)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    w->local_time = 0.0f;
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_reset_clock")
 
 int bge_world_tick(bge_world* w, float dt, const float gravity[3], uint32_t flags)
 try {

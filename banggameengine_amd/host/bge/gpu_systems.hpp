@@ -1,9 +1,15 @@
 // bge/gpu_systems.hpp — the reference's system call shapes on top of the C ABI (include/bge_world.h).
 //
-//   reference call site (src/core/Application.cpp)            replacement
-//   :256  m_physics.Update(m_scene, *m_camera, m_input, dt)   gpuPhysics.Update(m_scene, dt)   [rigid-body slice]
+//   reference call site (src/core/Application.cpp)            replacement (same name, same arguments)
+//   :256  m_physics.Update(m_scene, *m_camera, m_input, dt)   m_gpuPhysics.Update(m_scene, *m_camera, m_input, dt)   [rigid-body slice]
 //   :284  TransformSystem::Update(m_scene)                    bge::GpuTransformSystem<Scene>::Update(m_scene)
 //   :283,285  m_scene.CountDirtyTransforms()                  unchanged (host flags are kept coherent)
+//   :84   m_physics.ReloadConfigIfNeeded(m_scene)             m_gpuPhysics.ReloadConfigIfNeeded(m_scene)   [gravity, fixedStep]
+//   :324-326  OnSceneReloaded / GetFixedStep                  same names
+// GpuPhysicsSystem carries PhysicsSystem's public surface for this path (src/physics/PhysicsSystem.h:43-48, 77):
+// SetConfigPath, void Initialize(), OnSceneReloaded, bool ReloadConfigIfNeeded, Update(Scene&, const Camera&, const
+// InputSystem&, double), LogStats, GetFixedStep — and steps the world as the reference does: Bullet's
+// stepSimulation(dt, 4, max(fixedStep, 1/240)) with its sub-step clock (bge_world_step_simulation).
 //
 // Header-only and templated on the scene type: it needs only the accessors the reference's Scene already has
 // (GetTransforms, GetTransform, GetParent, HasTransform, GetRigidBodies, GetCollider — src/ecs/Scene.h:28-95)
@@ -27,16 +33,23 @@
 // position (the reference's Bullet body would ignore the edit).
 #pragma once
 
+#include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <filesystem>
+#include <fstream>
 #include <memory>
+#include <sstream>
+#include <string>
 #include <type_traits>
 #include <unordered_map>
 #include <utility>
 #include <vector>
 
 #include "../../../include/bge_world.h"
+#include "scene_json.hpp" // the JSON reader (physics.json)
 
 namespace bge {
 
@@ -133,6 +146,12 @@ public:
     }
 
     // --- rigid-body slice of PhysicsSystem::Update(Scene&, camera, input, dt)
+    // How UpdatePhysics steps the world: Bullet's stepSimulation(dt, max_sub_steps, fixed_step) (PhysicsSystem.cpp:855-863).
+    // max_sub_steps < 0: exactly one step of dt per call (no clock) — identical while the caller passes dt == fixed_step.
+    int max_sub_steps = 4;
+    float fixed_step = 1.0f / 120.0f;
+    int last_sub_steps = 0; // stepSimulation's return value of the last call
+
     bool UpdatePhysics(SceneT& scene, double dt)
     {
         if (!ok() || !RefreshTopology(scene) || !UploadBodies(scene) || !UploadDirtyTransforms(scene)) return false;
@@ -143,7 +162,12 @@ public:
             if (!UploadTriggers(scene, triggers)) return false;
             if (triggers) flags |= BGE_TICK_BROADPHASE; // the ghost overlaps come out of the broadphase step
         }
-        if (bge_world_tick(world_, static_cast<float>(dt), gravity, flags) != BGE_OK) return Log("bge_world_tick");
+        if (max_sub_steps < 0) {
+            last_sub_steps = 1;
+            if (bge_world_tick(world_, static_cast<float>(dt), gravity, flags) != BGE_OK) return Log("bge_world_tick");
+        } else if (bge_world_step_simulation(world_, dt, max_sub_steps, fixed_step, gravity, flags, &last_sub_steps) != BGE_OK) {
+            return Log("bge_world_step_simulation");
+        }
         trigger_events_.clear();
         if constexpr (detail::has_trigger_volumes<SceneT>::value) {
             if (triggers && !FetchTriggerEvents(scene)) return false;
@@ -172,6 +196,16 @@ public:
             written_[i] = 1;
         }
         return true;
+    }
+
+    // what LogStats prints as "bodies": the collision objects of the world (rigid bodies + active trigger ghosts)
+    int CollisionObjectCount()
+    {
+        bge_world_info info{};
+        if (!ok() || bge_world_get_info(world_, &info) != BGE_OK) return 0;
+        int n = static_cast<int>(info.n_bodies);
+        for (uint8_t a : t_active_) n += a ? 1 : 0;
+        return n;
     }
 
     // Enter / Stay / Exit of the last UpdatePhysics (what ProcessTriggerEvents publishes, PhysicsSystem.cpp:1017-1074)
@@ -506,30 +540,130 @@ public:
 
 template <class SceneT> class GpuPhysicsSystem {
 public:
-    bool Initialize() { return true; }
-    void OnSceneReloaded(SceneT& scene) { GpuMirrors<SceneT>::Drop(scene); }
-    double GetFixedStep() const { return fixedStep_; }
-    void SetGravity(float g) { gravityY_ = g; }
+    // ---- PhysicsSystem's public surface for this path (src/physics/PhysicsSystem.h:43-48, 77)
+    void SetConfigPath(std::filesystem::path path)
+    {
+        configPath_ = std::move(path);
+        hasLastWriteTime_ = false;
+    }
+    // EnsureWorld (PhysicsSystem.cpp:108-120): the device world of a scene is created on its first Update; here the
+    // GPU is probed once so that a missing device is reported at start-up, as a failed Bullet set-up would be
+    void Initialize()
+    {
+        GpuSceneMirror<SceneT> probe;
+        if (!probe.ok()) std::fprintf(stderr, "[GPU] Initialize: no usable device — %s\n", bge_last_error());
+    }
+    void OnSceneReloaded(SceneT& scene) { GpuMirrors<SceneT>::Drop(scene); } // the mirror (and its clock) is rebuilt by the next Update
+    // mtime poll of the config file, every frame (PhysicsSystem.cpp:216-240)
+    bool ReloadConfigIfNeeded(SceneT& scene)
+    {
+        if (configPath_.empty()) return false;
+        std::error_code ec;
+        const auto currentTime = std::filesystem::last_write_time(configPath_, ec);
+        if (ec) return false;
+        if (!hasLastWriteTime_ || currentTime != lastWriteTime_) {
+            lastWriteTime_ = currentTime;
+            hasLastWriteTime_ = true;
+            config_ = LoadConfigFromDisk();
+            (void)scene; // ApplyConfig's scene work is the character controllers' (out of scope); gravity reaches the world on the next Update
+            return true;
+        }
+        return false;
+    }
+    // rigid-body slice of PhysicsSystem::Update(Scene&, const Camera&, const InputSystem&, double) (PhysicsSystem.cpp:1208-1328);
+    // camera and input feed the character controller, which is not part of this path
+    template <class CameraT, class InputT> void Update(SceneT& scene, const CameraT&, const InputT&, double dt) { Step(scene, dt); }
+    void Update(SceneT& scene, double dt) { Step(scene, dt); }
+    // PhysicsSystem.cpp:1330-1341
+    void LogStats() const
+    {
+        std::printf("[Physics] bodies=%d characters=%zu stepTime=%.4fms substeps=%d fixedStep=%.4f actualDt=%.4f\n", lastBodies_,
+                    static_cast<size_t>(0), lastStepDurationMs_, lastStepSubsteps_, config_.fixedStep, lastStepDt_);
+    }
+    double GetFixedStep() const { return config_.fixedStep; }
+
+    // ---- additions
+    void SetGravity(float g) { config_.gravity = g; }
     // Bullet's own orientation scheme for every Dynamic body (include/bge_world.h, BGE_TICK_BULLET_BASIS); choose before
     // the first Update of a scene
     void SetBulletBasis(bool on) { bulletBasis_ = on; }
-    // rigid-body slice of PhysicsSystem::Update(Scene&, const Camera&, const InputSystem&, double dt)
-    void Update(SceneT& scene, double dt)
-    {
-        auto& m = GpuMirrors<SceneT>::Of(scene);
-        m.gravity[0] = 0.0f;
-        m.gravity[1] = gravityY_;
-        m.gravity[2] = 0.0f;
-        m.bullet_basis = bulletBasis_;
-        m.UpdatePhysics(scene, dt);
-    }
+    int LastSubSteps() const { return lastStepSubsteps_; }
     // trigger events of the last Update (publish them on the engine's EventBus, src/core/EventBus.h)
     const std::vector<GpuTriggerEvent>& TriggerEvents(SceneT& scene) const { return GpuMirrors<SceneT>::Of(scene).TriggerEvents(); }
 
+    // PhysicsSystem::Config (src/physics/PhysicsSystem.h:85-95); the character fields are read and kept, nothing here uses them
+    struct Config {
+        float gravity = -9.81f;
+        float fixedStep = 1.0f / 120.0f;
+        float stepHeight = 0.35f;
+        float maxSlopeDeg = 50.0f;
+        float capsuleHeight = 1.7f;
+        float capsuleRadius = 0.35f;
+        float walkSpeed = 3.5f;
+        float jumpImpulse = 5.0f;
+    };
+    const Config& GetConfig() const { return config_; }
+
 private:
-    float gravityY_ = -9.81f;
+    // LoadConfigFromDisk (PhysicsSystem.cpp:242-282): missing keys keep the current value, an unreadable or malformed
+    // file keeps the whole current config, a non-positive fixedStep becomes 1/120
+    Config LoadConfigFromDisk() const
+    {
+        Config cfg = config_;
+        std::ifstream file(configPath_);
+        if (!file.is_open()) {
+            std::fprintf(stderr, "[Physics] Failed to open config: %s\n", configPath_.string().c_str());
+            return cfg;
+        }
+        std::stringstream ss;
+        ss << file.rdbuf();
+        const std::string text = ss.str();
+        json::Value data;
+        std::string err;
+        json::Parser parser(text);
+        if (!parser.parse(data, &err) || data.kind != json::Value::Object) {
+            std::fprintf(stderr, "[Physics] Failed to parse config: %s\n", err.c_str());
+            return cfg;
+        }
+        cfg.gravity = detail::read_float(data, "gravity", cfg.gravity);
+        cfg.fixedStep = detail::read_float(data, "fixedStep", cfg.fixedStep);
+        cfg.stepHeight = detail::read_float(data, "stepHeight", cfg.stepHeight);
+        cfg.maxSlopeDeg = detail::read_float(data, "maxSlopeDeg", cfg.maxSlopeDeg);
+        cfg.walkSpeed = detail::read_float(data, "walkSpeed", cfg.walkSpeed);
+        cfg.jumpImpulse = detail::read_float(data, "jumpImpulse", cfg.jumpImpulse);
+        if (const json::Value* capsule = data.find("capsule"); capsule && capsule->kind == json::Value::Object) {
+            cfg.capsuleHeight = detail::read_float(*capsule, "height", cfg.capsuleHeight);
+            cfg.capsuleRadius = detail::read_float(*capsule, "radius", cfg.capsuleRadius);
+        }
+        if (!(cfg.fixedStep > 0.0f)) cfg.fixedStep = 1.0f / 120.0f;
+        return cfg;
+    }
+
+    void Step(SceneT& scene, double dt)
+    {
+        auto& m = GpuMirrors<SceneT>::Of(scene);
+        m.gravity[0] = 0.0f;
+        m.gravity[1] = config_.gravity; // m_world->setGravity(btVector3(0, m_config.gravity, 0)), PhysicsSystem.cpp:130, 292
+        m.gravity[2] = 0.0f;
+        m.bullet_basis = bulletBasis_;
+        m.max_sub_steps = 4;                                        // PhysicsSystem.cpp:863
+        m.fixed_step = std::max(config_.fixedStep, 1.0f / 240.0f); // kMinStep, PhysicsSystem.cpp:33, 855
+        const auto start = std::chrono::high_resolution_clock::now();
+        m.UpdatePhysics(scene, dt);
+        const auto end = std::chrono::high_resolution_clock::now();
+        lastStepDurationMs_ = std::chrono::duration<double, std::milli>(end - start).count(); // includes the pose download
+        lastStepDt_ = dt;
+        lastStepSubsteps_ = m.last_sub_steps;
+        lastBodies_ = m.CollisionObjectCount();
+    }
+
+    std::filesystem::path configPath_;
+    std::filesystem::file_time_type lastWriteTime_{};
+    bool hasLastWriteTime_ = false;
+    Config config_{};
     bool bulletBasis_ = false;
-    double fixedStep_ = 1.0f / 120.0f; // PhysicsSystem.h:88
+    double lastStepDurationMs_ = 0.0, lastStepDt_ = 0.0;
+    int lastStepSubsteps_ = 0, lastBodies_ = 0;
 };
 
 } // namespace bge

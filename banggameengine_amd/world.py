@@ -91,6 +91,16 @@ class World:
         g = (C.c_float * 3)(*gravity)
         check(lib().bge_world_tick_many(self._h, ticks, dt, g, flags))
 
+    def step_simulation(self, dt, max_sub_steps=4, fixed_step=FIXED_DT, gravity=GRAVITY, flags=TICK_PHYSICS) -> int:
+        """Bullet's stepSimulation(dt, max_sub_steps, fixed_step) around the world's ticks; returns the sub-steps due."""
+        g = (C.c_float * 3)(*gravity)
+        n = C.c_int(0)
+        check(lib().bge_world_step_simulation(self._h, float(dt), int(max_sub_steps), float(fixed_step), g, flags, C.byref(n)))
+        return int(n.value)
+
+    def reset_clock(self):
+        check(lib().bge_world_reset_clock(self._h))
+
     def sync(self):
         check(lib().bge_world_sync(self._h))
 

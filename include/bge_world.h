@@ -177,6 +177,27 @@ BGE_API int bge_world_set_velocities(bge_world* world, uint64_t first, uint64_t 
 BGE_API int bge_world_tick(bge_world* world, float dt, const float gravity[3], uint32_t flags);
 /* Enqueue `ticks` identical ticks back to back (the catch-up loop of Application::Run, Application.cpp:96-101). */
 BGE_API int bge_world_tick_many(bge_world* world, uint32_t ticks, float dt, const float gravity[3], uint32_t flags);
+/*
+ * PhysicsSystem::StepSimulation (src/physics/PhysicsSystem.cpp:848-875) = Bullet's
+ *     m_world->stepSimulation(static_cast<btScalar>(dt), 4, max(config.fixedStep, 1/240))
+ * around the world's ticks: the world keeps Bullet's clock m_localTime (binary32).  Every call adds dt to it;
+ * n = int(m_localTime / fixed_step) sub-steps of fixed_step are due (0 while the clock is below fixed_step), all n are
+ * taken off the clock, min(n, max_sub_steps) are simulated; *sub_steps (may be NULL) receives n, stepSimulation's return
+ * value.  With dt == fixed_step — what Application::Run passes (src/core/Application.cpp:96-101, 326) — that is exactly
+ * one sub-step per call and identical to bge_world_tick(world, fixed_step, gravity, flags).  max_sub_steps == 0 is Bullet's
+ * variable-step mode: one step of dt.
+ *   flags   as for bge_world_tick; BGE_TICK_PHYSICS is required.  The teleport rule (re-pose of dirty bodies) is applied
+ *           once, before the first sub-step (SyncKinematicBodiesToPhysics runs before stepSimulation); AABBs / pairs /
+ *           trigger events / world matrices / the root gather are produced once, from the state after the last sub-step
+ *           (trigger ghosts are posed from the Transforms as they were before the first).
+ *   n == 0  nothing is simulated, but what PhysicsSystem::Update does around the step still happens: dirty bodies are
+ *           re-posed, every Dynamic body's Transform is marked dirty again (SyncRigidBodiesFromPhysics), and every
+ *           remembered trigger overlap is reported as Stay (the ghosts' pair caches did not change).
+ * bge_world_reset_clock zeroes m_localTime (a new btDiscreteDynamicsWorld, e.g. after OnSceneReloaded of a new world).
+ */
+BGE_API int bge_world_step_simulation(bge_world* world, double dt, int max_sub_steps, float fixed_step, const float gravity[3],
+                                      uint32_t flags, int* sub_steps);
+BGE_API int bge_world_reset_clock(bge_world* world);
 BGE_API int bge_world_sync(bge_world* world);
 /*
  * Kernel timing with HIP events on the world's stream (the reference times its step with chrono around

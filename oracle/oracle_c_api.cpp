@@ -183,6 +183,15 @@ void orc_bulk_get_activation(void* h, uint64_t n, int32_t* state, float* time)
 void orc_set_deactivation(void* h, int enabled) { S(h)->physics.deactivation = enabled != 0; }
 
 void orc_physics_update(void* h, double dt) { S(h)->physics.Update(S(h)->scene, dt); }
+// Bullet's stepSimulation clock around the sub-steps (physics_ref.h `accumulate`); returns nothing, see orc_last_substeps
+void orc_set_accumulator(void* h, int enabled, float fixedStep, int maxSubSteps)
+{
+    S(h)->physics.accumulate = enabled != 0;
+    S(h)->physics.fixedStep = fixedStep;
+    S(h)->physics.maxSubSteps = maxSubSteps;
+    S(h)->physics.localTime = 0.0f;
+}
+int orc_last_substeps(void* h) { return S(h)->physics.lastSubSteps; }
 uint64_t orc_count_dirty(void* h) { return S(h)->scene.CountDirtyTransforms(); }
 uint64_t orc_transform_count(void* h) { return S(h)->scene.GetTransformCount(); }
 

@@ -40,6 +40,14 @@
 // (SyncKinematicBodiesToPhysics) moves it but leaves it asleep, exactly as setWorldTransform does.
 // With dt == fixedStep (src/core/Application.cpp:326, PhysicsSystem.h:77) that is exactly one
 // sub-step per tick; the caller passes that dt.
+// Bullet's accumulator around the sub-steps (btDiscreteDynamicsWorld::stepSimulation(timeStep, maxSubSteps = 4,
+// fixedTimeStep = max(config.fixedStep, 1/240)), PhysicsSystem.cpp:855-863) is restated behind `accumulate`:
+//   m_localTime += timeStep;  if (m_localTime >= fixedTimeStep) { n = int(m_localTime / fixedTimeStep);
+//   m_localTime -= n * fixedTimeStep; }   min(n, maxSubSteps) x internalSingleStepSimulation(fixedTimeStep)
+// (published Bullet code, binary32; applyGravity before and clearForces after the sub-steps make no difference to a
+// free body: the force is re-derived per sub-step here).  With n == 0 nothing is simulated, no collision detection runs —
+// the ghosts' pair caches keep last call's content, so ProcessTriggerEvents reports Stay for every remembered overlap —
+// while the re-pose rule before and the write-back + MarkDirty after the step still run.
 //
 // Angular velocity: nothing in the reference sets one, so ω = 0 for every reachable body and the solver's gyroscopic
 // impulse (BT_ENABLE_GYROSCOPIC_FORCE_IMPLICIT_BODY, Bullet's default flag) is exactly zero.  Seeding ω (bulk_set_velocity)
@@ -133,6 +141,12 @@ public:
     bool deactivation = true; // !gDisableDeactivation
     float linearSleepingThreshold = 0.8f, angularSleepingThreshold = 1.0f; // btRigidBodyConstructionInfo defaults
     float deactivationTimeLimit = 2.0f;                                     // gDeactivationTime
+    // stepSimulation's clock (off: every Update is exactly one sub-step of dt — the reference's steady state)
+    bool accumulate = false;
+    float fixedStep = 1.0f / 120.0f; // max(config.fixedStep, kMinStep) (PhysicsSystem.cpp:855)
+    int maxSubSteps = 4;
+    float localTime = 0.0f;          // btDiscreteDynamicsWorld::m_localTime
+    int lastSubSteps = 1;            // stepSimulation's return value (m_lastStepSubsteps)
 
     std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
     std::unordered_map<EntityId, RefTriggerRuntime>& TriggerRuntimes() { return triggerRuntime_; }
@@ -167,9 +181,24 @@ public:
             if (scene.IsAlive(kv.first)) EnsureTrigger(scene, kv.first, kv.second);
         }
         SyncKinematicBodiesToPhysics(scene);
-        StepSimulation(static_cast<float>(dt));
+        const float timeStep = static_cast<float>(dt);
+        int run = 1;
+        float step = timeStep;
+        lastSubSteps = 1;
+        if (accumulate) {
+            int due = 0;
+            localTime = localTime + timeStep;
+            if (localTime >= fixedStep) {
+                due = static_cast<int>(localTime / fixedStep);
+                localTime = localTime - static_cast<float>(due) * fixedStep;
+            }
+            lastSubSteps = due;
+            run = std::min(due, maxSubSteps);
+            step = fixedStep;
+        }
+        for (int k = 0; k < run; ++k) StepSimulation(step);
         SyncRigidBodiesFromPhysics(scene);
-        ProcessTriggerEvents(scene);
+        ProcessTriggerEvents(scene, run == 0);
     }
 
     // Extension used by the synthetic workloads (the reference has no API to give a body an
@@ -394,7 +423,7 @@ private:
         }
     }
 
-    void ProcessTriggerEvents(RefScene& scene)
+    void ProcessTriggerEvents(RefScene& scene, bool noStep = false)
     {
         events_.clear();
         for (auto& kv : triggerRuntime_) {
@@ -402,7 +431,9 @@ private:
             RefTriggerRuntime& rt = kv.second;
             if (!trigger || !rt.hasGhost || !rt.active) continue;
             std::vector<EntityId> current;
+            if (noStep) current = rt.overlaps; // no collision detection ran: the ghost's pair cache is last call's
             for (const auto& bk : runtime_) {
+                if (noStep) break;
                 const RefBodyRuntime& b = bk.second;
                 if (!b.hasBody || bk.first == kv.first || b.type == RefBodyType::Static) continue;
                 if ((rt.layer & b.mask) == 0 || (b.layer & rt.mask) == 0) continue;

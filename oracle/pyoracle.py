@@ -59,6 +59,9 @@ class _Lib:
         l.orc_trigger_events.restype = C.c_uint64
         l.orc_add_trigger.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         l.orc_physics_update.argtypes = [C.c_void_p, C.c_double]
+        l.orc_set_accumulator.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
+        l.orc_last_substeps.argtypes = [C.c_void_p]
+        l.orc_last_substeps.restype = C.c_int
         l.orc_set_physics_options.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         l.orc_add_rigidbody.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint32, C.c_uint32]
 
@@ -291,6 +294,13 @@ class RefScene:
 
     def PhysicsSystemUpdate(self, dt):
         lib().orc_physics_update(self.h, float(dt))
+
+    def SetAccumulator(self, enabled=True, fixed_step=1.0 / 120.0, max_sub_steps=4):
+        """Bullet's stepSimulation(dt, max_sub_steps, fixed_step) clock around the sub-steps (resets m_localTime)."""
+        lib().orc_set_accumulator(self.h, int(enabled), float(np.float32(fixed_step)), int(max_sub_steps))
+
+    def LastSubSteps(self):
+        return int(lib().orc_last_substeps(self.h))
 
     def CountDirtyTransforms(self):
         return lib().orc_count_dirty(self.h)

@@ -106,10 +106,18 @@ struct Pair {
         if (auto* t = ref.GetTransform(id)) { Put(&t->position, p); if (markDirty) t->MarkDirty(); }
         if (auto* t = gpu.GetTransform(id)) { Put(&t->position, p); if (markDirty) t->MarkDirty(); }
     }
+    double dt_override = 0.0;      // when non-zero: the dt of the next Tick
+    bool useReferenceShape = false; // call Update(Scene&, const Camera&, const InputSystem&, double)
+    int ticks = 0;
+    struct AnyCamera {} camera;
+    struct AnyInput {} input;
     void Tick()
     {
-        refPhysics.Update(ref, dt);
-        gpuPhysics.Update(gpu, dt);
+        const double d = dt_override != 0.0 ? dt_override : dt;
+        ++ticks;
+        refPhysics.Update(ref, d);
+        if (useReferenceShape) gpuPhysics.Update(gpu, camera, input, d);
+        else gpuPhysics.Update(gpu, d);
         ComparePose("after physics");
         CompareTriggerEvents();
         orc::RefTransformSystemUpdate(ref);
@@ -145,7 +153,7 @@ struct Pair {
 
 } // namespace
 
-int main()
+int main(int argc, char** argv)
 {
     {
         bge::GpuSceneMirror<bge::Scene> probe;
@@ -155,6 +163,24 @@ int main()
         }
     }
     Pair w;
+    // Application::ReloadScene -> m_physics.ReloadConfigIfNeeded(m_scene); m_fixedDt = m_physics.GetFixedStep()
+    // (src/core/Application.cpp:324-326) with the values of the reference's assets/config/physics.json
+    CHECK(w.gpuPhysics.GetFixedStep() == static_cast<double>(1.0f / 120.0f) && w.gpuPhysics.GetConfig().gravity == -9.81f, "defaults (PhysicsSystem.h:85-95)");
+    CHECK(!w.gpuPhysics.ReloadConfigIfNeeded(w.gpu), "no config path: nothing to reload");
+    if (argc > 1) {
+        w.gpuPhysics.SetConfigPath(argv[1]);
+        CHECK(w.gpuPhysics.ReloadConfigIfNeeded(w.gpu), "first poll of %s must load it", argv[1]);
+        CHECK(!w.gpuPhysics.ReloadConfigIfNeeded(w.gpu), "unchanged file: no reload");
+        const auto& cfg = w.gpuPhysics.GetConfig();
+        CHECK(cfg.gravity == -9.81f && cfg.fixedStep == 0.0083333333f && cfg.maxSlopeDeg == 55.0f && cfg.capsuleHeight == 2.6f &&
+                  cfg.capsuleRadius == 0.65f && cfg.walkSpeed == 3.6f && cfg.jumpImpulse == 8.5f && cfg.stepHeight == 0.35f,
+              "physics.json fields");
+        // the file's 0.0083333333 is one ulp BELOW 1.0f / 120.0f: the tick must be driven with GetFixedStep(), as the reference does
+        CHECK(w.gpuPhysics.GetFixedStep() == w.dt && w.gpuPhysics.GetFixedStep() != static_cast<double>(1.0f / 120.0f), "fixedStep from the file");
+    } else {
+        std::printf("usage: test_host_adapter <physics_config.json>\n");
+        return 2;
+    }
     std::mt19937 rng(1234);
     const int n = 4000;
     std::vector<uint32_t> ids;
@@ -287,6 +313,67 @@ int main()
         for (int k = 0; k < 20; ++k) w.Tick();
     }
 
-    if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, 279 ticks, %zu trigger events)\n", w.gpu.GetTransformCount(), w.events_seen);
+    // A scale edit + MarkDirty between PhysicsSystem::Update and TransformSystem::Update: the Transform is dirty
+    // anyway (the physics write-back marked it) and position / euler equal what the device holds — the edit must still
+    // reach the device, the reference recomputes `local` from the new scale in this very frame
+    {
+        w.refPhysics.Update(w.ref, w.dt);
+        w.gpuPhysics.Update(w.gpu, w.dt);
+        int edited = 0;
+        for (auto& kv : w.ref.GetRigidBodies()) {
+            if (static_cast<int>(kv.second.type) != 1 || kv.first % 3) continue;
+            const float s3[3] = {1.25f + 0.01f * (kv.first % 7), 0.75f, 2.0f};
+            auto* rt = w.ref.GetTransform(kv.first);
+            auto* gt = w.gpu.GetTransform(kv.first);
+            if (!rt || !gt) continue;
+            Put(&rt->scale, s3); rt->MarkDirty();
+            Put(&gt->scale, s3); gt->MarkDirty();
+            ++edited;
+        }
+        CHECK(edited > 50, "only %d scale edits", edited);
+        orc::RefTransformSystemUpdate(w.ref);
+        bge::GpuTransformSystem<bge::Scene>::Update(w.gpu);
+        w.CompareAll("scale edited between the two systems");
+        w.Tick();
+    }
+
+    // Bullet's sub-step clock (stepSimulation(dt, 4, fixedStep), PhysicsSystem.cpp:855-863) through the reference-shaped
+    // Update(Scene&, const Camera&, const InputSystem&, double): dt = 0.5x (every other call steps), 1x, 2.5x (2 or 3
+    // sub-steps), 6x (6 due, 4 simulated, the rest dropped), a hot-reloaded fixedStep, and teleports / body re-creation /
+    // trigger events in calls that simulate nothing
+    {
+        struct Camera {} camera;
+        struct InputSystem {} input;
+        w.refPhysics.accumulate = true;
+        w.refPhysics.localTime = 0.0f;
+        w.refPhysics.fixedStep = std::max(w.gpuPhysics.GetConfig().fixedStep, 1.0f / 240.0f); // PhysicsSystem.cpp:855
+        w.useReferenceShape = true;
+        const double fixed = w.gpuPhysics.GetFixedStep();
+        CHECK(fixed == w.dt, "fixedStep of the loaded config");
+        const double factors[] = {0.5, 0.5, 0.5, 1.0, 2.5, 2.5, 6.0, 0.25, 0.25, 0.25, 0.25, 1.0, 0.3, 3.7, 0.1};
+        int k = 0, zero_calls = 0, clamped_calls = 0;
+        for (double fct : factors) {
+            w.dt_override = fct * fixed;
+            if (k == 1 || k == 8) { // a call that simulates nothing still teleports and re-creates
+                float p[3] = {1.0f + k, 20.0f, -3.0f};
+                w.Move(ids[2100 + k], p, true);
+                for (auto& kv : w.ref.GetRigidBodies()) { if (kv.first % 11 == 0) kv.second.dirty = true; }
+                for (auto& kv : w.gpu.GetRigidBodies()) { if (kv.first % 11 == 0) kv.second.dirty = true; }
+            }
+            w.Tick();
+            CHECK(w.gpuPhysics.LastSubSteps() == w.refPhysics.lastSubSteps, "call %d (dt = %.2f x fixedStep): %d sub-steps vs %d in the oracle", k, fct,
+                  w.gpuPhysics.LastSubSteps(), w.refPhysics.lastSubSteps);
+            zero_calls += w.refPhysics.lastSubSteps == 0;
+            clamped_calls += w.refPhysics.lastSubSteps > 4;
+            ++k;
+        }
+        CHECK(zero_calls >= 5 && clamped_calls >= 1, "the dt script must cover 0 sub-steps (%d calls) and > 4 (%d calls)", zero_calls, clamped_calls);
+        (void)camera; (void)input;
+        w.dt_override = 0.0;
+        w.refPhysics.accumulate = false;
+        w.useReferenceShape = false;
+    }
+
+    if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, %d ticks, %zu trigger events)\n", w.gpu.GetTransformCount(), w.ticks, w.events_seen);
     return g_failures ? 1 : 0;
 }

@@ -557,6 +557,79 @@ def test_trigger_events_match_oracle_every_tick():
     assert seen_types == {0, 1, 2}                              # the scene really produced Enter, Stay and Exit
 
 
+@pytest.mark.parametrize("basis", [False, True])
+def test_step_simulation_clock_matches_oracle(basis):
+    """bge_world_step_simulation = Bullet's stepSimulation(dt, 4, fixedStep) around the ticks (PhysicsSystem.cpp:855-863;
+    VERDICT r01 missing #3): dt = 0.5x, 1x, 2.5x, 6x fixedStep and odd fractions.  Sub-step counts, poses, velocities, fed
+    AABBs, world matrices, dirty flags and trigger events must equal the oracle's after every call — including calls that
+    simulate nothing (they still teleport dirty bodies, mark Dynamic transforms dirty and report Stay for every
+    remembered overlap) and calls whose 6 due sub-steps are clamped to 4.  Fused (physics + transforms in one call) and
+    split (as the adapter calls them) forms; default and Bullet-basis orientation schemes."""
+    n = 4000
+    wl = synth.Workload("cube", synth.CHAINS4, n, 777, pos_box=synth.CUBE, bodies_on_roots_only=True)
+    wl.pos = (wl.pos * np.float32(15.0 / 262.0)).astype(np.float32)
+    wl.pos[:, 1] += np.float32(3.0)
+    rng = np.random.default_rng(21)
+    roots = np.flatnonzero(wl.parent == 0xFFFFFFFF)
+    wl.body_type[roots] = rng.choice([0, 1, 1, 1, 2], len(roots)).astype(np.uint8)
+    trig_entities = rng.choice(roots, 12, replace=False).astype(np.uint32)
+    t_size = rng.uniform(1.0, 4.0, (12, 3)).astype(np.float32)
+    t_oneshot = (rng.random(12) < 0.25).astype(np.uint8)
+    mode = po.ORIENT_BASIS if basis else po.ORIENT_IDEAL
+    bflag = B.TICK_BULLET_BASIS if basis else 0
+    fixed = DT
+    script = [1.0, 0.5, 0.5, 0.5, 2.5, 2.5, 6.0, 0.25, 0.25, 0.25, 0.25, 1.0, 0.3, 3.7, 0.1, 0.95, 1.0]
+    for fused in (True, False):
+        ref = build_oracle(wl, orient_mode=mode, aabbs=True)
+        for k in range(12):
+            ref.AddTriggerVolume(int(trig_entities[k]) + 1, 0, t_size[k], 0, 0xFFFFFFFF, bool(t_oneshot[k]), True)
+        ref.SetAccumulator(True, fixed, 4)
+        counts = []
+        with B.World(pair_capacity=64 * n) as w:
+            w.load(wl)
+            w.upload_triggers(trig_entities, None, t_size, None, None, t_oneshot, None)
+            for call, factor in enumerate(script):
+                dt = float(np.float64(factor) * np.float64(fixed))
+                if call in (2, 8):   # inside calls that simulate nothing: a teleport and a re-created body
+                    e = int(roots[5 + call])
+                    new_pos = np.array([[1.0, 9.0 + call, -2.0]], np.float32)
+                    ref.SetTRS(e + 1, pos=new_pos[0])
+                    w.upload_trs(pos=new_pos, first=e)
+                    ref.MarkBodyDirty(int(roots[40]) + 1)
+                    w.upload_bodies(wl.body_type[roots[40]:roots[40] + 1], first=int(roots[40]))
+                ref.PhysicsSystemUpdate(dt)
+                if fused:
+                    got_n = w.step_simulation(dt, 4, fixed, flags=B.TICK_ALL | B.TICK_BROADPHASE | bflag)
+                else:
+                    got_n = w.step_simulation(dt, 4, fixed, flags=B.TICK_PHYSICS | B.TICK_BROADPHASE | bflag)
+                    pos, euler = w.download_pose()
+                    rpos, reuler = ref.bulk_pose()
+                    assert_bits_equal(pos, rpos, f"call {call}: position after physics")
+                    assert_bits_equal(euler, reuler, f"call {call}: rotationEuler after physics")
+                    assert np.array_equal(w.download_dirty(), ref.bulk_world()[1].astype(bool)), f"call {call}: dirty after physics"
+                    w.tick(dt=DT, flags=B.TICK_TRANSFORMS)
+                ref.TransformSystemUpdate()
+                assert got_n == ref.LastSubSteps(), f"call {call} (dt = {factor} x fixedStep): {got_n} sub-steps, oracle {ref.LastSubSteps()}"
+                counts.append(got_n)
+                if call == 0:
+                    ref.bulk_set_velocity(wl.vel * np.float32(3.0))
+                    w.set_velocities(wl.vel * np.float32(3.0))
+                want_world, want_dirty = ref.bulk_world()
+                assert_bits_equal(w.download_world(), want_world, f"call {call}: world")
+                assert np.array_equal(w.download_dirty(), want_dirty.astype(bool)), f"call {call}: dirty"
+                rb, gb = ref.bulk_bodies(), w.download_bodies()
+                ex = rb["exists"]
+                dyn = ex & (wl.body_type == 1)   # (the oracle's velocity seeding also writes into static / kinematic records)
+                assert_bits_equal(gb["linvel"][dyn], rb["linvel"][dyn], f"call {call}: velocity")
+                assert_bits_equal(gb["quat"][ex], rb["quat"][ex], f"call {call}: quaternion")
+                if got_n > 0:
+                    assert_bits_equal(gb["aabb"][ex], rb["aabb"][ex], f"call {call}: fed AABBs")
+                want_ev = ref.TriggerEvents()
+                want_ev[:, 1:] -= 1
+                assert np.array_equal(w.trigger_events(), want_ev), f"call {call}: trigger events"
+        assert counts.count(0) >= 6 and max(counts) == 6 and 2 in counts and 3 in counts, counts
+
+
 def test_transform_fixtures_incl_multi_pass_layouts():
     """tests/golden/transform_cases.npz on the GPU: flat, chains, subtrees, a forest with Transform-less parents, a
     600-deep chain (three dependent passes) and a 700-wide root (children in a later pass read the parent from memory)."""

@@ -6,6 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
+PHYSICS_JSON = os.path.join(ROOT, "tests", "golden", "physics_config.json")  # values of the reference's assets/config/physics.json
 
 
 def _build():
@@ -18,14 +19,14 @@ def test_adapter_compiles_and_reports_missing_gpu():
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present; the gpu-marked test runs the program")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, PHYSICS_JSON], capture_output=True, text=True, timeout=120)
     assert r.returncode == 77 and "no usable GPU" in r.stdout  # loud failure, no CPU fallback
 
 
 @pytest.mark.gpu
 def test_adapter_matches_oracle_through_scripted_scene_edits():
     exe = _build()
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, PHYSICS_JSON], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
 
@@ -64,3 +65,19 @@ def test_host_logic_under_address_and_ub_sanitizers():
     r = subprocess.run([os.path.join(CPP, "sanitize_host")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "sanitize_host ok" in r.stdout
+
+
+def test_adapter_instantiates_on_the_references_exact_member_signatures():
+    """Compile-only (g++ -std=c++20 -c -Werror): bge/gpu_systems.hpp and bge/scene_json.hpp on a mock whose Scene, Transform,
+    RigidBody, Collider and TriggerVolume have exactly the reference's member signatures (src/ecs/Scene.h:19-109) — the
+    const / non-const accessor pairs included — driven through the calls src/core/Application.cpp makes:
+    Update(Scene&, const Camera&, const InputSystem&, double), void Initialize(), bool ReloadConfigIfNeeded(Scene&),
+    GetFixedStep(), LogStats(), OnSceneReloaded(Scene&), static TransformSystem::Update(Scene&)."""
+    _build()
+    obj = os.path.join(CPP, "compile_reference_shapes.o")
+    assert os.path.exists(obj)
+    syms = subprocess.run(["nm", "-C", "--undefined-only", obj], capture_output=True, text=True).stdout
+    # the object really calls the mock's members (declared, never defined) and the C ABI
+    for needed in ("Scene::GetTransforms()", "Scene::GetRigidBodies()", "Scene::GetTriggerVolumes()", "Scene::GetParent(unsigned int) const",
+                   "Scene::AddTriggerVolume(unsigned int)", "bge_world_step_simulation", "bge_world_tick"):
+        assert needed in syms, needed
