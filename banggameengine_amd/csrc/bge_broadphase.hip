@@ -81,6 +81,9 @@ struct Accum {
     // widest extent seen in each bin (float bits; extents are positive), same copies: the cell size is the widest SMALL
     // body, not the upper edge of its bin — edges are 19-25 % apart and the number of AABB tests grows with the cube of the cell
     uint32_t extent_max[kHistShards][kExtentBins];
+    // "large" weight of every bin: bodies (k_bp_bounds: each body counts itself) or waves (k_bp_reduce_partials: the tick
+    // kernel reports one widest extent per wave, so a bin above the chosen edge stands for at least that many large bodies)
+    uint32_t extent_large[kHistShards][kExtentBins];
     uint32_t scan_ticket;              // tile tickets of k_scan_lookback (dispatch order)
     uint32_t scan_error;               // a look-back gave up (never observed; keeps a logic error from hanging the GPU)
 };
@@ -197,6 +200,112 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
         const uint32_t h = hist[k];
         if (h) {
             atomicAdd(&acc->extent_hist[blockIdx.x % kHistShards][k], h);
+            atomicAdd(&acc->extent_large[blockIdx.x % kHistShards][k], h);
+            if (hmax[k]) atomicMax(&acc->extent_max[blockIdx.x % kHistShards][k], hmax[k]);
+        }
+    }
+}
+
+// The same accumulators from the per-wave partials the tick kernel wrote beside the AABBs (TickParams::bp_partial: bounds,
+// body count and widest extent of each wave's 64 slots) — 32 bytes per wave instead of a pass over 28 bytes per body.  The
+// extent histogram is then a histogram of WAVE maxima: bin b holds the bodies of the waves whose widest body falls into b
+// (they are all at most that wide) and, as its "large" weight, the number of such waves.  Good enough to choose the cell
+// size — the choice only affects speed: whatever the cell, a body wider than it is treated as large by the sort itself.
+constexpr uint32_t kReduceBlocks = 128;
+__global__ void __launch_bounds__(256) k_bp_reduce_partials(const float4* __restrict__ partials, uint32_t n_partials, Accum* acc)
+{
+    __shared__ uint32_t hist[kExtentBins];
+    __shared__ uint32_t hwaves[kExtentBins];
+    __shared__ uint32_t hmax[kExtentBins];
+    __shared__ float red[4][6];
+    __shared__ uint32_t red_cnt[4];
+    for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) {
+        hist[k] = 0;
+        hwaves[k] = 0;
+        hmax[k] = 0;
+    }
+    __syncthreads();
+    float mn[3] = {INFINITY, INFINITY, INFINITY};
+    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t cnt = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n_partials + stride - 1u) / stride; // uniform trip count: the aggregation ballots across the wave
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x + r * stride;
+        uint32_t my_bin = 0, my_count = 0, my_ext = 0;
+        bool have_bin = false;
+        if (q < n_partials) {
+            const float4 a = partials[2ull * q], b = partials[2ull * q + 1ull];
+            my_count = __float_as_uint(b.w);
+            if (my_count) {
+                mn[0] = fminf(mn[0], a.x);
+                mn[1] = fminf(mn[1], a.y);
+                mn[2] = fminf(mn[2], a.z);
+                mx[0] = fmaxf(mx[0], b.x);
+                mx[1] = fmaxf(mx[1], b.y);
+                mx[2] = fmaxf(mx[2], b.z);
+                cnt += my_count;
+                const float e = a.w;
+                const bool ok = e > 0.0f && e < INFINITY;
+                my_bin = ok ? extent_bin(e) : 0u;
+                my_ext = ok ? __float_as_uint(e) : 0u;
+                have_bin = true;
+            }
+        }
+        // wave-aggregated histogram update (the waves of a scene share a few bins), as in k_bp_bounds
+        while (true) {
+            const unsigned long long pending = __ballot(have_bin);
+            if (pending == 0) break;
+            const int leader = __ffsll(static_cast<long long>(pending)) - 1;
+            const uint32_t lead_bin = __shfl(my_bin, leader, 64);
+            const bool mine = have_bin && my_bin == lead_bin;
+            uint32_t c = mine ? my_count : 0u, e = mine ? my_ext : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                c += __shfl_xor(c, off, 64);
+                e = max(e, static_cast<uint32_t>(__shfl_xor(e, off, 64)));
+            }
+            const unsigned long long same = __ballot(mine);
+            if (static_cast<int>(threadIdx.x & 63u) == leader) {
+                atomicAdd(&hist[lead_bin], c);
+                atomicAdd(&hwaves[lead_bin], static_cast<uint32_t>(__popcll(same)));
+                atomicMax(&hmax[lead_bin], e);
+            }
+            if (mine) have_bin = false;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], __shfl_down(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, 64));
+        }
+        cnt += __shfl_down(cnt, off, 64);
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) {
+        for (int a = 0; a < 3; ++a) {
+            red[wave][a] = mn[a];
+            red[wave][3 + a] = mx[a];
+        }
+        red_cnt[wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int wv = 0; wv < 4; ++wv) total += red_cnt[wv];
+        for (int a = 0; a < 3; ++a) {
+            acc->part_min[blockIdx.x][a] = fminf(fminf(red[0][a], red[1][a]), fminf(red[2][a], red[3][a]));
+            acc->part_max[blockIdx.x][a] = fmaxf(fmaxf(red[0][3 + a], red[1][3 + a]), fmaxf(red[2][3 + a], red[3][3 + a]));
+        }
+        acc->part_count[blockIdx.x] = total;
+    }
+    for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) {
+        const uint32_t h = hist[k];
+        if (h) {
+            atomicAdd(&acc->extent_hist[blockIdx.x % kHistShards][k], h);
+            atomicAdd(&acc->extent_large[blockIdx.x % kHistShards][k], hwaves[k]);
             if (hmax[k]) atomicMax(&acc->extent_max[blockIdx.x % kHistShards][k], hmax[k]);
         }
     }
@@ -220,6 +329,7 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
 {
     constexpr uint32_t kWaves = kParamsThreads / 64;
     __shared__ uint32_t below[kExtentBins + 1]; // exclusive prefix: bodies in bins < b
+    __shared__ uint32_t lbelow[kExtentBins + 1]; // the same prefix over the bins' "large" weights (bodies, or waves)
     __shared__ uint32_t binmax[kExtentBins];    // widest extent in the bin (float bits)
     __shared__ float red[kWaves][6];
     __shared__ uint32_t red_cnt[kWaves];
@@ -238,15 +348,18 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
             cnt += acc->part_count[b];
         }
         for (uint32_t b = threadIdx.x; b < kExtentBins; b += kParamsThreads) {
-            uint32_t t = 0, m = 0;
+            uint32_t t = 0, m = 0, lw = 0;
 #pragma unroll
             for (uint32_t c = 0; c < kHistShards; ++c) {
                 t += acc->extent_hist[c][b];
+                lw += acc->extent_large[c][b];
                 m = max(m, acc->extent_max[c][b]);
                 acc->extent_hist[c][b] = 0; // consumed: ready for the next run's k_bp_bounds (there is no reset kernel)
+                acc->extent_large[c][b] = 0;
                 acc->extent_max[c][b] = 0;
             }
             below[b] = t; // the totals, for the moment
+            lbelow[b] = lw;
             binmax[b] = m;
         }
         // the counters the REST of this run accumulates into (every kernel that touches them is launched after this one)
@@ -297,26 +410,29 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
     }
     {
         // exclusive prefix of the histogram: 16 consecutive bins per lane + a wave64 __shfl_up scan of the lane totals
-        uint32_t h[16];
-        uint32_t sum = 0;
+        for (int which = 0; which < 2; ++which) {
+            uint32_t* arr = which ? lbelow : below;
+            uint32_t h[16];
+            uint32_t sum = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            h[k] = below[lane * 16 + k];
-            sum += h[k];
-        }
-        uint32_t incl = sum;
+            for (int k = 0; k < 16; ++k) {
+                h[k] = arr[lane * 16 + k];
+                sum += h[k];
+            }
+            uint32_t incl = sum;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= static_cast<uint32_t>(off)) incl += t;
-        }
-        uint32_t run = incl - sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, 64);
+                if (lane >= static_cast<uint32_t>(off)) incl += t;
+            }
+            uint32_t run = incl - sum;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            below[lane * 16 + k] = run;
-            run += h[k];
+            for (int k = 0; k < 16; ++k) {
+                arr[lane * 16 + k] = run;
+                run += h[k];
+            }
+            if (lane == 63) arr[kExtentBins] = run;
         }
-        if (lane == 63) below[kExtentBins] = run;
     }
     wave_sync();
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -338,7 +454,9 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
         if (small == 0 && n != 0 && b + 2 < kExtentBins) continue; // an edge below every body: nothing would be small
         const double c = static_cast<double>(extent_bin_upper(b));
         if (!(c > 0.0) || !(c < 1.0e30)) continue;
-        const double large = static_cast<double>(n - small);
+        // bodies that would be large: every body of a bin above the edge (k_bp_bounds), or at least one per wave whose
+        // widest body lies above it (k_bp_reduce_partials)
+        const double large = static_cast<double>(lbelow[kExtentBins] - lbelow[b + 1]);
         const double cost = static_cast<double>(small) * small / volume * c * c * c * 13.5 + large * n + 1.0e-9 * b;
         if (cost < best_cost) {
             best_cost = cost;
@@ -1523,6 +1641,7 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
     if (const char* e = std::getenv("BGE_BP_PAIRS")) block_pairs_ = std::string(e) == "block";  // A/B: workgroup-granular pair search
     sort_groups_ = kSortGroups;
     if (const char* e = std::getenv("BGE_BP_SORT_GROUPS")) sort_groups_ = std::min<uint32_t>(kSortGroups, std::max(1, std::atoi(e))); // tests: several passes per workgroup at small n
+    if (const char* e = std::getenv("BGE_BP_BOUNDS")) fused_bounds_ = std::string(e) != "pass"; // A/B and tests: k_bp_bounds' own pass over the AABBs
     if (const char* e = std::getenv("BGE_BP_FILTER")) small_palette_ = std::string(e) != "table"; // A/B and tests: keep the (group, mask) table
     if (const char* e = std::getenv("BGE_BP_COARSE")) transposed_coarse_ = std::string(e) != "scatter"; // A/B: per-thread scattered record writes
     if (const char* e = std::getenv("BGE_BP_RECORDS")) full_records_ = std::atoi(e) == 48;  // A/B: BGE_BP_RECORDS=48 keeps full records
@@ -1577,7 +1696,7 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
 }
 
 int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const uint32_t* entity_of_slot, const PairWindow* window,
-                    const FilterPalette* palette)
+                    const FilterPalette* palette, const float4* wave_partials)
 {
     const bool compact_records = palette && palette->class_of_slot && palette->table && !window && !full_records_;
     if (n > n_slots_) {
@@ -1605,8 +1724,15 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     const uint32_t scan_blocks = blocks_for(scan_n, kScanBlock);
     const uint32_t slot_blocks = blocks_for(n, 256);
 
-    const uint32_t bounds_blocks = std::min<uint32_t>(slot_blocks, kBoundsBlocks);
-    hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
+    uint32_t bounds_blocks = std::min<uint32_t>(slot_blocks, kBoundsBlocks);
+    if (wave_partials && fused_bounds_) {
+        // the tick kernel left one partial per wave beside the AABBs: 32 bytes per 64 slots instead of 28 per slot
+        const uint32_t n_partials = static_cast<uint32_t>(n / 64);
+        bounds_blocks = std::min<uint32_t>(kReduceBlocks, blocks_for(n_partials, 256));
+        hipLaunchKernelGGL(k_bp_reduce_partials, dim3(bounds_blocks), dim3(256), 0, stream, wave_partials, n_partials, acc);
+    } else {
+        hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
+    }
     hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(kParamsThreads), 0, stream, acc, table_size_, bounds_blocks);
     if (lds_sort_) {
         const uint32_t groups = std::min<uint32_t>(sort_groups_, blocks_for(n, kSortThreads));

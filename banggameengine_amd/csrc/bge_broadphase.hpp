@@ -29,7 +29,7 @@ public:
     int configure(uint64_t n_slots, uint64_t pair_capacity);
     // Collect the overlapping pairs of the AABBs the tick kernel just wrote.
     int run(hipStream_t stream, const WorldView& w, uint64_t n_slots_ticked, const uint32_t* entity_of_slot,
-            const PairWindow* window = nullptr, const FilterPalette* palette = nullptr);
+            const PairWindow* window = nullptr, const FilterPalette* palette = nullptr, const float4* wave_partials = nullptr);
     int download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uint64_t* total);
     // The search leaves the pairs in 64 shard slices; this builds the compact list (idempotent until the next run).
     int compact(hipStream_t stream);
@@ -60,6 +60,7 @@ private:
     uint32_t sort_shift_ = 12, sort_buckets_ = 0;
     void *sort_matrix_ = nullptr, *sort_offsets_ = nullptr, *sort_status_ = nullptr, *coarse_ = nullptr;
     bool block_pairs_ = false;
+    bool fused_bounds_ = true;      // grid from the tick kernel's per-wave partials (TickParams::bp_partial) when the caller has them; BGE_BP_BOUNDS=pass for A/B
     uint32_t sort_groups_ = 512;    // chunk workgroups of the coarse passes (BGE_BP_SORT_GROUPS lowers it: tests)
     uint32_t fine_window_[2] = {0, 0}; // records in k_sort_fine_t's LDS window: [0] 48-byte records, [1] 32-byte records
     bool small_palette_ = true;     // wave search: one compatibility word per class when the palette has <= 32 classes

@@ -106,6 +106,28 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Wave64 reductions with DPP (one VALU instruction per step, no LDS): after the six steps lane 63 holds the result.
+// row_shr 1/2/4/8 make an inclusive scan inside each row of 16 lanes (min / max are idempotent, so overlapping windows are
+// fine); row_bcast:15 carries each row's last lane into the next row (rows 1 and 3), row_bcast:31 lane 31 into rows 2 and 3.
+// Lanes that must not contribute pass the identity.  Call with all 64 lanes active.
+template <bool IS_MIN> __device__ __forceinline__ float wave_reduce_to_lane63(float v)
+{
+    const int ident = __float_as_int(IS_MIN ? INFINITY : -INFINITY);
+#define BGE_DPP_STEP(ctrl, rmask)                                                                                      \
+    {                                                                                                                 \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(ident, __float_as_int(v), ctrl, rmask, 0xf, false)); \
+        v = IS_MIN ? fminf(v, o) : fmaxf(v, o);                                                                        \
+    }
+    BGE_DPP_STEP(0x111, 0xf) // row_shr:1
+    BGE_DPP_STEP(0x112, 0xf) // row_shr:2
+    BGE_DPP_STEP(0x114, 0xf) // row_shr:4
+    BGE_DPP_STEP(0x118, 0xf) // row_shr:8
+    BGE_DPP_STEP(0x142, 0xa) // row_bcast:15 -> rows 1, 3
+    BGE_DPP_STEP(0x143, 0xc) // row_bcast:31 -> rows 2, 3
+#undef BGE_DPP_STEP
+    return v;
+}
+
 #ifdef BGE_EXPERIMENT_NO_SLEEP /* timing-only A/B build: bodies never fall asleep */
 constexpr bool kSleepEnabled = false;
 #else
@@ -142,6 +164,9 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
         if (XFORM) scl = ld3(w.scale, slot);
     }
 
+    // (AABB variants) this lane's fed box for the wave's broadphase partial: identity when the slot carries no body
+    float box_mn[3] = {INFINITY, INFINITY, INFINITY}, box_mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool has_box = false;
     if (PHYS) {
         const uint32_t type = f & kTypeMask;
         if (valid && type != 0) {
@@ -199,7 +224,10 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 for (int a = 0; a < 3; ++a) {
                     bb[a] = mn[a];
                     bb[3 + a] = mx[a];
+                    box_mn[a] = mn[a];
+                    box_mx[a] = mx[a];
                 }
+                has_box = true;
             }
 
             if (dynamic) {
@@ -280,6 +308,28 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 f |= kTDirty; // transform->MarkDirty()
             }
             f &= ~kBDirty;
+        }
+    }
+
+    if (AABB && PHYS) {
+        // Broadphase partial of this wave (replaces a pass of k_bp_bounds over all AABBs): bounds, body count, widest box.
+        // The extent is the expression the sort's large-body test evaluates (bge_broadphase.hip body_is_large).
+        if (p.bp_partial) { // uniform
+            float ext = fmaxf(fmaxf(box_mx[0] - box_mn[0], box_mx[1] - box_mn[1]), box_mx[2] - box_mn[2]);
+            if (!(has_box && ext > 0.0f && ext < INFINITY)) ext = -INFINITY;
+            const unsigned long long boxes = __ballot(has_box);
+            float r[7];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                r[a] = wave_reduce_to_lane63<true>(box_mn[a]);
+                r[3 + a] = wave_reduce_to_lane63<false>(box_mx[a]);
+            }
+            r[6] = wave_reduce_to_lane63<false>(ext);
+            if ((tid & 63u) == 63u) {
+                float4* dst = p.bp_partial + 2ull * (4ull * tile + (tid >> 6));
+                dst[0] = make_float4(r[0], r[1], r[2], r[6]);
+                dst[1] = make_float4(r[3], r[4], r[5], __uint_as_float(static_cast<uint32_t>(__popcll(boxes))));
+            }
         }
     }
 

@@ -55,6 +55,9 @@ struct TickParams {
     uint32_t tile_begin;
     uint32_t nt_out; // non-temporal stores for world / normal matrices (working set larger than the Infinity Cache)
     float* root_out; // when non-null: roots also write their world matrix (compact, 12 floats) to root_out[root_index] (send buffer of the gather)
+    float4* bp_partial; // when non-null (AABB variants): every wave also writes the bounds of its bodies' fed AABBs, their
+                        // number and the widest one — 2 x float4 at bp_partial[2 * (tile * 4 + wave)]: (min.xyz, widest extent),
+                        // (max.xyz, count bits) — so that the broadphase needs no pass of its own over the AABBs for the grid
     uint32_t no_repose; // this tick is the 2nd..nth sub-step of ONE stepSimulation call (bge_world_step_simulation): dirty flags
                         // do not re-pose bodies — SyncKinematicBodiesToPhysics ran once, before the first sub-step
 };

@@ -144,6 +144,7 @@ struct bge_world {
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
     DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table, grav_palette;
+    DevBuf bp_partials; // per-wave bounds / count / widest extent written by the tick kernel for the broadphase (32 B per wave)
     float grav_cached[3] = {0.0f, 0.0f, 0.0f};
     bool grav_palette_stale = true; // the mass palette or the gravity vector changed since the table was built
     // Collision-filter palette: scenes use a handful of (layer, mask, static) combinations, so the broadphase's sorted
@@ -270,7 +271,7 @@ struct bge_world {
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count}) {
             b->release();
         }
@@ -1055,6 +1056,15 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
             // ghost boxes from the Transforms as they are before the step
             HIP_TRY(bge::launch_trigger_aabb(w->stream, static_cast<uint32_t>(w->triggers.size()), w->trigger_view(), w->view));
         }
+        if (flags & BGE_TICK_BROADPHASE) {
+            // the broadphase takes its grid from per-wave partials the tick kernel writes beside the AABBs
+            const size_t need = std::max<size_t>(w->flat.n_tiles_total, 1) * 4 * 32;
+            if (w->bp_partials.bytes < need) {
+                HIP_TRY(hipStreamSynchronize(w->stream));
+                HIP_TRY(w->bp_partials.ensure(need));
+            }
+            p.bp_partial = w->bp_partials.as<float4>();
+        }
         const size_t n_passes = w->flat.pass_tile_begin.size() - 1;
         // BGE_TICK_GATHER_ROOTS with a transform pass: the roots write the all-gather's send buffer themselves
         const bool fused_gather = (flags & BGE_TICK_GATHER_ROOTS) && xform;
@@ -1108,7 +1118,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
                                              w->filter_overflow ? nullptr : w->filter_table.as<uint4>(),
                                              static_cast<uint32_t>(w->filter_palette.size())};
             rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
-                                   w->entity_of_slot.as<uint32_t>(), nullptr, &palette);
+                                   w->entity_of_slot.as<uint32_t>(), nullptr, &palette, w->bp_partials.as<float4>());
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
             w->pairs_from_slab = false;
             if (with_triggers) {
