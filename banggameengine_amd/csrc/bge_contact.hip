@@ -1,0 +1,689 @@
+// bge_contact.hip — the static ground plane of the reference's physics world and Bullet's contact handling for it, one
+// thread per body.
+//
+// The reference adds an infinite static plane at y = 0 (friction 1, restitution 0) to every world
+// (src/physics/PhysicsSystem.cpp:149-166) and steps with Bullet's default narrowphase and sequential-impulse solver
+// (:122-128, :863).  Bodies do not collide with each other on this path: every Dynamic body is an island of its own whose
+// only manifold is the one with the plane, so the step is independent per body and maps onto one thread:
+//   k_ground   performDiscreteCollisionDetection for (plane, body) — btConvexPlaneCollisionAlgorithm: one contact per step at
+//              the shape's support vertex, kept in a 4-point persistent manifold (nearest-point replacement, area-based
+//              eviction, refresh with removal beyond the breaking threshold) — and solveConstraints for the island {body}:
+//              external force impulse, implicit gyroscopic impulse, contact and friction rows with warm starting,
+//              10 split-impulse iterations, 10 velocity iterations, write-back of velocities, impulses and the pushed pose.
+//              A body without a contact and without angular velocity is left to k_tick's plain update (the same arithmetic).
+//   k_tick     then integrates the pose with the velocities found here (cinfo bit kCiSolved: gravity is already in them).
+// The arithmetic — operation order, where Bullet's compiled row solvers fuse multiply-adds, which dot products add in
+// which order — is oracle/contact_ref.h's (that header states what is pinned by the reference's exe and what is not);
+// tests/test_gpu_parity.py compares every body bit for bit.  Heavy per-thread state (four contact rows and four friction
+// rows) makes this a register-hungry kernel; it touches only bodies at the ground, so it is sized for correctness first.
+#include <hip/hip_runtime.h>
+
+#include "bge_device_math.hpp"
+#include "bge_flatten.hpp"
+#include "bge_kernels.hpp"
+
+namespace bge {
+
+using namespace dev;
+
+namespace {
+
+__device__ __forceinline__ F3 add3(const F3& a, const F3& b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 sub3(const F3& a, const F3& b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 scale3(const F3& a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot3(const F3& a, const F3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross3(const F3& a, const F3& b) { return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ F3 mat_vec(const M3& m, const F3& v)
+{
+    return F3{m.m[0][0] * v.x + m.m[0][1] * v.y + m.m[0][2] * v.z, m.m[1][0] * v.x + m.m[1][1] * v.y + m.m[1][2] * v.z,
+              m.m[2][0] * v.x + m.m[2][1] * v.y + m.m[2][2] * v.z};
+}
+__device__ __forceinline__ F3 mat_t_vec(const M3& m, const F3& v)
+{
+    return F3{m.m[0][0] * v.x + m.m[1][0] * v.y + m.m[2][0] * v.z, m.m[0][1] * v.x + m.m[1][1] * v.y + m.m[2][1] * v.z,
+              m.m[0][2] * v.x + m.m[1][2] * v.y + m.m[2][2] * v.z};
+}
+
+struct CtShape {
+    bool capsule;
+    F3 dims; // box: half extents with margin; capsule: (radius, half height, radius)
+};
+
+__device__ __forceinline__ F3 ct_local_inertia(const CtShape& s, float mass)
+{
+    if (s.capsule) {
+        const float radius = s.dims.x;
+        const float hx = radius, hy = radius + s.dims.y, hz = radius;
+        const float lx = 2.0f * hx, ly = 2.0f * hy, lz = 2.0f * hz;
+        const float x2 = lx * lx, y2 = ly * ly, z2 = lz * lz;
+        const float scaledmass = mass * 0.08333333f;
+        return F3{scaledmass * (y2 + z2), scaledmass * (x2 + z2), scaledmass * (x2 + y2)};
+    }
+    const float lx = 2.0f * s.dims.x, ly = 2.0f * s.dims.y, lz = 2.0f * s.dims.z;
+    return F3{mass / 12.0f * (ly * ly + lz * lz), mass / 12.0f * (lx * lx + lz * lz), mass / 12.0f * (lx * lx + ly * ly)};
+}
+__device__ __forceinline__ F3 ct_inv_inertia_local(const F3& i)
+{
+    return F3{i.x != 0.0f ? 1.0f / i.x : 0.0f, i.y != 0.0f ? 1.0f / i.y : 0.0f, i.z != 0.0f ? 1.0f / i.z : 0.0f};
+}
+__device__ __forceinline__ M3 ct_inv_inertia_world(const M3& b, const F3& il)
+{
+    M3 s;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        s.m[r][0] = b.m[r][0] * il.x;
+        s.m[r][1] = b.m[r][1] * il.y;
+        s.m[r][2] = b.m[r][2] * il.z;
+    }
+    M3 o;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.m[r][c] = s.m[r][0] * b.m[c][0] + s.m[r][1] * b.m[c][1] + s.m[r][2] * b.m[c][2];
+    }
+    return o;
+}
+__device__ __forceinline__ float ct_breaking_threshold(const CtShape& s)
+{
+    const float ex = s.dims.x;
+    const float ey = s.capsule ? s.dims.x + s.dims.y : s.dims.y;
+    const float ez = s.capsule ? s.dims.x : s.dims.z;
+    const F3 mn = F3{0.0f - ex, 0.0f - ey, 0.0f - ez}, mx = F3{0.0f + ex, 0.0f + ey, 0.0f + ez};
+    const F3 d = sub3(mx, mn);
+    const float radius = __builtin_sqrtf(dot3(d, d)) * 0.5f;
+    const F3 c = scale3(add3(mn, mx), 0.5f);
+    const float disc = radius + __builtin_sqrtf(dot3(c, c));
+    return disc * kBtContactBreakingThreshold;
+}
+__device__ __forceinline__ F3 ct_support_vertex(const CtShape& s, const F3& dir)
+{
+    if (!s.capsule) return F3{dir.x >= 0.0f ? s.dims.x : -s.dims.x, dir.y >= 0.0f ? s.dims.y : -s.dims.y, dir.z >= 0.0f ? s.dims.z : -s.dims.z};
+    F3 vec = dir;
+    const float lenSqr = dot3(vec, vec);
+    if (lenSqr < 0.0001f) {
+        vec = F3{1.0f, 0.0f, 0.0f};
+    } else {
+        const float rlen = 1.0f / __builtin_sqrtf(lenSqr);
+        vec = scale3(vec, rlen);
+    }
+    F3 sup = F3{0.0f, 0.0f, 0.0f};
+    float maxDot = -1.0e18f;
+    {
+        const F3 vtx = F3{0.0f, s.dims.y, 0.0f};
+        const float d = dot3(vec, vtx);
+        if (d > maxDot) {
+            maxDot = d;
+            sup = vtx;
+        }
+    }
+    {
+        const F3 vtx = F3{0.0f, -s.dims.y, 0.0f};
+        const float d = dot3(vec, vtx);
+        if (d > maxDot) {
+            maxDot = d;
+            sup = vtx;
+        }
+    }
+    F3 vecnorm = dir;
+    if (dot3(vecnorm, vecnorm) < kBtEpsilon * kBtEpsilon) vecnorm = F3{-1.0f, -1.0f, -1.0f};
+    vecnorm = scale3(vecnorm, 1.0f / __builtin_sqrtf(dot3(vecnorm, vecnorm)));
+    return add3(sup, scale3(vecnorm, s.dims.x));
+}
+
+struct CtPoint {
+    F3 localA, localB;
+    float appliedImpulse, appliedLateral;
+    F3 worldA, worldB;
+    float distance;
+};
+__device__ __forceinline__ CtPoint ct_empty_point()
+{
+    CtPoint p;
+    p.localA = p.localB = p.worldA = p.worldB = F3{0.0f, 0.0f, 0.0f};
+    p.appliedImpulse = p.appliedLateral = p.distance = 0.0f;
+    return p;
+}
+
+__device__ __forceinline__ int ct_sort_cached_points(const CtPoint (&p)[4], const CtPoint& pt)
+{
+    int maxPenetrationIndex = -1;
+    float maxPenetration = pt.distance;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (p[i].distance < maxPenetration) {
+            maxPenetrationIndex = i;
+            maxPenetration = p[i].distance;
+        }
+    }
+    float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const F3 p0 = p[0].localA, p1 = p[1].localA, p2 = p[2].localA, p3 = p[3].localA;
+    if (maxPenetrationIndex != 0) {
+        const F3 c = cross3(sub3(pt.localA, p1), sub3(p3, p2));
+        res[0] = dot3(c, c);
+    }
+    if (maxPenetrationIndex != 1) {
+        const F3 c = cross3(sub3(pt.localA, p0), sub3(p3, p2));
+        res[1] = dot3(c, c);
+    }
+    if (maxPenetrationIndex != 2) {
+        const F3 c = cross3(sub3(pt.localA, p0), sub3(p3, p1));
+        res[2] = dot3(c, c);
+    }
+    if (maxPenetrationIndex != 3) {
+        const F3 c = cross3(sub3(pt.localA, p0), sub3(p2, p1));
+        res[3] = dot3(c, c);
+    }
+    int maxIndex = -1;
+    float maxVal = -1.0e18f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = __builtin_fabsf(res[i]);
+        if (a > maxVal) {
+            maxIndex = i;
+            maxVal = a;
+        }
+    }
+    return maxIndex;
+}
+
+// btConvexPlaneCollisionAlgorithm::processCollision against y = 0 (oracle/contact_ref.h CollideWithGround)
+__device__ __forceinline__ void ct_collide(CtPoint (&p)[4], int& n, const CtShape& shape, float breaking, const F3& origin, const M3& basis)
+{
+    const F3 dirLocal = F3{-basis.m[1][0], -basis.m[1][1], -basis.m[1][2]};
+    const F3 vtx = ct_support_vertex(shape, dirLocal);
+    const F3 vtxInPlane = add3(mat_vec(basis, vtx), origin);
+    const float distance = vtxInPlane.y;
+    if (distance < breaking) {
+        const F3 pointInWorld = F3{vtxInPlane.x, vtxInPlane.y - distance, vtxInPlane.z};
+        if (!(distance > breaking)) {
+            CtPoint np = ct_empty_point();
+            const F3 pointA = F3{pointInWorld.x, pointInWorld.y + distance, pointInWorld.z};
+            np.localA = mat_t_vec(basis, sub3(pointA, origin));
+            np.localB = pointInWorld;
+            np.worldA = pointA;
+            np.worldB = pointInWorld;
+            np.distance = distance;
+            float shortest = breaking * breaking;
+            int nearest = -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < n) {
+                    const F3 diffA = sub3(p[i].localA, np.localA);
+                    const float d2 = dot3(diffA, diffA);
+                    if (d2 < shortest) {
+                        shortest = d2;
+                        nearest = i;
+                    }
+                }
+            }
+            int insert;
+            if (nearest >= 0) {
+                insert = nearest;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i == nearest) {
+                        np.appliedImpulse = p[i].appliedImpulse;
+                        np.appliedLateral = p[i].appliedLateral;
+                    }
+                }
+            } else {
+                insert = n;
+                if (insert == 4) {
+                    insert = ct_sort_cached_points(p, np);
+                } else {
+                    n++;
+                }
+                if (insert < 0) insert = 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i == insert) p[i] = np;
+            }
+        }
+    }
+    // refreshContactPoints
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        if (i < n) {
+            p[i].worldA = add3(mat_vec(basis, p[i].localA), origin);
+            p[i].worldB = p[i].localB;
+            p[i].distance = dot3(sub3(p[i].worldA, p[i].worldB), F3{0.0f, 1.0f, 0.0f});
+        }
+    }
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        if (i < n) {
+            bool remove = !(p[i].distance <= breaking);
+            if (!remove) {
+                const F3 projectedPoint = sub3(p[i].worldA, scale3(F3{0.0f, 1.0f, 0.0f}, p[i].distance));
+                const F3 projectedDifference = sub3(p[i].worldB, projectedPoint);
+                const float distance2d = dot3(projectedDifference, projectedDifference);
+                remove = distance2d > breaking * breaking;
+            }
+            if (remove) {
+                const int last = n - 1;
+                CtPoint moved = ct_empty_point();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k == last) moved = p[k];
+                }
+                if (i != last) p[i] = moved;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k == last) p[k] = ct_empty_point();
+                }
+                n--;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ Q4 ct_quat_times_vec(const Q4& q, const F3& w)
+{
+    return Q4{q.w * w.x + q.y * w.z - q.z * w.y, q.w * w.y + q.z * w.x - q.x * w.z, q.w * w.z + q.x * w.y - q.y * w.x,
+              -q.x * w.x - q.y * w.y - q.z * w.z};
+}
+__device__ __forceinline__ Q4 ct_quat_mul(const Q4& a, const Q4& b)
+{
+    Q4 r;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    return r;
+}
+__device__ __forceinline__ F3 ct_quat_rotate(const Q4& rotation, const F3& v)
+{
+    const Q4 q = ct_quat_times_vec(rotation, v);
+    const Q4 inv{-rotation.x, -rotation.y, -rotation.z, rotation.w};
+    const Q4 r = ct_quat_mul(q, inv);
+    return F3{r.x, r.y, r.z};
+}
+__device__ __forceinline__ F3 ct_solve33(const M3& J, const F3& b)
+{
+    const F3 col1 = F3{J.m[0][0], J.m[1][0], J.m[2][0]};
+    const F3 col2 = F3{J.m[0][1], J.m[1][1], J.m[2][1]};
+    const F3 col3 = F3{J.m[0][2], J.m[1][2], J.m[2][2]};
+    float det = dot3(col1, cross3(col2, col3));
+    if (__builtin_fabsf(det) > kBtEpsilon) det = 1.0f / det;
+    return F3{det * dot3(b, cross3(col2, col3)), det * dot3(col1, cross3(b, col3)), det * dot3(col1, cross3(col2, b))};
+}
+__device__ __forceinline__ M3 ct_skew(const F3& v)
+{
+    M3 s;
+    s.m[0][0] = 0.0f; s.m[0][1] = -v.z; s.m[0][2] = v.y;
+    s.m[1][0] = v.z; s.m[1][1] = 0.0f; s.m[1][2] = -v.x;
+    s.m[2][0] = -v.y; s.m[2][1] = v.x; s.m[2][2] = 0.0f;
+    return s;
+}
+__device__ __forceinline__ F3 ct_gyroscopic_impulse(const F3& idl, const F3& omega1, const Q4& q, float step)
+{
+    const Q4 qinv{-q.x, -q.y, -q.z, q.w};
+    F3 omegab = ct_quat_rotate(qinv, omega1);
+    const F3 ibo = F3{idl.x * omegab.x, idl.y * omegab.y, idl.z * omegab.z};
+    const F3 f = scale3(cross3(omegab, ibo), step);
+    const M3 s0 = ct_skew(omegab), s1 = ct_skew(ibo);
+    const float il[3] = {idl.x, idl.y, idl.z};
+    M3 J;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s0Ib = s0.m[r][c] * il[c];
+            const float ib = r == c ? il[c] : 0.0f;
+            J.m[r][c] = ib + (s0Ib - s1.m[r][c]) * step;
+        }
+    }
+    const F3 omega_div = ct_solve33(J, f);
+    omegab = sub3(omegab, omega_div);
+    const F3 omega2 = ct_quat_rotate(q, omegab);
+    return sub3(omega2, omega1);
+}
+
+struct CtRow {
+    F3 normal, relposCrossN, angularComp;
+    float jacDiagABInv, rhs, rhsPenetration, cfm, lower, upper, friction, applied, appliedPush;
+};
+struct CtBody {
+    F3 dLin, dAng, push, turn, linVel, angVel, extForce, extTorque, invMass;
+};
+
+__device__ __forceinline__ void ct_resolve_row(CtBody& a, CtRow& c, bool withUpperLimit)
+{
+    float deltaImpulse = c.rhs - c.applied * c.cfm;
+    const float dv1 = ((c.relposCrossN.x * a.dAng.x + c.relposCrossN.y * a.dAng.y) + c.relposCrossN.z * a.dAng.z) +
+                      ((c.normal.x * a.dLin.x + c.normal.y * a.dLin.y) + c.normal.z * a.dLin.z);
+    const float dv2 = 0.0f + 0.0f;
+    deltaImpulse = __builtin_fmaf(-dv1, c.jacDiagABInv, deltaImpulse);
+    deltaImpulse = __builtin_fmaf(-dv2, c.jacDiagABInv, deltaImpulse);
+    const float sum = c.applied + deltaImpulse;
+    if (c.lower < sum) {
+        if (withUpperLimit && !(sum < c.upper)) {
+            deltaImpulse = c.upper - c.applied;
+            c.applied = c.upper;
+        } else {
+            c.applied = sum;
+        }
+    } else {
+        deltaImpulse = c.lower - c.applied;
+        c.applied = c.lower;
+    }
+    a.dLin = F3{__builtin_fmaf(c.normal.x * a.invMass.x, deltaImpulse, a.dLin.x), __builtin_fmaf(c.normal.y * a.invMass.y, deltaImpulse, a.dLin.y),
+                __builtin_fmaf(c.normal.z * a.invMass.z, deltaImpulse, a.dLin.z)};
+    a.dAng = F3{__builtin_fmaf(c.angularComp.x, deltaImpulse, a.dAng.x), __builtin_fmaf(c.angularComp.y, deltaImpulse, a.dAng.y),
+                __builtin_fmaf(c.angularComp.z, deltaImpulse, a.dAng.z)};
+}
+
+__device__ __forceinline__ void ct_resolve_split(CtBody& a, CtRow& c)
+{
+    if (!c.rhsPenetration) return;
+    float deltaImpulse = c.rhsPenetration - c.appliedPush * c.cfm;
+    const float dv1 = (c.normal.x * a.push.x + (c.normal.y * a.push.y + c.normal.z * a.push.z)) +
+                      (c.relposCrossN.x * a.turn.x + (c.relposCrossN.y * a.turn.y + c.relposCrossN.z * a.turn.z));
+    const float dv2 = 0.0f + 0.0f;
+    deltaImpulse = deltaImpulse - dv1 * c.jacDiagABInv;
+    deltaImpulse = deltaImpulse - dv2 * c.jacDiagABInv;
+    const float sum = c.appliedPush + deltaImpulse;
+    if (sum < c.lower) {
+        deltaImpulse = c.lower - c.appliedPush;
+        c.appliedPush = c.lower;
+    } else {
+        c.appliedPush = sum;
+    }
+    const F3 lin = F3{c.normal.x * a.invMass.x, c.normal.y * a.invMass.y, c.normal.z * a.invMass.z};
+    a.push = add3(a.push, scale3(lin, deltaImpulse));
+    a.turn = add3(a.turn, scale3(c.angularComp, deltaImpulse));
+}
+
+__device__ __forceinline__ CtRow ct_zero_row()
+{
+    CtRow c;
+    c.normal = c.relposCrossN = c.angularComp = F3{0.0f, 0.0f, 0.0f};
+    c.jacDiagABInv = c.rhs = c.rhsPenetration = c.cfm = c.lower = c.upper = c.friction = c.applied = c.appliedPush = 0.0f;
+    return c;
+}
+
+// solveGroup for the island {body} (oracle/contact_ref.h SolveBodyAgainstGround)
+__device__ __noinline__ bool ct_solve(F3& origin, F3& linVel, F3& angVel, Q4& orn, M3& basis, CtPoint (&p)[4], int n, float invMassScalar,
+                                      const F3& invInertiaLocal, const F3& localInertia, float friction, const F3& force, float dt)
+{
+    constexpr int kIterations = 10;
+    constexpr float kErp2 = 0.2f, kSplitThreshold = -0.04f, kSplitTurnErp = 0.1f, kWarmstart = 0.85f, kSor = 1.0f;
+    const F3 nrm = F3{0.0f, 1.0f, 0.0f};
+    const M3 invI = ct_inv_inertia_world(basis, invInertiaLocal);
+    CtBody sb;
+    sb.dLin = sb.dAng = sb.push = sb.turn = F3{0.0f, 0.0f, 0.0f};
+    sb.invMass = F3{invMassScalar, invMassScalar, invMassScalar};
+    sb.linVel = linVel;
+    sb.angVel = angVel;
+    sb.extForce = scale3(scale3(force, invMassScalar), dt);
+    sb.extTorque = F3{0.0f, 0.0f, 0.0f};
+    sb.extTorque = add3(sb.extTorque, ct_gyroscopic_impulse(localInertia, angVel, orn, dt));
+
+    CtRow normalRow[4], frictionRow[4];
+    const float invTimeStep = 1.0f / dt;
+    const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, friction * 1.0f));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        normalRow[j] = ct_zero_row();
+        frictionRow[j] = ct_zero_row();
+        if (j < n) {
+            CtRow& c = normalRow[j];
+            const F3 rel_pos1 = sub3(p[j].worldA, origin);
+            const F3 vel1 = add3(add3(sb.linVel, sb.extForce), cross3(add3(sb.angVel, sb.extTorque), rel_pos1));
+            const F3 vel = sub3(vel1, F3{0.0f, 0.0f, 0.0f});
+            const float rel_vel = dot3(nrm, vel);
+            const float relaxation = kSor;
+            const F3 torqueAxis0 = cross3(rel_pos1, nrm);
+            c.angularComp = mat_vec(invI, torqueAxis0);
+            {
+                const F3 vec = cross3(c.angularComp, rel_pos1);
+                const float denom0 = invMassScalar + dot3(nrm, vec);
+                const float cfm0 = 0.0f * invTimeStep;
+                c.jacDiagABInv = relaxation / (denom0 + 0.0f + cfm0);
+            }
+            c.normal = nrm;
+            c.relposCrossN = torqueAxis0;
+            const float penetration = p[j].distance + 0.0f;
+            c.friction = combinedFriction;
+            const float restitution = 0.0f;
+            c.applied = p[j].appliedImpulse * kWarmstart;
+            {
+                const F3 lin = F3{c.normal.x * sb.invMass.x, c.normal.y * sb.invMass.y, c.normal.z * sb.invMass.z};
+                sb.dLin = add3(sb.dLin, scale3(lin, c.applied));
+                sb.dAng = add3(sb.dAng, scale3(c.angularComp, c.applied * 1.0f));
+            }
+            c.appliedPush = 0.0f;
+            {
+                const float vel1Dotn = dot3(c.normal, add3(sb.linVel, sb.extForce)) + dot3(c.relposCrossN, add3(sb.angVel, sb.extTorque));
+                const float vel2Dotn = 0.0f + 0.0f;
+                const float rel_vel2 = vel1Dotn + vel2Dotn;
+                float positionalError = 0.0f;
+                float velocityError = restitution - rel_vel2;
+                if (penetration > 0.0f) {
+                    positionalError = 0.0f;
+                    velocityError -= penetration * invTimeStep;
+                } else {
+                    positionalError = -penetration * kErp2 * invTimeStep;
+                }
+                const float penetrationImpulse = positionalError * c.jacDiagABInv;
+                const float velocityImpulse = velocityError * c.jacDiagABInv;
+                if (penetration > kSplitThreshold) {
+                    c.rhs = penetrationImpulse + velocityImpulse;
+                    c.rhsPenetration = 0.0f;
+                } else {
+                    c.rhs = velocityImpulse;
+                    c.rhsPenetration = penetrationImpulse;
+                }
+                c.cfm = 0.0f * c.jacDiagABInv;
+                c.lower = 0.0f;
+                c.upper = 1e10f;
+            }
+            F3 dir = sub3(vel, scale3(nrm, rel_vel));
+            const float lat_rel_vel = dot3(dir, dir);
+            if (lat_rel_vel > kBtEpsilon) {
+                dir = scale3(dir, 1.0f / __builtin_sqrtf(lat_rel_vel));
+            } else {
+                dir = F3{-1.0f, 0.0f, 0.0f}; // btPlaneSpace1((0,1,0)), first tangent
+            }
+            CtRow& f = frictionRow[j];
+            f.friction = combinedFriction;
+            f.normal = dir;
+            f.relposCrossN = cross3(rel_pos1, dir);
+            f.angularComp = mat_vec(invI, f.relposCrossN);
+            {
+                const F3 vec = cross3(f.angularComp, rel_pos1);
+                const float denom0 = invMassScalar + dot3(dir, vec);
+                f.jacDiagABInv = relaxation / (denom0 + 0.0f);
+            }
+            {
+                const float vel1Dotn = dot3(f.normal, add3(sb.linVel, sb.extForce)) + dot3(f.relposCrossN, sb.angVel);
+                const float vel2Dotn = 0.0f + 0.0f;
+                const float rv = vel1Dotn + vel2Dotn;
+                const float velocityError = 0.0f - rv;
+                const float velocityImpulse = velocityError * f.jacDiagABInv;
+                f.rhs = 0.0f + velocityImpulse;
+                f.rhsPenetration = 0.0f;
+                f.cfm = 0.0f;
+                f.lower = -f.friction;
+                f.upper = f.friction;
+            }
+            f.applied = p[j].appliedLateral * kWarmstart;
+            {
+                const F3 lin = scale3(f.normal, invMassScalar);
+                sb.dLin = add3(sb.dLin, scale3(lin, f.applied));
+                sb.dAng = add3(sb.dAng, scale3(f.angularComp, f.applied * 1.0f));
+            }
+        }
+    }
+#pragma unroll 1
+    for (int it = 0; it < kIterations; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < n) ct_resolve_split(sb, normalRow[j]);
+        }
+    }
+#pragma unroll 1
+    for (int it = 0; it < kIterations; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < n) ct_resolve_row(sb, normalRow[j], false);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < n) {
+                const float totalImpulse = normalRow[j].applied;
+                if (totalImpulse > 0.0f) {
+                    frictionRow[j].lower = -(frictionRow[j].friction * totalImpulse);
+                    frictionRow[j].upper = frictionRow[j].friction * totalImpulse;
+                    ct_resolve_row(sb, frictionRow[j], true);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < n) {
+            p[j].appliedImpulse = normalRow[j].applied;
+            p[j].appliedLateral = frictionRow[j].applied;
+        }
+    }
+    sb.linVel = add3(sb.linVel, sb.dLin);
+    sb.angVel = add3(sb.angVel, sb.dAng);
+    bool moved = false;
+    if (sb.push.x != 0.0f || sb.push.y != 0.0f || sb.push.z != 0.0f || sb.turn.x != 0.0f || sb.turn.y != 0.0f || sb.turn.z != 0.0f) {
+        origin = add3(origin, scale3(sb.push, dt));
+        orn = bt_integrate_orientation(orn, scale3(sb.turn, kSplitTurnErp), dt);
+        basis = bt_mat_from_quat(orn);
+        moved = true;
+    }
+    linVel = add3(sb.linVel, sb.extForce);
+    angVel = add3(sb.angVel, sb.extTorque);
+    return moved;
+}
+
+template <bool BASIS>
+__global__ void __launch_bounds__(128) k_ground(WorldView w, GroundParams g)
+{
+    const uint64_t slot64 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (slot64 >= g.n_slots) return;
+    const uint32_t slot = static_cast<uint32_t>(slot64);
+    const uint32_t f0 = w.flags[slot];
+    if (!(f0 & kValid) || (f0 & kTypeMask) != 2u) return; // Dynamic bodies only: nothing else responds to a contact
+    const uint32_t ci0 = w.cinfo[slot];
+    if (!(ci0 & kCiGroundMask)) return; // the body's mask excludes the ground's group (StaticFilter)
+    if (f0 & kDrowsy) {
+        // asleep, or falling asleep at this step's island build: not collided (both objects inactive), not solved
+        const uint32_t dz = w.deact[slot];
+        if (dz == kDeactWants || dz == kDeactSleeping) return;
+    }
+    const uint32_t cls = f0 >> kMassShift;
+    float inv_mass;
+    F3 force;
+    if (cls != kMassClassArray) {
+        const float4 gf = w.grav_palette[cls];
+        inv_mass = gf.w;
+        force = F3{gf.x, gf.y, gf.z};
+    } else {
+        inv_mass = w.inv_mass[slot];
+        force = F3{g.gx / inv_mass, g.gy / inv_mass, g.gz / inv_mass};
+    }
+    if (inv_mass == 0.0f) return;
+    const float4 cs = w.cshape[slot];
+    CtShape shape;
+    shape.capsule = (ci0 & kCiCapsule) != 0;
+    shape.dims = F3{cs.x, cs.y, cs.z};
+    int n = static_cast<int>((ci0 >> kCiCountShift) & 7u);
+    const bool spin = (f0 & kSpin) != 0;
+    F3 pos = ld3(w.pos, slot);
+    const float breaking = ct_breaking_threshold(shape);
+    if (n == 0 && !spin) {
+        // cheap reject: no vertex of the shape can be within the breaking threshold of the plane
+        const float reach = (__builtin_fabsf(cs.x) + __builtin_fabsf(cs.y) + __builtin_fabsf(cs.z)) * 1.01f + 0.01f;
+        if (pos.y - reach > breaking) return;
+    }
+    Q4 q = ld4(w.quat, slot);
+    M3 basis = bt_mat_from_quat(q);
+    CtPoint p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = ct_empty_point();
+        if (i < n) {
+            const float4 a = reinterpret_cast<const float4*>(w.manifold)[8ull * slot + 2 * i];
+            const float4 b = reinterpret_cast<const float4*>(w.manifold)[8ull * slot + 2 * i + 1];
+            p[i].localA = F3{a.x, a.y, a.z};
+            p[i].appliedImpulse = a.w;
+            // localB.y is exactly 0 (the point is the projection onto y = 0): its slot carries the point's distance as the last
+            // refresh left it, which sortCachedPoints reads before this step's refresh
+            p[i].localB = F3{b.x, 0.0f, b.z};
+            p[i].distance = b.y;
+            p[i].appliedLateral = b.w;
+        }
+    }
+    ct_collide(p, n, shape, breaking, pos, basis);
+    uint32_t ci = (ci0 & ~(7u << kCiCountShift)) | (static_cast<uint32_t>(n) << kCiCountShift);
+    if (n == 0 && !spin) {
+        if (ci != ci0) w.cinfo[slot] = ci;
+        return; // k_tick's plain update
+    }
+    F3 v = ld3(w.vel, slot);
+    F3 av = spin ? ld3(w.angvel, slot) : F3{0.0f, 0.0f, 0.0f};
+    if (g.want_aabb) {
+        // the AABB Bullet feeds its broadphase is taken BEFORE the solver runs (predictUnconstraintMotion / updateAabbs):
+        // k_tick, which runs after this kernel, would see the solved velocities — so it is written here (same arithmetic)
+        const F3 he = ld3(w.half_extent, slot);
+        float mn[3], mx[3];
+        bt_aabb_of_pose(pos, basis, he, mn, mx);
+        const F3 pp{pos.x + v.x * g.dt, pos.y + v.y * g.dt, pos.z + v.z * g.dt};
+        float mn2[3], mx2[3];
+        const bool turn = BASIS || spin;
+        if (turn) {
+            const M3 r2 = bt_mat_from_quat(bt_integrate_orientation(BASIS ? bt_quat_from_mat(basis) : q, av, g.dt));
+            bt_aabb_of_pose(pp, r2, he, mn2, mx2);
+        } else {
+            bt_aabb_of_pose(pp, basis, he, mn2, mx2);
+        }
+        float* bb = w.aabb + 6ull * slot;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            bb[a] = mn2[a] < mn[a] ? mn2[a] : mn[a];
+            bb[3 + a] = mx2[a] > mx[a] ? mx2[a] : mx[a];
+        }
+    }
+    const float mass = w.cmass[slot];
+    const F3 localInertia = ct_local_inertia(shape, mass);
+    const F3 invInertiaLocal = ct_inv_inertia_local(localInertia);
+    Q4 orn = BASIS ? bt_quat_from_mat(basis) : q;
+    const bool moved = ct_solve(pos, v, av, orn, basis, p, n, inv_mass, invInertiaLocal, localInertia, w.cfriction[slot], force, g.dt);
+    st3(w.vel, slot, v);
+    st3(w.angvel, slot, av);
+    if (moved) {
+        st3(w.pos, slot, pos);
+        st4(w.quat, slot, orn);
+        ci |= kCiMoved;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < n) {
+            reinterpret_cast<float4*>(w.manifold)[8ull * slot + 2 * i] = make_float4(p[i].localA.x, p[i].localA.y, p[i].localA.z, p[i].appliedImpulse);
+            reinterpret_cast<float4*>(w.manifold)[8ull * slot + 2 * i + 1] = make_float4(p[i].localB.x, p[i].distance, p[i].localB.z, p[i].appliedLateral);
+        }
+    }
+    w.cinfo[slot] = ci | kCiSolved;
+    const bool spin_now = av.x != 0.0f || av.y != 0.0f || av.z != 0.0f;
+    const uint32_t f = spin_now ? (f0 | kSpin) : (f0 & ~kSpin);
+    if (f != f0) w.flags[slot] = f;
+}
+
+} // namespace
+
+hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundParams& g, bool bullet_basis)
+{
+    if (g.n_slots == 0) return hipSuccess;
+    const dim3 grid(static_cast<uint32_t>((g.n_slots + 127) / 128)), block(128);
+    if (bullet_basis) hipLaunchKernelGGL(k_ground<true>, grid, block, 0, stream, w, g);
+    else hipLaunchKernelGGL(k_ground<false>, grid, block, 0, stream, w, g);
+    return hipGetLastError();
+}
+
+} // namespace bge

@@ -180,6 +180,11 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             // is recomputed from it: same bits, 16 instead of 36 bytes.
             const bool turn = BASIS ? dynamic : spin;
             bool advanced = false;
+            // ground plane on: k_ground collided this body with the plane before this kernel ran and, if it is in contact (or
+            // spinning), solved it — its velocities are final (gravity impulse included), its fed AABB is written
+            uint32_t ci = 0;
+            if (p.cinfo_in && dynamic) ci = p.cinfo_in[slot];
+            const bool solved = (ci & kCiSolved) != 0;
             Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
             F3 v{0.0f, 0.0f, 0.0f};
             F3 av{0.0f, 0.0f, 0.0f};
@@ -198,7 +203,16 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 if (turn || AABB) q = ld4(w.quat, slot);
             }
 
-            if (AABB) {
+            if (AABB && solved) {
+                const float* bb = w.aabb + 6ull * slot; // written by k_ground from the pre-solve state
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    box_mn[a] = bb[a];
+                    box_mx[a] = bb[3 + a];
+                }
+                has_box = true;
+            }
+            if (AABB && !solved) {
                 const F3 he = ld3(w.half_extent, slot);
                 const M3 r = bt_mat_from_quat(q);
                 float mn[3], mx[3];
@@ -263,9 +277,11 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     }
                 } else if (inv_mass != 0.0f) {
                     // applyGravity (F = g * (1/invMass)) + solver write-back of the external force impulse
-                    v.x = v.x + (force.x * inv_mass) * p.dt;
-                    v.y = v.y + (force.y * inv_mass) * p.dt;
-                    v.z = v.z + (force.z * inv_mass) * p.dt;
+                    if (!solved) {
+                        v.x = v.x + (force.x * inv_mass) * p.dt;
+                        v.y = v.y + (force.y * inv_mass) * p.dt;
+                        v.z = v.z + (force.z * inv_mass) * p.dt;
+                    }
                     // integrateTransforms
                     pos.x = pos.x + v.x * p.dt;
                     pos.y = pos.y + v.y * p.dt;
@@ -301,10 +317,12 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 }
                 // SyncRigidBodiesFromPhysics: rotationEuler <- getEulerZYX(basis) whenever the orientation was
                 // (re)posed or advanced; a non-spinning body keeps its euler triple bit for bit
-                if (repose || advanced) {
+                if (repose || advanced || (ci & kCiMoved)) {
+                    if (!(repose || advanced)) q = ld4(w.quat, slot); // the split impulse moved a body that does not spin
                     eul = bt_transform_euler_from_mat(bt_mat_from_quat(q));
                     st3(w.euler, slot, eul);
                 }
+                if (ci & (kCiSolved | kCiMoved)) w.cinfo[slot] = ci & ~(kCiSolved | kCiMoved); // consumed
                 f |= kTDirty; // transform->MarkDirty()
             }
             f &= ~kBDirty;
@@ -541,12 +559,19 @@ __global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, co
                                  uint64_t first, uint64_t count,
                                  const uint32_t* __restrict__ type_bits, const float* __restrict__ inv_mass,
                                  const float* __restrict__ half_extent3, const uint32_t* __restrict__ group,
-                                 const uint32_t* __restrict__ mask, const uint32_t* __restrict__ filter_class, WorldView w)
+                                 const uint32_t* __restrict__ mask, const uint32_t* __restrict__ filter_class, WorldView w,
+                                 const float* __restrict__ cdims3, const float* __restrict__ cmass, const uint32_t* __restrict__ cbits)
 {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
     const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
+    if (cdims3) {
+        // a (re)created body starts without contacts: removeRigidBody dropped its pair with the ground and the manifold with it
+        w.cshape[slot] = make_float4(cdims3[3 * i], cdims3[3 * i + 1], cdims3[3 * i + 2], 0.0f);
+        w.cmass[slot] = cmass[i];
+        w.cinfo[slot] = cbits[i];
+    }
     w.filter_class[slot] = filter_class[i];
     uint32_t f = w.flags[slot];
     f &= ~(kTypeMask | kBDirty | kSpin | kMassMask | kDrowsy); // a (re)created body is ACTIVE_TAG with its timer at zero
@@ -608,6 +633,10 @@ __global__ void k_init_slots(uint64_t n_slots, const uint32_t* __restrict__ stru
     w.group[s] = 1u;
     w.mask[s] = 0xffffffffu;
     w.filter_class[s] = 0u;
+    w.cshape[s] = make_float4(0.5f, 0.5f, 0.5f, 0.0f);
+    w.cmass[s] = 0.0f;
+    w.cfriction[s] = 0.5f; // RigidBody::friction default (src/ecs/PhysicsComponents.h:32)
+    w.cinfo[s] = kCiGroundMask;
     // mtxIdentity(local), mtxIdentity(world)
     for (int k = 0; k < 16; ++k) w.world[16 * s + k] = (k % 5 == 0) ? 1.0f : 0.0f;
     for (int k = 0; k < 6; ++k) w.aabb[6 * s + k] = 0.0f;
@@ -800,11 +829,11 @@ hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity
 hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                  const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
                                  const uint32_t* group, const uint32_t* mask, const uint32_t* filter_class, const WorldView& w,
-                                 const uint32_t* index)
+                                 const uint32_t* index, const float* cdims3, const float* cmass, const uint32_t* cbits)
 {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_bodies, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, index, first, count,
-                       type_bits, inv_mass, half_extent3, group, mask, filter_class, w);
+                       type_bits, inv_mass, half_extent3, group, mask, filter_class, w, cdims3, cmass, cbits);
     return hipGetLastError();
 }
 

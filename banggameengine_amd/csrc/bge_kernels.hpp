@@ -35,6 +35,27 @@ struct WorldView {
     float* aabb;              // [slots][6]  min xyz, max xyz fed to the broadphase
     float* normal;            // [slots][16] transpose(inverse(world)); allocated on first use
     const uint32_t* root_index; // [slots]   position of a root in the root table (read by roots only, when packing)
+    // ground contact (bge_contact.hip): the collider as Bullet holds it and the body's manifold with the plane y = 0
+    float4* cshape;           // [slots]     box: half extents with margin; capsule: (radius, half height, radius); w unused
+    float* cmass;             // [slots]     the body's mass as handed to btRigidBody (inertia = f(mass), not f(1 / inv_mass))
+    float* cfriction;         // [slots]     RigidBody::friction
+    uint32_t* cinfo;          // [slots]     kCi* bits below
+    float* manifold;          // [slots][32] four contact points x (localA.xyz, appliedImpulse, localB.x, distance, localB.z, appliedImpulseLateral1);
+                              //             allocated when the ground plane is switched on
+};
+
+// per-slot contact word (the flag word has no bit left)
+constexpr uint32_t kCiCapsule = 1u;      // collider is a capsule (else a box)
+constexpr uint32_t kCiGroundMask = 2u;   // the body's mask contains the ground's group (btBroadphaseProxy::StaticFilter = 2)
+constexpr uint32_t kCiSolved = 4u;       // k_ground ran the solver for this body in this sub-step: velocities are final, gravity included
+constexpr uint32_t kCiMoved = 8u;        // ... and the split impulse corrected the pose (rotationEuler must be rewritten)
+constexpr uint32_t kCiCountShift = 4;    // bits 4..6: contact points in the manifold (0..4)
+
+struct GroundParams {
+    float dt;
+    float gx, gy, gz;
+    uint64_t n_slots;
+    uint32_t want_aabb; // the tick feeds AABBs (broadphase / triggers): solved bodies' boxes are written here, before the solve
 };
 
 // Trigger volumes (ghost objects), indexed by trigger number
@@ -58,6 +79,7 @@ struct TickParams {
     float4* bp_partial; // when non-null (AABB variants): every wave also writes the bounds of its bodies' fed AABBs, their
                         // number and the widest one — 2 x float4 at bp_partial[2 * (tile * 4 + wave)]: (min.xyz, widest extent),
                         // (max.xyz, count bits) — so that the broadphase needs no pass of its own over the AABBs for the grid
+    const uint32_t* cinfo_in; // ground plane on: k_ground ran before this kernel; bodies it solved carry kCiSolved (null: no ground)
     uint32_t no_repose; // this tick is the 2nd..nth sub-step of ONE stepSimulation call (bge_world_step_simulation): dirty flags
                         // do not re-pose bodies — SyncKinematicBodiesToPhysics ran once, before the first sub-step
 };
@@ -69,6 +91,10 @@ hipError_t launch_tick(hipStream_t stream, const WorldView& w, const TickParams&
 // bodies, write Dynamic poses back, mark them dirty — no integration (bge_world_step_simulation)
 hipError_t launch_pose_only(hipStream_t stream, const WorldView& w, uint64_t n_slots, bool bullet_basis);
 
+// Ground plane y = 0: collide every Dynamic body with it and run Bullet's solver for the bodies in contact (bge_contact.hip);
+// launched before launch_tick of the same sub-step.
+hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundParams& g, bool bullet_basis);
+
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits,
                                const uint32_t* index = nullptr);
@@ -77,7 +103,8 @@ hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity
 hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                  const uint32_t* type_bits, const float* inv_mass, const float* half_extent3,
                                  const uint32_t* group, const uint32_t* mask, const uint32_t* filter_class, const WorldView& w,
-                                 const uint32_t* index = nullptr);
+                                 const uint32_t* index = nullptr, const float* cdims3 = nullptr, const float* cmass = nullptr,
+                                 const uint32_t* cbits = nullptr);
 hipError_t launch_scatter_velocities(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                      const float* lin, const float* ang, const WorldView& w);
 hipError_t launch_init_slots(hipStream_t stream, uint64_t n_slots, const uint32_t* structural_flags, const WorldView& w);

@@ -144,6 +144,8 @@ struct bge_world {
     DevBuf flags, parent, tile_hdr, slot_of_entity, entity_of_slot, root_slots, root_index;
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
     DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table, grav_palette;
+    DevBuf cshape, cmass, cfriction, cinfo, manifold; // ground contact (bge_contact.hip); manifold allocated when the plane is switched on
+    bool ground_plane = false; // the reference's static plane y = 0 (PhysicsSystem.cpp:149-166); off: free bodies (BASELINE's workloads)
     DevBuf bp_partials; // per-wave bounds / count / widest extent written by the tick kernel for the broadphase (32 B per wave)
     float grav_cached[3] = {0.0f, 0.0f, 0.0f};
     bool grav_palette_stale = true; // the mass palette or the gravity vector changed since the table was built
@@ -266,12 +268,17 @@ struct bge_world {
         view.filter_class = filter_class.as<uint32_t>();
         view.root_index = root_index.as<uint32_t>();
         view.normal = normal.as<float>();
+        view.cshape = cshape.as<float4>();
+        view.cmass = cmass.as<float>();
+        view.cfriction = cfriction.as<float>();
+        view.cinfo = cinfo.as<uint32_t>();
+        view.manifold = manifold.as<float>();
     }
     void release_all()
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count}) {
             b->release();
         }
@@ -568,8 +575,9 @@ try {
     if (n_keep) {
         for (auto [buf, width] : std::initializer_list<std::pair<DevBuf*, uint32_t>>{
                  {&w->pos, 3}, {&w->euler, 3}, {&w->scale, 3}, {&w->world, 16}, {&w->vel, 3}, {&w->angvel, 3},
-                 {&w->quat, 4}, {&w->inv_mass, 1}, {&w->deact, 1}, {&w->filter_class, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6}}) {
-            carries.push_back(Carry{buf, width, TmpBuf{}});
+                 {&w->quat, 4}, {&w->inv_mass, 1}, {&w->deact, 1}, {&w->filter_class, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6},
+                 {&w->cshape, 4}, {&w->cmass, 1}, {&w->cfriction, 1}, {&w->cinfo, 1}, {&w->manifold, 32}}) {
+            if (buf->p) carries.push_back(Carry{buf, width, TmpBuf{}}); // (the manifold store exists only with the ground plane on)
         }
         for (Carry& c : carries) {
             HIP_TRY(c.tmp.ensure(n_keep * c.width * 4));
@@ -655,6 +663,14 @@ try {
     HIP_TRY(w->group.ensure(S * 4));
     HIP_TRY(w->mask.ensure(S * 4));
     HIP_TRY(w->aabb.ensure(S * 24));
+    HIP_TRY(w->cshape.ensure(S * 16));
+    HIP_TRY(w->cmass.ensure(S * 4));
+    HIP_TRY(w->cfriction.ensure(S * 4));
+    HIP_TRY(w->cinfo.ensure(S * 4));
+    if (w->ground_plane) {
+        HIP_TRY(w->manifold.ensure(S * 128));
+        HIP_TRY(hipMemsetAsync(w->manifold.p, 0, w->manifold.bytes, w->stream));
+    }
     HIP_TRY(w->root_worlds.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 64));
     HIP_TRY(w->counter.ensure(64));
     HIP_TRY(w->mass_palette.ensure(256 * sizeof(float2)));
@@ -820,7 +836,10 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
         w->palette_inv_mass.push_back(0.0f);
         w->palette_class[0u] = 0;
     }
-    std::vector<uint32_t> words(count * 8);
+    std::vector<uint32_t> words(count * 13);
+    float* cdims = reinterpret_cast<float*>(words.data() + 8 * count); // collider as Bullet holds it (ground contact)
+    float* cmass = reinterpret_cast<float*>(words.data() + 11 * count);
+    uint32_t* cbits = words.data() + 12 * count;
     uint32_t* type_bits = words.data();
     float* inv_mass = reinterpret_cast<float*>(words.data() + count);
     float* he = reinterpret_cast<float*>(words.data() + 2 * count);
@@ -850,6 +869,17 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
         const uint32_t l = layer ? layer[i] : 1u;
         group[i] = l ? l : 1u;
         msk[i] = mask ? mask[i] : 0xffffffffu;
+        if (sh == BGE_SHAPE_CAPSULE) {
+            // btCapsuleShape(radius, 2 * halfHeight): m_implicitShapeDimensions = (radius, 0.5 * height, radius)
+            cdims[3 * i] = std::max(sz[0], 0.01f);
+            cdims[3 * i + 1] = 0.5f * (std::max(sz[1], 0.0f) * 2.0f);
+            cdims[3 * i + 2] = cdims[3 * i];
+        } else {
+            std::memcpy(cdims + 3 * i, he + 3 * i, 12); // btBoxShape::getHalfExtentsWithMargin() is what the AABB uses too
+        }
+        cmass[i] = t == BGE_BODY_DYNAMIC ? std::max(mass ? mass[i] : 1.0f, 0.01f) : 0.0f;
+        // the ground is in group StaticFilter (2) with mask AllFilter: it reaches the bodies whose mask has bit 1
+        cbits[i] = (sh == BGE_SHAPE_CAPSULE ? bge::kCiCapsule : 0u) | ((msk[i] & 2u) ? bge::kCiGroundMask : 0u);
         fclass[i] = t == BGE_BODY_NONE ? 0u : w->filter_class_of(group[i], msk[i], t == BGE_BODY_STATIC);
     }
     if (palette_changed) {
@@ -868,7 +898,9 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
     const uint32_t* d = w->stage.as<uint32_t>();
     HIP_TRY(bge::launch_scatter_bodies(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, d,
                                        reinterpret_cast<const float*>(d + count), reinterpret_cast<const float*>(d + 2 * count),
-                                       d + 5 * count, d + 6 * count, d + 7 * count, w->view, di));
+                                       d + 5 * count, d + 6 * count, d + 7 * count, w->view, di,
+                                       reinterpret_cast<const float*>(d + 8 * count), reinterpret_cast<const float*>(d + 11 * count),
+                                       d + 12 * count));
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->maybe_dirty = true;
     return BGE_OK;
@@ -967,7 +999,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
     // launches on one stream), so it is off by default.
     uint32_t first_eager = 0;
     const bool use_graph = std::getenv("BGE_USE_GRAPH") != nullptr;
-    if (use_graph && !sub.no_repose && !w->graph_disabled && phys && ticks >= 2 * bge_world::kGraphTicks && w->profiling != 2 &&
+    if (use_graph && !sub.no_repose && !w->ground_plane && !w->graph_disabled && phys && ticks >= 2 * bge_world::kGraphTicks && w->profiling != 2 &&
         !(flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS | BGE_TICK_GATHER_ROOTS)) && w->flat.n_tiles_ticked <= bge_world::kGraphMaxTiles &&
         w->flat.n_tiles_ticked > 0) {
         const bool same = w->graph_exec && w->graph_flags == flags && w->graph_dt == dt && w->graph_g[0] == gravity[0] &&
@@ -1064,6 +1096,23 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
                 HIP_TRY(w->bp_partials.ensure(need));
             }
             p.bp_partial = w->bp_partials.as<float4>();
+        }
+        if (phys && w->ground_plane) {
+            // Ground plane on.  Bullet's order inside PhysicsSystem::Update: teleport dirty bodies (before stepSimulation), then per
+            // sub-step collision detection + solver, then integrateTransforms — so the re-pose runs as its own kernel (once per
+            // stepSimulation call), k_ground collides and solves the bodies at the ground, and the tick kernel integrates.
+            const uint64_t n_slots = static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile;
+            if (!sub.no_repose) HIP_TRY(bge::launch_pose_only(w->stream, w->view, n_slots, (flags & BGE_TICK_BULLET_BASIS) != 0));
+            bge::GroundParams gp{};
+            gp.dt = dt;
+            gp.gx = gravity[0];
+            gp.gy = gravity[1];
+            gp.gz = gravity[2];
+            gp.n_slots = n_slots;
+            gp.want_aabb = (flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS)) ? 1u : 0u;
+            HIP_TRY(bge::launch_ground(w->stream, w->view, gp, (flags & BGE_TICK_BULLET_BASIS) != 0));
+            p.no_repose = 1u;
+            p.cinfo_in = w->cinfo.as<uint32_t>();
         }
         const size_t n_passes = w->flat.pass_tile_begin.size() - 1;
         // BGE_TICK_GATHER_ROOTS with a transform pass: the roots write the all-gather's send buffer themselves
@@ -1224,6 +1273,69 @@ try {
     return BGE_OK;
 }
 BGE_CATCH_ALL("bge_world_reset_clock")
+
+int bge_world_set_ground_plane(bge_world* w, int enabled)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    const bool on = enabled != 0;
+    if (on && w->has_topology && !w->manifold.p) {
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        HIP_TRY(w->manifold.ensure(std::max<uint64_t>(w->flat.n_slots, bge::kTile) * 128));
+        HIP_TRY(hipMemsetAsync(w->manifold.p, 0, w->manifold.bytes, w->stream));
+        w->rebuild_view();
+    }
+    w->ground_plane = on;
+    w->drop_graph();
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_set_ground_plane")
+
+static int upload_friction_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const float* friction)
+{
+    if (count == 0) return BGE_OK;
+    if (!friction) return fail(BGE_ERR_INVALID, "friction is NULL");
+    DeviceGuard guard(w->device);
+    const uint32_t* di = nullptr;
+    if (int rc = stage_index(w, count, index, &di)) return rc;
+    return upload_rows(w, first, count, 1, friction, w->cfriction.p, 0, di);
+}
+
+int bge_world_upload_friction(bge_world* w, uint64_t first, uint64_t count, const float* friction)
+try {
+    if (int rc = check_range(w, first, count)) return rc;
+    return upload_friction_impl(w, first, count, nullptr, friction);
+}
+BGE_CATCH_ALL("bge_world_upload_friction")
+
+int bge_world_upload_friction_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, const float* friction)
+try {
+    if (int rc = check_range(w, 0, 0)) return rc;
+    if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
+    return upload_friction_impl(w, 0, count, entity_index, friction);
+}
+BGE_CATCH_ALL("bge_world_upload_friction_indexed")
+
+int bge_world_download_contacts(bge_world* w, uint64_t first, uint64_t count, uint8_t* n_points, float* points32)
+try {
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    std::vector<uint32_t> ci(count);
+    if (int rc = download_rows(w, first, count, 1, w->cinfo.p, ci.data())) return rc;
+    if (n_points) {
+        for (uint64_t i = 0; i < count; ++i) n_points[i] = w->manifold.p ? static_cast<uint8_t>((ci[i] >> bge::kCiCountShift) & 7u) : 0;
+    }
+    if (points32) {
+        if (!w->manifold.p) {
+            std::memset(points32, 0, count * 128);
+        } else if (int rc = download_rows(w, first, count, 32, w->manifold.p, points32)) {
+            return rc;
+        }
+    }
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_download_contacts")
 
 int bge_world_tick(bge_world* w, float dt, const float gravity[3], uint32_t flags)
 try {

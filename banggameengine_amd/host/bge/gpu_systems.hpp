@@ -28,6 +28,7 @@
 // Errors never throw (the reference's hot path has no exceptions): a failed call logs "[GPU] ..." to stderr and
 // returns false, leaving the host structs as they were.
 //
+// Bodies collide with the ground plane only, not with each other (no convex-convex narrowphase on this path).
 // Known deviations (documented in DESIGN.md): Transform::local is not refreshed; a Dynamic body whose Transform
 // is edited BETWEEN PhysicsSystem::Update and TransformSystem::Update of the same tick continues from the edited
 // position (the reference's Bullet body would ignore the edit).
@@ -77,6 +78,8 @@ public:
         d.device = device;
         d.stream = stream;
         if (bge_world_create(&d, &world_) != BGE_OK) Log("bge_world_create");
+        // every world of the reference has the static plane y = 0 (PhysicsSystem::EnsureGround, PhysicsSystem.cpp:149-166)
+        else if (bge_world_set_ground_plane(world_, 1) != BGE_OK) Log("bge_world_set_ground_plane");
     }
     ~GpuSceneMirror() { bge_world_destroy(world_); }
     GpuSceneMirror(const GpuSceneMirror&) = delete;
@@ -88,6 +91,12 @@ public:
     // BGE_TICK_BULLET_BASIS: carry every Dynamic body's orientation the way Bullet does (basis round trip each step, euler
     // rewritten from it) instead of leaving a non-spinning body's orientation and euler untouched
     bool bullet_basis = false;
+    // The ground plane is part of every reference world; SetGroundPlane(false) turns the bodies into free bodies (what
+    // BASELINE's synthetic workloads are).  Takes effect on the next UpdatePhysics.
+    void SetGroundPlane(bool on)
+    {
+        if (ok() && bge_world_set_ground_plane(world_, on ? 1 : 0) != BGE_OK) Log("bge_world_set_ground_plane");
+    }
 
     // Resident mode: the world matrices stay on the device after TransformSystem::Update; only the host `dirty` flags
     // are kept coherent and the caller fetches the matrices it needs (FetchWorld) — e.g. the visible set.  Coherent
@@ -151,6 +160,7 @@ public:
     int max_sub_steps = 4;
     float fixed_step = 1.0f / 120.0f;
     int last_sub_steps = 0; // stepSimulation's return value of the last call
+    int ground_plane_state = 1; // what the world was last told (GpuPhysicsSystem keeps it in step with its own switch)
 
     bool UpdatePhysics(SceneT& scene, double dt)
     {
@@ -422,7 +432,7 @@ private:
     bool UploadBodies(SceneT& scene)
     {
         index_list_.clear();
-        b_type_.clear(); b_mass_.clear(); b_shape_.clear(); b_size_.clear(); b_layer_.clear(); b_mask_.clear();
+        b_type_.clear(); b_mass_.clear(); b_shape_.clear(); b_size_.clear(); b_layer_.clear(); b_mask_.clear(); b_friction_.clear();
         seen_.assign(ids_.size(), 0);
         for (auto& kv : scene.GetRigidBodies()) {
             auto it = index_of_.find(kv.first);
@@ -439,6 +449,7 @@ private:
             b_size_.push_back(col->size.x); b_size_.push_back(col->size.y); b_size_.push_back(col->size.z);
             b_layer_.push_back(rb.layer);
             b_mask_.push_back(rb.mask);
+            b_friction_.push_back(rb.friction); // info.m_friction = body.friction (PhysicsSystem.cpp:437)
             body_[i].exists = true;
             rb.dirty = false;   // PhysicsSystem.cpp:476
             col->dirty = false; // PhysicsSystem.cpp:403
@@ -452,6 +463,7 @@ private:
                 b_size_.insert(b_size_.end(), {0.5f, 0.5f, 0.5f});
                 b_layer_.push_back(1);
                 b_mask_.push_back(0xffffffffu);
+                b_friction_.push_back(0.5f);
                 body_[i].exists = false;
             }
         }
@@ -459,6 +471,9 @@ private:
         if (bge_world_upload_bodies_indexed(world_, index_list_.size(), index_list_.data(), b_type_.data(), b_mass_.data(),
                                             b_shape_.data(), b_size_.data(), b_layer_.data(), b_mask_.data()) != BGE_OK) {
             return Log("bge_world_upload_bodies_indexed");
+        }
+        if (bge_world_upload_friction_indexed(world_, index_list_.size(), index_list_.data(), b_friction_.data()) != BGE_OK) {
+            return Log("bge_world_upload_friction_indexed");
         }
         return true;
     }
@@ -502,7 +517,7 @@ private:
         float* data() { return p; }
     } down_;
     std::vector<uint8_t> b_type_, b_shape_;
-    std::vector<float> b_mass_, b_size_;
+    std::vector<float> b_mass_, b_size_, b_friction_;
     std::vector<uint32_t> b_layer_, b_mask_;
     size_t live_ = 0;
     std::vector<uint32_t> t_entity_, t_layer_, t_mask_, t_signature_;
@@ -587,6 +602,8 @@ public:
     // Bullet's own orientation scheme for every Dynamic body (include/bge_world.h, BGE_TICK_BULLET_BASIS); choose before
     // the first Update of a scene
     void SetBulletBasis(bool on) { bulletBasis_ = on; }
+    // the static ground plane every reference world has (on by default); off = free bodies
+    void SetGroundPlane(bool on) { groundPlane_ = on; }
     int LastSubSteps() const { return lastStepSubsteps_; }
     // trigger events of the last Update (publish them on the engine's EventBus, src/core/EventBus.h)
     const std::vector<GpuTriggerEvent>& TriggerEvents(SceneT& scene) const { return GpuMirrors<SceneT>::Of(scene).TriggerEvents(); }
@@ -646,6 +663,10 @@ private:
         m.gravity[1] = config_.gravity; // m_world->setGravity(btVector3(0, m_config.gravity, 0)), PhysicsSystem.cpp:130, 292
         m.gravity[2] = 0.0f;
         m.bullet_basis = bulletBasis_;
+        if (m.ground_plane_state != static_cast<int>(groundPlane_)) {
+            m.SetGroundPlane(groundPlane_);
+            m.ground_plane_state = static_cast<int>(groundPlane_);
+        }
         m.max_sub_steps = 4;                                        // PhysicsSystem.cpp:863
         m.fixed_step = std::max(config_.fixedStep, 1.0f / 240.0f); // kMinStep, PhysicsSystem.cpp:33, 855
         const auto start = std::chrono::high_resolution_clock::now();
@@ -662,6 +683,7 @@ private:
     bool hasLastWriteTime_ = false;
     Config config_{};
     bool bulletBasis_ = false;
+    bool groundPlane_ = true;
     double lastStepDurationMs_ = 0.0, lastStepDt_ = 0.0;
     int lastStepSubsteps_ = 0, lastBodies_ = 0;
 };

@@ -98,6 +98,22 @@ class World:
         check(lib().bge_world_step_simulation(self._h, float(dt), int(max_sub_steps), float(fixed_step), g, flags, C.byref(n)))
         return int(n.value)
 
+    def set_ground_plane(self, enabled=True):
+        """The reference's static plane y = 0 with Bullet's contact handling (include/bge_world.h)."""
+        check(lib().bge_world_set_ground_plane(self._h, int(enabled)))
+
+    def upload_friction(self, friction, first=0):
+        fr = _arr(friction, np.float32)
+        check(lib().bge_world_upload_friction(self._h, first, len(fr), _p(fr)))
+
+    def download_contacts(self, first=0, count=None):
+        """(n, points): n[i] contact points of body i with the ground; points[i, k] = localA.xyz, appliedImpulse, localB.x, distance, localB.z, lateral."""
+        count = self.n - first if count is None else count
+        n = np.zeros(count, np.uint8)
+        pts = np.zeros((count, 4, 8), np.float32)
+        check(lib().bge_world_download_contacts(self._h, first, count, _p(n), _p(pts)))
+        return n, pts
+
     def reset_clock(self):
         check(lib().bge_world_reset_clock(self._h))
 

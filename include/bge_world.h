@@ -239,6 +239,25 @@ BGE_API int bge_world_download_activation(bge_world* world, uint64_t first, uint
 /* Thresholds of the above (Bullet's defaults 0.8, 1.0, 2.0 — the reference never changes them).
  * seconds == 0 disables sleeping (Bullet: gDeactivationTime == 0). */
 BGE_API int bge_world_set_sleeping(bge_world* world, float linear_threshold, float angular_threshold, float seconds);
+/*
+ * The static ground plane of the reference's physics world, with Bullet's contact handling for it (SURVEY.md section 8(f)
+ * rank 4).  PhysicsSystem::EnsureGround (src/physics/PhysicsSystem.cpp:149-166) adds btStaticPlaneShape((0,1,0), 0) with
+ * friction 1 and restitution 0 to every world, in group StaticFilter (2) with mask AllFilter; stepSimulation (:863) then runs
+ * btConvexPlaneCollisionAlgorithm and btSequentialImpulseConstraintSolver for every Dynamic body at the plane:
+ *   per sub-step ONE contact at the collider's support vertex, kept in a 4-point persistent manifold; contact + friction
+ *   rows with warm starting, split impulse below -0.04, 10 iterations; the implicit gyroscopic impulse of a spinning body.
+ * A body dropped on the plane comes to rest on it and falls asleep (bge_world_download_activation).  Bodies still do not
+ * collide with EACH OTHER on this path (no convex-convex narrowphase): a body is an island of its own.
+ *   bge_world_set_ground_plane   0 (default) = free bodies, what BASELINE's workloads are; 1 = the reference's world.
+ *                                A body whose mask lacks bit 1 (value 2) passes through, as in Bullet.
+ *   bge_world_upload_friction    RigidBody::friction (default 0.5, src/ecs/PhysicsComponents.h:32); the plane's is 1.
+ *   bge_world_download_contacts  n_points[i] in 0..4 and, per body, 4 x (localA.xyz, appliedImpulse, localB.x, distance,
+ *                                localB.z, appliedImpulseLateral1; localB.y is exactly 0) — inspection (the reference exposes no contacts).
+ */
+BGE_API int bge_world_set_ground_plane(bge_world* world, int enabled);
+BGE_API int bge_world_upload_friction(bge_world* world, uint64_t first, uint64_t count, const float* friction);
+BGE_API int bge_world_upload_friction_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, const float* friction);
+BGE_API int bge_world_download_contacts(bge_world* world, uint64_t first, uint64_t count, uint8_t* n_points, float* points32);
 /* Scene::CountDirtyTransforms (src/ecs/Scene.cpp:435-446): a device-side wave-reduced count. */
 BGE_API int bge_world_dirty_count(bge_world* world, uint64_t* out);
 /* Overlapping pairs of the last BROADPHASE tick as (a, b) entity indices, a < b, unordered list.

@@ -192,6 +192,26 @@ void orc_set_accumulator(void* h, int enabled, float fixedStep, int maxSubSteps)
     S(h)->physics.localTime = 0.0f;
 }
 int orc_last_substeps(void* h) { return S(h)->physics.lastSubSteps; }
+// the reference's static ground plane y = 0 with Bullet's contact handling for it (contact_ref.h)
+void orc_set_ground_plane(void* h, int enabled) { S(h)->physics.groundPlane = enabled != 0; }
+void orc_set_friction(void* h, uint32_t id, float friction)
+{
+    if (RefRigidBody* b = S(h)->scene.GetRigidBody(id)) b->friction = friction;
+}
+// contacts of a body with the ground: count, and per point (localA.xyz, appliedImpulse, localB.x, distance, localB.z, appliedImpulseLateral1)
+int orc_get_ground_contacts(void* h, uint32_t id, float* out32)
+{
+    auto& rts = S(h)->physics.Runtimes();
+    auto it = rts.find(id);
+    if (it == rts.end()) return 0;
+    const auto& m = it->second.ground;
+    for (int k = 0; k < m.n && out32; ++k) {
+        float* o = out32 + 8 * k;
+        o[0] = m.p[k].localA.x; o[1] = m.p[k].localA.y; o[2] = m.p[k].localA.z; o[3] = m.p[k].appliedImpulse;
+        o[4] = m.p[k].localB.x; o[5] = m.p[k].distance; o[6] = m.p[k].localB.z; o[7] = m.p[k].appliedImpulseLateral1; // (localB.y is exactly 0)
+    }
+    return m.n;
+}
 uint64_t orc_count_dirty(void* h) { return S(h)->scene.CountDirtyTransforms(); }
 uint64_t orc_transform_count(void* h) { return S(h)->scene.GetTransformCount(); }
 

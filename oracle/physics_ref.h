@@ -77,6 +77,7 @@
 #include <vector>
 
 #include "bullet_math.h"
+#include "contact_ref.h"
 #include "ecs_ref.h"
 
 namespace orc {
@@ -103,6 +104,12 @@ struct RefBodyRuntime {
     float deactivationTime = 0.0f; // btCollisionObject::m_deactivationTime
     float aabbMin[3] = {0, 0, 0};
     float aabbMax[3] = {0, 0, 0};
+    // ground contact (contact_ref.h): the collider as Bullet holds it, mass properties, the manifold with the plane
+    ct::Shape shape;
+    float mass = 0.0f, friction = 0.5f;
+    bt::Vec3 localInertia{0, 0, 0}, invInertiaLocal{0, 0, 0};
+    float contactBreakingThreshold = 0.02f;
+    ct::Manifold ground;
 };
 
 // Trigger volumes.  Follows:
@@ -147,6 +154,10 @@ public:
     int maxSubSteps = 4;
     float localTime = 0.0f;          // btDiscreteDynamicsWorld::m_localTime
     int lastSubSteps = 1;            // stepSimulation's return value (m_lastStepSubsteps)
+    // the static plane y = 0 the reference adds to every world (PhysicsSystem.cpp:149-166) with Bullet's narrowphase and
+    // solver for it (contact_ref.h).  Off by default: BASELINE's workloads are free bodies.  A body whose
+    // mask lacks btBroadphaseProxy::StaticFilter (2) does not collide with it.
+    bool groundPlane = false;
 
     std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
     std::unordered_map<EntityId, RefTriggerRuntime>& TriggerRuntimes() { return triggerRuntime_; }
@@ -235,11 +246,16 @@ private:
                 const float halfHeight = std::max(collider.size.y, 0.0f);
                 // btCapsuleShape(radius, 2*halfHeight): m_implicitShapeDimensions.y = 0.5*height
                 rt.aabbHalfExtents = bt::CapsuleAabbHalfExtents(radius, 0.5f * (halfHeight * 2.0f));
+                rt.shape.capsule = true;
+                rt.shape.dims = bt::Vec3{radius, 0.5f * (halfHeight * 2.0f), radius};
             } else {
                 rt.aabbHalfExtents = bt::BoxAabbHalfExtents(std::max(collider.size.x, 0.01f),
                                                            std::max(collider.size.y, 0.01f),
                                                            std::max(collider.size.z, 0.01f));
+                rt.shape.capsule = false;
+                rt.shape.dims = rt.aabbHalfExtents; // getHalfExtentsWithMargin() = implicit dimensions + margin
             }
+            rt.contactBreakingThreshold = ct::ContactBreakingThreshold(rt.shape);
             rt.hasShape = true;
             collider.dirty = false;
             inserted = true;
@@ -250,6 +266,12 @@ private:
             float mass = 0.0f;
             if (body.type == RefBodyType::Dynamic) mass = std::max(body.mass, 0.01f);
             rt.invMass = mass != 0.0f ? 1.0f / mass : 0.0f; // btRigidBody::setMassProps
+            rt.mass = mass;
+            // shape->calculateLocalInertia(mass, inertia) (PhysicsSystem.cpp:431-434), info.m_friction = body.friction (:437)
+            rt.localInertia = mass > 0.0f ? ct::LocalInertia(rt.shape, mass) : bt::Vec3{0, 0, 0};
+            rt.invInertiaLocal = ct::InvInertiaLocal(rt.localInertia);
+            rt.friction = body.friction;
+            rt.ground.Clear(); // removeRigidBody drops the broadphase pair and with it the manifold
             PoseFromTransform(rt, *transform);
             rt.linvel = bt::Vec3{0, 0, 0};
             rt.angvel = bt::Vec3{0, 0, 0};
@@ -326,14 +348,39 @@ private:
             // applyGravity + solver write-back of the external force impulse.  m_gravity = acceleration / m_inverseMass:
             // a division per component in the reference's build (btRigidBody::setGravity, check_bullet_order.py)
             const bt::Vec3 force{g.x / rt.invMass, g.y / rt.invMass, g.z / rt.invMass};
-            rt.linvel.x = rt.linvel.x + (force.x * rt.invMass) * dt;
-            rt.linvel.y = rt.linvel.y + (force.y * rt.invMass) * dt;
-            rt.linvel.z = rt.linvel.z + (force.z * rt.invMass) * dt;
-            // integrateTransforms
+            bool solved = false;
+            if (groundPlane && (rt.mask & 2u) != 0u) {
+                // performDiscreteCollisionDetection for the pair (ground, body): group StaticFilter = 2 against the body's
+                // mask, the body's group against AllFilter; then the island {body} through the solver.  A body without a
+                // contact and without angular velocity takes the plain update below — the same arithmetic, (v + 0) + impulse.
+                ct::CollideWithGround(rt.ground, rt.shape, rt.contactBreakingThreshold, rt.origin, rt.basis);
+                if (rt.ground.n > 0 || spinning) {
+                    ct::BodyState b{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
+                    const bool moved = ct::SolveBodyAgainstGround(b, rt.ground, rt.shape, rt.invMass, rt.invInertiaLocal, rt.localInertia,
+                                                                  rt.friction, force, dt);
+                    rt.linvel = b.linVel;
+                    rt.angvel = b.angVel;
+                    if (moved) { // the split impulse corrected the pose
+                        rt.origin = b.origin;
+                        rt.orn = b.orn;
+                        rt.basis = b.basis;
+                        rt.freshPose = true;
+                    }
+                    solved = true;
+                }
+            }
+            if (!solved) {
+                rt.linvel.x = rt.linvel.x + (force.x * rt.invMass) * dt;
+                rt.linvel.y = rt.linvel.y + (force.y * rt.invMass) * dt;
+                rt.linvel.z = rt.linvel.z + (force.z * rt.invMass) * dt;
+            }
+            // integrateTransforms (with the velocities the solver left)
+            const bool spinningNow = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
+            const bool rotateNow = orientMode != kOrientIdeal || spinningNow;
             rt.origin.x = rt.origin.x + rt.linvel.x * dt;
             rt.origin.y = rt.origin.y + rt.linvel.y * dt;
             rt.origin.z = rt.origin.z + rt.linvel.z * dt;
-            if (rotate) {
+            if (rotateNow) {
                 rt.orn = bt::IntegrateOrientation(CurrentOrn(rt), rt.angvel, dt);
                 rt.basis = bt::MatFromQuat(rt.orn);
                 rt.freshPose = true;

@@ -62,6 +62,10 @@ class _Lib:
         l.orc_set_accumulator.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
         l.orc_last_substeps.argtypes = [C.c_void_p]
         l.orc_last_substeps.restype = C.c_int
+        l.orc_set_ground_plane.argtypes = [C.c_void_p, C.c_int]
+        l.orc_set_friction.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+        l.orc_get_ground_contacts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        l.orc_get_ground_contacts.restype = C.c_int
         l.orc_set_physics_options.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         l.orc_add_rigidbody.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint32, C.c_uint32]
 
@@ -298,6 +302,19 @@ class RefScene:
     def SetAccumulator(self, enabled=True, fixed_step=1.0 / 120.0, max_sub_steps=4):
         """Bullet's stepSimulation(dt, max_sub_steps, fixed_step) clock around the sub-steps (resets m_localTime)."""
         lib().orc_set_accumulator(self.h, int(enabled), float(np.float32(fixed_step)), int(max_sub_steps))
+
+    def SetGroundPlane(self, enabled=True):
+        """The static plane y = 0 of every reference world (PhysicsSystem.cpp:149-166) with Bullet's contact handling."""
+        lib().orc_set_ground_plane(self.h, int(enabled))
+
+    def SetFriction(self, eid, friction):
+        lib().orc_set_friction(self.h, eid, float(friction))
+
+    def GroundContacts(self, eid):
+        """(n, rows): rows[k] = localA.xyz, appliedImpulse, localB.x, distance, localB.z, appliedImpulseLateral1 of the body's k-th contact."""
+        out = np.zeros((4, 8), np.float32)
+        n = lib().orc_get_ground_contacts(self.h, eid, _vp(out))
+        return n, out[:n].copy()
 
     def LastSubSteps(self):
         return int(lib().orc_last_substeps(self.h))

@@ -66,6 +66,7 @@ struct Pair {
         rb->mass = gb->mass = mass;
         rb->layer = gb->layer = layer;
         rb->mask = gb->mask = mask;
+        rb->friction = gb->friction = 0.25f + 0.25f * static_cast<float>(id % 5); // RigidBody::friction reaches the contacts
     }
     void Trigger(uint32_t id, int shape, const float* size, uint32_t layer, uint32_t mask, bool oneShot)
     {
@@ -163,6 +164,7 @@ int main(int argc, char** argv)
         }
     }
     Pair w;
+    w.refPhysics.groundPlane = true; // the adapter's worlds have the reference's ground plane, as every PhysicsSystem world does
     // Application::ReloadScene -> m_physics.ReloadConfigIfNeeded(m_scene); m_fixedDt = m_physics.GetFixedStep()
     // (src/core/Application.cpp:324-326) with the values of the reference's assets/config/physics.json
     CHECK(w.gpuPhysics.GetFixedStep() == static_cast<double>(1.0f / 120.0f) && w.gpuPhysics.GetConfig().gravity == -9.81f, "defaults (PhysicsSystem.h:85-95)");

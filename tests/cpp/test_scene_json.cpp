@@ -107,8 +107,9 @@ static void RunCase(const std::string& text, const char* what, bool gpu)
     if (!gpu) return;
     orc::RefPhysicsSystem refPhysics;
     refPhysics.computeAabbs = true; // the ghost overlaps come from the fed body AABBs
+    refPhysics.groundPlane = true;  // every reference world has it; so has every world of the adapter
     bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
-    const double dt = static_cast<double>(0.0083333333f);
+    const double dt = gpuPhysics.GetFixedStep(); // the reference drives its tick with m_physics.GetFixedStep() (Application.cpp:86, 326)
     for (int k = 0; k < 5; ++k) {
         refPhysics.Update(ref, dt);
         gpuPhysics.Update(scene, dt);
@@ -195,6 +196,62 @@ int main(int argc, char** argv)
         CHECK(!bge::LoadSceneFromJsonText("{\"entities\": 3}", s, &bad), "'entities' must be an array");
     }
     RunCase(kSynthetic, "synthetic", gpu);
+    {
+        // SURVEY 8(f) rank 4, the reference's scene format: a Dynamic box and a capsule dropped onto the plane y = 0 every
+        // reference world has (PhysicsSystem.cpp:149-166) come to rest on it and fall asleep; a body whose mask excludes the
+        // ground's group falls through; a child entity follows its parent.  Product store + GPU adapter against oracle
+        // store + oracle physics, every tick, bit for bit (file: ground_drop_scene.json beside the demo fixture).
+        std::string path = argv[1];
+        const size_t slash = path.find_last_of('/');
+        path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "ground_drop_scene.json";
+        std::ifstream gf(path);
+        std::stringstream gs;
+        gs << gf.rdbuf();
+        CHECK(!gs.str().empty(), "cannot read %s", path.c_str());
+        orc::RefScene ref;
+        bge::Scene scene;
+        std::string err;
+        std::unordered_map<std::string, uint32_t> keys;
+        CHECK(bge::LoadSceneFromJsonText(gs.str(), ref, &err), "ground drop, oracle store: %s", err.c_str());
+        CHECK(bge::LoadSceneFromJsonText(gs.str(), scene, &err, &keys), "ground drop, product store: %s", err.c_str());
+        CompareStores(ref, scene, "ground drop", false);
+        CHECK(scene.GetRigidBody(keys["crate"]) && scene.GetRigidBody(keys["crate"])->friction == 0.6f, "friction ingested");
+        if (gpu) {
+            orc::RefPhysicsSystem refPhysics;
+            refPhysics.groundPlane = true;
+            bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
+            const double dt = gpuPhysics.GetFixedStep();
+            for (int k = 0; k < 560; ++k) {
+                refPhysics.Update(ref, dt);
+                gpuPhysics.Update(scene, dt);
+                orc::RefTransformSystemUpdate(ref);
+                bge::GpuTransformSystem<bge::Scene>::Update(scene);
+                CompareStores(ref, scene, "ground drop", true);
+                if (g_failures) break;
+            }
+            const auto* crate = scene.GetTransform(keys["crate"]);
+            const auto* barrel = scene.GetTransform(keys["barrel"]);
+            const auto* ghost = scene.GetTransform(keys["ghost"]);
+            CHECK(crate && crate->position.y > 0.49f && crate->position.y < 0.51f, "the crate rests on the plane (y = %g)", crate ? crate->position.y : 0.0f);
+            CHECK(barrel && barrel->position.y > 0.29f && barrel->position.y < 0.31f, "the capsule lies on the plane (y = %g)", barrel ? barrel->position.y : 0.0f);
+            CHECK(ghost && ghost->position.y < -50.0f, "a body whose mask lacks the ground's group falls through (y = %g)", ghost ? ghost->position.y : 0.0f);
+            for (const char* name : {"crate", "barrel"}) {
+                const auto& rt = refPhysics.Runtimes().at(keys[name]);
+                CHECK(rt.activation == orc::kIslandSleeping, "%s is asleep in the oracle (state %d)", name, rt.activation);
+            }
+            // ... and on the device (the adapter's dense indices follow hash-map order: count the states)
+            uint8_t state[4] = {0, 0, 0, 0};
+            CHECK(bge_world_download_activation(bge::GpuMirrors<bge::Scene>::Of(scene).world(), 0, 4, state, nullptr) == BGE_OK, "download_activation");
+            int asleep = 0, awake = 0, none = 0;
+            for (uint8_t st : state) {
+                asleep += st == BGE_ISLAND_SLEEPING;
+                awake += st == BGE_ACTIVE_TAG;
+                none += st == BGE_ACTIVATION_NONE;
+            }
+            CHECK(asleep == 2 && awake == 1 && none == 1, "device activation states: %d asleep, %d awake, %d without a body", asleep, awake, none);
+            std::printf("ground drop: crate at y = %.6f, capsule at y = %.6f, both asleep after %d ticks\n", crate->position.y, barrel->position.y, 560);
+        }
+    }
     if (g_failures == 0) std::printf("scene json: all checks passed%s\n", gpu ? " (with GPU ticks)" : "");
     return g_failures ? 1 : 0;
 }

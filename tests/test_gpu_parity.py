@@ -630,6 +630,88 @@ def test_step_simulation_clock_matches_oracle(basis):
         assert counts.count(0) >= 6 and max(counts) == 6 and 2 in counts and 3 in counts, counts
 
 
+@pytest.mark.parametrize("basis,aabbs", [(False, False), (True, False), (False, True)])
+def test_ground_plane_contacts_match_oracle_bitwise(basis, aabbs):
+    """the reference's static plane y = 0 (PhysicsSystem.cpp:149-166) with Bullet's narrowphase and
+    solver for it (bge_contact.hip against oracle/contact_ref.h).  Boxes and capsules of mixed size, mass, friction and
+    orientation are dropped from 0.2 .. 2.5 m; they hit the plane (hard landings take the split-impulse path), tumble,
+    slide, come to rest on 2 .. 4 cached contact points and fall asleep.  Static / Kinematic bodies, bodies whose mask
+    excludes the ground's group (they fall through), bodies in parent chains and re-created / teleported bodies ride along.
+    Every tick: position, rotationEuler, quaternion, both velocities, contact counts, contact points with their applied
+    impulses, activation state and timer (and the fed AABBs) must equal the oracle's bit for bit."""
+    n = 1200
+    rng = np.random.default_rng(77)
+    wl = synth.Workload("ground", synth.CHAINS4, n, 4711, bodies_on_roots_only=False)
+    wl.pos[:, 0] = rng.uniform(-40, 40, n).astype(np.float32)
+    wl.pos[:, 2] = rng.uniform(-40, 40, n).astype(np.float32)
+    wl.pos[:, 1] = rng.uniform(0.2, 2.5, n).astype(np.float32)
+    wl.euler[rng.random(n) < 0.15] = 0.0                      # some land perfectly flat (pure vertical push, four-way ties)
+    wl.body_type = rng.choice([1, 1, 1, 1, 1, 0, 2, 255], n).astype(np.uint8)
+    shape = rng.choice([0, 0, 0, 1], n).astype(np.uint8)
+    size = rng.uniform(0.15, 0.9, (n, 3)).astype(np.float32)
+    size[rng.random(n) < 0.2] = 0.5
+    mass = rng.choice([0.3, 1.0, 1.0, 2.5, 40.0], n).astype(np.float32)
+    friction = rng.choice([0.5, 0.5, 0.05, 1.0, 3.0], n).astype(np.float32)
+    mask = rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFD], n).astype(np.uint32)   # ...FD: no ground
+    ref = build_oracle(wl, orient_mode=po.ORIENT_BASIS if basis else po.ORIENT_IDEAL, aabbs=aabbs, shape=shape, size=size, mass=mass, mask=mask)
+    for i in range(n):
+        ref.SetFriction(i + 1, float(friction[i]))
+    ref.SetGroundPlane(True)
+    flags = B.TICK_ALL | (B.TICK_BULLET_BASIS if basis else 0) | (B.TICK_AABBS if aabbs else 0)
+    dyn = wl.body_type == 1
+    seen_counts, slept, pushed = set(), 0, 0
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, mass=mass, shape=shape, size=size, mask=mask)
+        w.upload_friction(friction)
+        w.set_ground_plane(True)
+        for tick in range(470):
+            if tick == 200:   # a teleport back into the air and a re-created body, both resting on the plane by now
+                e = int(np.flatnonzero(dyn)[3])
+                up = np.array([[wl.pos[e, 0], 1.5, wl.pos[e, 2]]], np.float32)
+                ref.SetTRS(e + 1, pos=up[0])
+                w.upload_trs(pos=up, first=e)
+                e2 = int(np.flatnonzero(dyn)[9])
+                ref.MarkBodyDirty(e2 + 1)
+                w.upload_bodies(wl.body_type[e2:e2 + 1], mass=mass[e2:e2 + 1], shape=shape[e2:e2 + 1], size=size[e2:e2 + 1], mask=mask[e2:e2 + 1], first=e2)
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, flags=flags)
+            if tick % 3 and tick > 5 and tick not in (200, 201, 202):
+                continue                                   # full comparison every third tick (and around the edits)
+            rb, gb = ref.bulk_bodies(), w.download_bodies()
+            ex = rb["exists"]
+            pos, euler = w.download_pose()
+            rpos, reuler = ref.bulk_pose()
+            assert_bits_equal(pos, rpos, f"tick {tick}: position")
+            assert_bits_equal(gb["linvel"][dyn], rb["linvel"][dyn], f"tick {tick}: linear velocity")
+            assert_bits_equal(gb["angvel"][dyn], rb["angvel"][dyn], f"tick {tick}: angular velocity")
+            assert_bits_equal(gb["quat"][ex], rb["quat"][ex], f"tick {tick}: quaternion")
+            assert_bits_equal(euler, reuler, f"tick {tick}: rotationEuler")
+            if aabbs:
+                assert_bits_equal(gb["aabb"][ex], rb["aabb"][ex], f"tick {tick}: fed AABBs")
+            cn, cpts = w.download_contacts()
+            for e in np.flatnonzero(dyn)[:: 7 if tick % 30 else 1]:
+                rn, rpts = ref.GroundContacts(int(e) + 1)
+                assert cn[e] == rn, f"tick {tick}: body {e} has {cn[e]} contacts, oracle {rn}"
+                assert_bits_equal(cpts[e, :rn], rpts, f"tick {tick}: contact points of body {e}")
+            seen_counts |= set(cn[dyn].tolist())
+            st, tm = w.download_activation()
+            rst, rtm = ref.bulk_activation()
+            assert np.array_equal(st[ex], rst[ex].astype(np.uint8)), f"tick {tick}: activation states"
+            assert_bits_equal(tm[ex & (rst == 1)], rtm[ex & (rst == 1)], f"tick {tick}: deactivation timers")
+            slept = int((st[dyn] == 2).sum())
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world matrices at the end")
+        final_pos, _ = w.download_pose()
+    through = dyn & (mask == 0xFFFFFFFD)
+    assert (final_pos[through & (wl.parent == 0xFFFFFFFF), 1] < -5.0).all()        # no ground for them: still falling
+    resting = dyn & (mask == 0xFFFFFFFF)
+    assert (final_pos[resting, 1] > 0.0).all() and (final_pos[resting, 1] < 2.0).all()  # everybody else stopped on the plane
+    assert {1, 2, 4} <= seen_counts, seen_counts                                    # single contacts, capsule lines, box faces
+    assert slept > 0.7 * resting.sum(), f"only {slept} of {resting.sum()} bodies fell asleep"
+
+
 def test_transform_fixtures_incl_multi_pass_layouts():
     """tests/golden/transform_cases.npz on the GPU: flat, chains, subtrees, a forest with Transform-less parents, a
     600-deep chain (three dependent passes) and a 700-wide root (children in a later pass read the parent from memory)."""

@@ -1,6 +1,7 @@
 """Bounds on the choices the physics restatement makes (CPU only): orientation-state idealisation and the
 deterministic libm.  Tolerance of the whole path is 1e-5 relative (BASELINE.json north_star)."""
 import numpy as np
+import pytest
 
 from banggameengine_amd import synth
 from oracle import pyoracle as po
@@ -170,3 +171,85 @@ def test_sleeping_body_stays_asleep_when_teleported_wakes_when_recreated():
         _step(ref)
     st, tm = ref.bulk_activation()
     assert st[0] == 1 and tm[0] > 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ground plane + contacts (oracle/contact_ref.h).  Spec-derived, parity unpinned except for the two
+# row solvers read from the reference's exe; these tests pin the oracle's OWN behaviour so that a change in it is seen.
+def _drop(shape=0, size=(0.5, 0.5, 0.5), pos=(0.0, 2.0, 0.0), euler=(0.3, 0.2, 0.1), mass=1.0, friction=0.5, mask=0xFFFFFFFF,
+          mode=po.ORIENT_IDEAL, ticks=600, vel=None):
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(-9.81, mode, False)
+    ref.SetGroundPlane(True)
+    e = ref.CreateEntity()
+    ref.AddTransform(e, pos=pos, euler=euler, scale=(1, 1, 1))
+    ref.AddCollider(e, shape, size)
+    ref.AddRigidBody(e, po.BODY_DYNAMIC, mass, 1, mask)
+    ref.SetFriction(e, friction)
+    ref.n = 1
+    for t in range(ticks):
+        ref.PhysicsSystemUpdate(DT)
+        ref.TransformSystemUpdate()
+        if t == 0 and vel is not None:
+            ref.SetVelocity(e, vel)
+    return ref, e
+
+
+@pytest.mark.parametrize("mode", [po.ORIENT_IDEAL, po.ORIENT_BASIS])
+def test_box_dropped_on_the_ground_plane_comes_to_rest_and_sleeps(mode):
+    ref, e = _drop(mode=mode)
+    b = ref.GetBody(e)
+    n, pts = ref.GroundContacts(e)
+    assert abs(b["origin"][1] - 0.5) < 2e-3                     # rests on a face: centre one half extent above y = 0
+    assert n == 4 and (np.abs(pts[:, 5]) < 0.02).all()          # four cached corner contacts within the breaking threshold
+    assert not b["linvel"].any() and not b["angvel"].any()      # asleep: velocities are zeroed every step
+    st, tm = ref.bulk_activation()
+    assert st[0] == 2                                           # ISLAND_SLEEPING
+    t = ref.GetTransform(e)
+    assert abs(t["world"][13] - b["origin"][1]) == 0.0          # Transform follows the body
+
+
+def test_capsule_lies_down_on_the_plane():
+    ref, e = _drop(shape=1, size=(0.3, 0.5, 0.0), euler=(0.0, 0.0, 1.3), ticks=700)
+    b = ref.GetBody(e)
+    assert abs(b["origin"][1] - 0.3) < 2e-3                     # on its side: centre one radius above the plane
+    st, _ = ref.bulk_activation()
+    assert st[0] == 2
+
+
+def test_friction_stops_a_sliding_box_and_its_coefficient_matters():
+    far = {}
+    for fr in (0.05, 0.5):
+        ref, e = _drop(pos=(0.0, 0.52, 0.0), euler=(0, 0, 0), friction=fr, vel=(4.0, 0.0, 0.0), ticks=500)
+        far[fr] = float(ref.GetBody(e)["origin"][0])
+    assert far[0.5] > 0.2 and far[0.05] > 3.0 * far[0.5]        # the slippery box slides much further (ground friction is 1)
+
+
+def test_a_body_whose_mask_excludes_the_static_group_falls_through():
+    ref, e = _drop(mask=0xFFFFFFFD, ticks=240)
+    assert ref.GetBody(e)["origin"][1] < -15.0 and ref.GroundContacts(e)[0] == 0
+
+
+def test_hard_landing_takes_the_split_impulse_path_and_does_not_gain_energy():
+    # 20 m/s downwards: one step travels 0.17, far deeper than the -0.04 split-impulse threshold
+    ref, e = _drop(pos=(0.0, 1.0, 0.0), euler=(0, 0, 0), vel=(0.0, -20.0, 0.0), ticks=4)
+    ys = []
+    for _ in range(200):
+        ref.PhysicsSystemUpdate(DT)
+        ref.TransformSystemUpdate()
+        ys.append(float(ref.GetBody(e)["origin"][1]))
+    assert min(ys) > 0.3 and max(ys) < 1.0                      # pushed out of the plane without being catapulted
+    assert abs(ys[-1] - 0.5) < 5e-3
+
+
+def test_ground_plane_off_is_the_free_body_path_bit_for_bit():
+    """With the plane off nothing of contact_ref.h runs; with it on, a body that never comes near the plane and does not spin
+    takes exactly the free-body arithmetic."""
+    wl = synth.config("flat10k", n=500)
+    wl.pos[:, 1] += np.float32(500.0)
+    a = run_oracle(build_oracle(wl), wl, 30)
+    b = build_oracle(wl)
+    b.SetGroundPlane(True)
+    run_oracle(b, wl, 30)
+    assert np.array_equal(a.bulk_world()[0].view(np.uint32), b.bulk_world()[0].view(np.uint32))
+    assert np.array_equal(a.bulk_bodies()["linvel"].view(np.uint32), b.bulk_bodies()["linvel"].view(np.uint32))
