@@ -54,6 +54,8 @@ constexpr uint32_t kHdrCountShift = 8;      // bits 8..16: valid slots (0..256)
 constexpr uint32_t kHdrCountMask = 0x1ffu;
 constexpr uint32_t kHdrExt = 1u << 17;      // some node has an external parent
 constexpr uint32_t kHdrWaveLocal = 1u << 18; // every in-tile parent sits in its child's 64-slot group: no workgroup barrier
+constexpr uint32_t kHdrAllDynamic = 1u << 19; // every valid slot of the tile carries a Dynamic body (set by bge_world_upload_bodies):
+                                              // the tick kernel then loads the velocities without waiting for the flag words
 constexpr uint32_t kGroup = 64;             // slots per wave64
 
 struct Flattened {

@@ -154,11 +154,29 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
     const uint32_t max_level = hdr & kHdrLevelMask;
 
     const uint32_t f0 = w.flags[slot];
+    // The component loads do not wait for the flag word: every array is allocated for whole tiles, so the loads of a slot
+    // that turns out to be empty (or of a velocity nobody integrates) are harmless, and issuing them together with the flags
+    // takes one memory round trip instead of two out of a workgroup's life (BGE_SPECULATIVE_LOADS=0: A/B build).  Measured at
+    // 1 M flat bodies: 24.4 -> 23.7 us per tick; velocities are only loaded early in tiles whose slots all carry a Dynamic body
+    // (loading them everywhere cost 64-node subtrees, 1 body in 64 entities, 4 % more time)
+#ifndef BGE_SPECULATIVE_LOADS
+#define BGE_SPECULATIVE_LOADS 1
+#endif
+    F3 pos{0.0f, 0.0f, 0.0f}, eul{0.0f, 0.0f, 0.0f}, scl{1.0f, 1.0f, 1.0f}, vel_early{0.0f, 0.0f, 0.0f};
+    if (BGE_SPECULATIVE_LOADS) {
+        pos = ld3(w.pos, slot);
+        eul = ld3(w.euler, slot);
+        if (XFORM) scl = ld3(w.scale, slot);
+        if (PHYS && (hdr & kHdrAllDynamic)) vel_early = ld3(w.vel, slot); // (elsewhere most slots have no velocity to read)
+    }
     uint32_t f = f0;
     const bool valid = (f & kValid) != 0;
-
-    F3 pos{0.0f, 0.0f, 0.0f}, eul{0.0f, 0.0f, 0.0f}, scl{1.0f, 1.0f, 1.0f};
-    if (valid) {
+    if (BGE_SPECULATIVE_LOADS) {
+        if (!valid) {
+            pos = eul = F3{0.0f, 0.0f, 0.0f};
+            scl = F3{1.0f, 1.0f, 1.0f};
+        }
+    } else if (valid) {
         pos = ld3(w.pos, slot);
         eul = ld3(w.euler, slot);
         if (XFORM) scl = ld3(w.scale, slot);
@@ -198,7 +216,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     f &= ~kSpin;
                 }
             } else {
-                if (dynamic) v = ld3(w.vel, slot);
+                if (dynamic) v = (BGE_SPECULATIVE_LOADS && (hdr & kHdrAllDynamic)) ? vel_early : ld3(w.vel, slot);
                 if (spin) av = ld3(w.angvel, slot);
                 if (turn || AABB) q = ld4(w.quat, slot);
             }

@@ -892,6 +892,28 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
         HIP_TRY(hipMemcpyAsync(w->mass_palette.p, pal.data(), pal.size() * sizeof(float2), hipMemcpyHostToDevice, w->stream));
         HIP_TRY(hipStreamSynchronize(w->stream));
     }
+    {
+        // tile headers: "every valid slot carries a Dynamic body" lets the tick kernel load velocities without waiting for flags
+        std::vector<uint32_t> dyn_in_tile(w->flat.n_tiles_total, 0);
+        for (uint64_t e = 0; e < w->flat.n_entities; ++e) {
+            const uint32_t sl = w->flat.slot_of_entity[e];
+            if (sl != bge::kNone && w->body_type_host[e] == BGE_BODY_DYNAMIC) dyn_in_tile[sl / bge::kTile]++;
+        }
+        bool changed = false;
+        for (uint32_t t = 0; t < w->flat.n_tiles_total; ++t) {
+            const uint32_t count = (w->flat.tile_hdr[t] >> bge::kHdrCountShift) & bge::kHdrCountMask;
+            const uint32_t want = (count != 0 && dyn_in_tile[t] == count) ? bge::kHdrAllDynamic : 0u;
+            if ((w->flat.tile_hdr[t] & bge::kHdrAllDynamic) != want) {
+                w->flat.tile_hdr[t] = (w->flat.tile_hdr[t] & ~bge::kHdrAllDynamic) | want;
+                changed = true;
+            }
+        }
+        if (changed) {
+            HIP_TRY(hipStreamSynchronize(w->stream));
+            HIP_TRY(hipMemcpy(w->tile_hdr.p, w->flat.tile_hdr.data(), static_cast<size_t>(w->flat.n_tiles_total) * 4, hipMemcpyHostToDevice));
+            w->drop_graph();
+        }
+    }
     const size_t bytes = words.size() * 4;
     HIP_TRY(w->stage.ensure(bytes));
     HIP_TRY(hipMemcpyAsync(w->stage.p, words.data(), bytes, hipMemcpyHostToDevice, w->stream));
