@@ -139,10 +139,13 @@ constexpr bool kSleepEnabled = true;
 #ifndef BGE_BASIS_MIN_WAVES
 #define BGE_BASIS_MIN_WAVES 6 /* the BGE_TICK_BULLET_BASIS variants without AABBs / normal matrices: 80 VGPRs; measured at 1 M bodies 35.1 us at 4, 34.8 at 6, 36.4 at 8 (64 VGPRs + 12 B scratch) */
 #endif
+#ifndef BGE_XFORM_MIN_WAVES
+#define BGE_XFORM_MIN_WAVES 7 /* the variants with the transform part and nothing else heavy (the headline kernel): at 8 waves per SIMD they get 64 VGPRs and spill 12 B per lane — 8 B per entity of scratch writes that rocprofv3 WRITE_SIZE showed (96 instead of 88 B); at 7 (72 VGPRs, no scratch) 1 M flat bodies tick in 22.9 us instead of 23.9, 2 M in 64-node subtrees in 37.9 instead of 38.7; 6 gives 23.2 */
+#endif
 template <bool PHYS, bool XFORM, bool AABB, bool NORMAL, bool BASIS>
 // 8 waves per SIMD (<= 64 VGPRs): the kernel waits on memory and, in block tiles, on barriers; occupancy hides both
 // (the NORMAL variant carries a 4x4 inverse: it gets 128 VGPRs instead of spilling)
-__global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES : (BASIS ? BGE_BASIS_MIN_WAVES : 8))) k_tick(WorldView w, TickParams p)
+__global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES : (BASIS ? BGE_BASIS_MIN_WAVES : (XFORM ? BGE_XFORM_MIN_WAVES : 8)))) k_tick(WorldView w, TickParams p)
 {
     __shared__ float4 lds[kTile * 4];
 
