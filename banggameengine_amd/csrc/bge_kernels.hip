@@ -148,6 +148,19 @@ template <bool PHYS, bool XFORM, bool AABB, bool NORMAL, bool BASIS>
 __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES : (BASIS ? BGE_BASIS_MIN_WAVES : (XFORM ? BGE_XFORM_MIN_WAVES : 8)))) k_tick(WorldView w, TickParams p)
 {
     __shared__ float4 lds[kTile * 4];
+    // BASIS: the euler write-back (getRotation -> setRotation -> getEulerZYX: two square roots, six divisions, asin, two atan2
+    // per body) is only needed by bodies whose quaternion changed in this step — 12 % of non-spinning bodies in steady state,
+    // scattered over all waves, so no wave could skip it.  Those lanes queue (lane, quaternion) here; after a barrier the first
+    // n threads of the workgroup compute the angles for the n queued bodies (usually one wave instead of four) and hand them back.
+    __shared__ uint32_t eq_count;
+    __shared__ uint32_t eq_lane[(PHYS && BASIS) ? kTile : 1];
+    __shared__ float4 eq_quat[(PHYS && BASIS) ? kTile : 1];
+    __shared__ float4 eq_euler[(PHYS && BASIS) ? kTile : 1];
+    if (PHYS && BASIS) {
+        if (threadIdx.x == 0) eq_count = 0;
+        __syncthreads();
+    }
+    bool euler_deferred = false;
 
     const uint32_t tile = p.tile_begin + blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -308,9 +321,16 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     pos.y = pos.y + v.y * p.dt;
                     pos.z = pos.z + v.z * p.dt;
                     if (turn) {
-                        q = bt_integrate_orientation(BASIS ? bt_quat_from_mat(bt_mat_from_quat(q)) : q, av, p.dt);
-                        st4(w.quat, slot, q);
-                        advanced = true;
+                        const Q4 qn = bt_integrate_orientation(BASIS ? bt_quat_from_mat(bt_mat_from_quat(q)) : q, av, p.dt);
+                        // BASIS: a quaternion the round trip maps onto itself (88 % of the non-spinning bodies in steady state)
+                        // needs neither the store nor new angles — rotationEuler already holds getEulerZYX of exactly these bits
+                        const bool same = BASIS && !repose && __float_as_uint(qn.x) == __float_as_uint(q.x) && __float_as_uint(qn.y) == __float_as_uint(q.y) &&
+                                          __float_as_uint(qn.z) == __float_as_uint(q.z) && __float_as_uint(qn.w) == __float_as_uint(q.w);
+                        q = qn;
+                        if (!same) {
+                            st4(w.quat, slot, q);
+                            advanced = true;
+                        }
                     }
                     st3(w.vel, slot, v);
                     st3(w.pos, slot, pos);
@@ -340,13 +360,36 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 // (re)posed or advanced; a non-spinning body keeps its euler triple bit for bit
                 if (repose || advanced || (ci & kCiMoved)) {
                     if (!(repose || advanced)) q = ld4(w.quat, slot); // the split impulse moved a body that does not spin
-                    eul = bt_transform_euler_from_mat(bt_mat_from_quat(q));
-                    st3(w.euler, slot, eul);
+                    if (BASIS) {
+                        const uint32_t at = atomicAdd(&eq_count, 1u);
+                        eq_lane[at] = tid;
+                        eq_quat[at] = make_float4(q.x, q.y, q.z, q.w);
+                        euler_deferred = true;
+                    } else {
+                        eul = bt_transform_euler_from_mat(bt_mat_from_quat(q));
+                        st3(w.euler, slot, eul);
+                    }
                 }
                 if (ci & (kCiSolved | kCiMoved)) w.cinfo[slot] = ci & ~(kCiSolved | kCiMoved); // consumed
                 f |= kTDirty; // transform->MarkDirty()
             }
             f &= ~kBDirty;
+        }
+    }
+
+    if (PHYS && BASIS) {
+        __syncthreads();
+        const uint32_t n_queued = eq_count;
+        if (tid < n_queued) {
+            const float4 qq = eq_quat[tid];
+            const F3 e = bt_transform_euler_from_mat(bt_mat_from_quat(Q4{qq.x, qq.y, qq.z, qq.w}));
+            eq_euler[eq_lane[tid]] = make_float4(e.x, e.y, e.z, 0.0f);
+        }
+        __syncthreads();
+        if (euler_deferred) {
+            const float4 e = eq_euler[tid];
+            eul = F3{e.x, e.y, e.z};
+            st3(w.euler, slot, eul);
         }
     }
 

@@ -41,6 +41,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# BGE_TICK_BULLET_BASIS: every Dynamic body also reads its quaternion (16 B).  The quaternion and rotationEuler are written back
+# (16 + 12 B) only for bodies whose quaternion changed in the step — Bullet rewrites all of them, with the same bits — so the
+# algorithmic minimum counts the read only (conservative for the roofline fraction: a spinning scene writes 28 B more per body)
+BASIS_EXTRA_BYTES = 16.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 STUB = os.environ.get("BGE_BENCH_STUB") == "1"  # tests/test_bench_launcher.py only: control flow over gloo, no GPU work
 
@@ -302,7 +306,7 @@ def measure_extra_config(B, synth, torch, label, name, entities, steps, warmup, 
             bpu = 208.0 + 8.0 * pairs / wl.n
             out["pairs"] = pairs
         if bullet_basis:
-            bpu += 44.0 * float((wl.body_type == 1).mean())
+            bpu += BASIS_EXTRA_BYTES * float((wl.body_type == 1).mean())
             out["orientation"] = "bullet basis round trip every tick"
         achieved = bpu * wl.n / (kernel_ms * 1e-3) / 1e9
         out.update({
@@ -563,8 +567,7 @@ def run_rank(args):
             bytes_per_update = 208.0 + 8.0 * world.pair_count() / per_gpu
             kernel_name = "k_tick<physics,transforms,aabb> + broadphase (sort, pair search)"
         if args.bullet_basis:
-            # every Dynamic body also reads and writes its quaternion (16 + 16 B) and writes rotationEuler (12 B)
-            bytes_per_update += 44.0 * float((wl.body_type == 1).mean())
+            bytes_per_update += BASIS_EXTRA_BYTES * float((wl.body_type == 1).mean())
             kernel_name += " [bullet basis]"
         alg_bytes = bytes_per_update * per_gpu  # per step on one GPU
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
