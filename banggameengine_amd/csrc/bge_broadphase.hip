@@ -86,6 +86,7 @@ struct Accum {
     uint32_t extent_large[kHistShards][kExtentBins];
     uint32_t scan_ticket;              // tile tickets of k_scan_lookback (dispatch order)
     uint32_t scan_error;               // a look-back gave up (never observed; keeps a logic error from hanging the GPU)
+    uint32_t reduce_ticket;            // workgroups of k_bp_reduce_partials that are done; the last one decides the grid
 };
 
 constexpr uint32_t kLargeCell = 0xffffffffu;
@@ -211,8 +212,13 @@ __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint3
 // extent histogram is then a histogram of WAVE maxima: bin b holds the bodies of the waves whose widest body falls into b
 // (they are all at most that wide) and, as its "large" weight, the number of such waves.  Good enough to choose the cell
 // size — the choice only affects speed: whatever the cell, a body wider than it is treated as large by the sort itself.
+// With `decide` the workgroup that finishes last goes on to choose the grid (decide_grid below) — what a separate
+// k_bp_params launch did: 5.2 + 15.6 us as two kernels at 4 M bodies (profiles/r02/cube4m_kernel_stats.csv).
 constexpr uint32_t kReduceBlocks = 128;
-__global__ void __launch_bounds__(256) k_bp_reduce_partials(const float4* __restrict__ partials, uint32_t n_partials, Accum* acc)
+template <uint32_t NS> __device__ void decide_grid(Accum* acc, uint32_t max_cells, uint32_t n_bounds_blocks);
+constexpr uint32_t kReduceShards = 4; // histogram copies the 128 workgroups of k_bp_reduce_partials spread their atomics over
+__global__ void __launch_bounds__(256) k_bp_reduce_partials(const float4* __restrict__ partials, uint32_t n_partials, Accum* acc,
+                                                            uint32_t max_cells, uint32_t decide)
 {
     __shared__ uint32_t hist[kExtentBins];
     __shared__ uint32_t hwaves[kExtentBins];
@@ -304,11 +310,27 @@ __global__ void __launch_bounds__(256) k_bp_reduce_partials(const float4* __rest
     for (uint32_t k = threadIdx.x; k < kExtentBins; k += blockDim.x) {
         const uint32_t h = hist[k];
         if (h) {
-            atomicAdd(&acc->extent_hist[blockIdx.x % kHistShards][k], h);
-            atomicAdd(&acc->extent_large[blockIdx.x % kHistShards][k], hwaves[k]);
-            if (hmax[k]) atomicMax(&acc->extent_max[blockIdx.x % kHistShards][k], hmax[k]);
+            atomicAdd(&acc->extent_hist[blockIdx.x % kReduceShards][k], h);
+            atomicAdd(&acc->extent_large[blockIdx.x % kReduceShards][k], hwaves[k]);
+            if (hmax[k]) atomicMax(&acc->extent_max[blockIdx.x % kReduceShards][k], hmax[k]);
         }
     }
+    if (!decide) return;
+    // Every thread's stores and atomics are made visible at device scope, then one ticket per workgroup; whoever draws the
+    // last one sees all the others' results (acquire: this CU's vector L1 is dropped) and decides.  Every workgroup reaches
+    // this point, so the ticket word is back at 0 when the kernel ends.
+    __shared__ uint32_t last_one;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(&acc->reduce_ticket, 1u);
+        last_one = t == gridDim.x - 1u;
+        if (last_one) acc->reduce_ticket = 0;
+    }
+    __syncthreads();
+    if (!last_one) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    decide_grid<kReduceShards>(acc, max_cells, gridDim.x);
 }
 
 // LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the
@@ -325,9 +347,10 @@ __device__ __forceinline__ void wave_sync()
 //            + n_large(c) * n                        (k_bp_large: every large body against everything)
 // over the histogram's bin edges c (a body is "small" when its widest side is < c); then grow the cell
 // until the padded grid fits the table.
-__global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32_t max_cells, uint32_t n_bounds_blocks)
+// NS: how many of the kHistShards copies of the extent histogram the producer filled (the others are all zero).
+template <uint32_t NS> __device__ void decide_grid(Accum* acc, uint32_t max_cells, uint32_t n_bounds_blocks)
 {
-    constexpr uint32_t kWaves = kParamsThreads / 64;
+    constexpr uint32_t kWaves = kParamsThreads / 64; // at most: the caller's workgroup has blockDim.x / 64 of them
     __shared__ uint32_t below[kExtentBins + 1]; // exclusive prefix: bodies in bins < b
     __shared__ uint32_t lbelow[kExtentBins + 1]; // the same prefix over the bins' "large" weights (bodies, or waves)
     __shared__ uint32_t binmax[kExtentBins];    // widest extent in the bin (float bits)
@@ -340,27 +363,46 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
         // for the partials and one for the histogram (every thread one bin, its 16 copies in flight together).
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         uint32_t cnt = 0;
-        for (uint32_t b = threadIdx.x; b < n_bounds_blocks; b += kParamsThreads) {
+        for (uint32_t b = threadIdx.x; b < n_bounds_blocks; b += blockDim.x) {
             for (int a = 0; a < 3; ++a) {
                 mn[a] = fminf(mn[a], acc->part_min[b][a]);
                 mx[a] = fmaxf(mx[a], acc->part_max[b][a]);
             }
             cnt += acc->part_count[b];
         }
-        for (uint32_t b = threadIdx.x; b < kExtentBins; b += kParamsThreads) {
-            uint32_t t = 0, m = 0, lw = 0;
+        // All of a thread's histogram words are loaded before the first of them is cleared: interleaved, every load waited
+        // behind the store in front of it and the 48 round trips came one after the other (20 us of k_bp_params' 21).
+        constexpr uint32_t G = kHistShards / NS; // bins per thread and sweep: 48 loads in flight either way
+        for (uint32_t b0 = threadIdx.x; b0 < kExtentBins; b0 += blockDim.x * G) {
+            uint32_t hv[G][NS], lv[G][NS], mv[G][NS];
 #pragma unroll
-            for (uint32_t c = 0; c < kHistShards; ++c) {
-                t += acc->extent_hist[c][b];
-                lw += acc->extent_large[c][b];
-                m = max(m, acc->extent_max[c][b]);
-                acc->extent_hist[c][b] = 0; // consumed: ready for the next run's k_bp_bounds (there is no reset kernel)
-                acc->extent_large[c][b] = 0;
-                acc->extent_max[c][b] = 0;
+            for (uint32_t g = 0; g < G; ++g) {
+                const uint32_t b = min(b0 + g * blockDim.x, kExtentBins - 1u);
+#pragma unroll
+                for (uint32_t c = 0; c < NS; ++c) {
+                    hv[g][c] = acc->extent_hist[c][b];
+                    lv[g][c] = acc->extent_large[c][b];
+                    mv[g][c] = acc->extent_max[c][b];
+                }
             }
-            below[b] = t; // the totals, for the moment
-            lbelow[b] = lw;
-            binmax[b] = m;
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                const uint32_t b = b0 + g * blockDim.x;
+                if (b >= kExtentBins) continue;
+                uint32_t t = 0, m = 0, lw = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < NS; ++c) {
+                    t += hv[g][c];
+                    lw += lv[g][c];
+                    m = max(m, mv[g][c]);
+                    acc->extent_hist[c][b] = 0; // consumed: ready for the next run (there is no reset kernel)
+                    acc->extent_large[c][b] = 0;
+                    acc->extent_max[c][b] = 0;
+                }
+                below[b] = t; // the totals, for the moment
+                lbelow[b] = lw;
+                binmax[b] = m;
+            }
         }
         // the counters the REST of this run accumulates into (every kernel that touches them is launched after this one)
         if (threadIdx.x < kShards) acc->shard_count[threadIdx.x][0] = 0;
@@ -394,7 +436,7 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
         gmn[a] = INFINITY;
         gmx[a] = -INFINITY;
     }
-    for (uint32_t wv = 0; wv < kParamsThreads / 64; ++wv) {
+    for (uint32_t wv = 0; wv < blockDim.x / 64; ++wv) {
         for (int a = 0; a < 3; ++a) {
             gmn[a] = fminf(gmn[a], red[wv][a]);
             gmx[a] = fmaxf(gmx[a], red[wv][3 + a]);
@@ -508,6 +550,12 @@ __global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32
     g.dim_xy = dx * dy;
     g.n_cells = dx * dy * dz;
     acc->grid = g;
+}
+
+// decide_grid as a launch of its own: after k_bp_bounds, and after k_bp_reduce_partials under BGE_BP_PARAMS=split
+__global__ void __launch_bounds__(kParamsThreads) k_bp_params(Accum* acc, uint32_t max_cells, uint32_t n_bounds_blocks)
+{
+    decide_grid<kHistShards>(acc, max_cells, n_bounds_blocks);
 }
 
 __device__ __forceinline__ uint32_t cell_axis(const GridParams& g, float v, int a)
@@ -1545,6 +1593,131 @@ __global__ void __launch_bounds__(256) k_bp_large(uint64_t n_slots, const Accum*
     if (st.fill) stage_flush(sink, st, st.fill);
 }
 
+// ---- box queries against the sorted bodies of this run (trigger ghosts when a scene carries many of them)
+// A body sits in the cell of its min corner and a small body is narrower than one cell, so the bodies that can overlap a box
+// [mn, mx] have their min corner in the cells cell(mn) - 1 .. cell(mx) of every axis (clamped like the bodies' own cells).
+// Boxes covering more than kQueryMaxCells cells are handed back to the caller's all-bodies pass: one wave walking a large
+// part of the table would be slower than that pass.
+constexpr uint32_t kQueryMaxCells = 8192;
+struct BoxCells {
+    uint32_t lo[3], n[3];
+};
+__device__ __forceinline__ bool box_cells(const GridParams& g, const float* b, BoxCells& c)
+{
+    if (!(b[0] <= b[3] && b[1] <= b[4] && b[2] <= b[5]) || g.n_cells == 0u) return false; // an empty box (inactive ghost), or no grid
+    const uint32_t dim[3] = {g.dim_x, g.dim_xy / g.dim_x, g.n_cells / g.dim_xy};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t lo = min(max(cell_axis(g, b[a], a), 2u) - 1u, dim[a] - 2u);
+        const uint32_t hi = min(cell_axis(g, b[3 + a], a), dim[a] - 2u);
+        c.lo[a] = lo;
+        c.n[a] = hi >= lo ? hi - lo + 1u : 1u;
+    }
+    return true;
+}
+
+// counters: [0] hits, [1] boxes in big_list, [2] boxes in grid_list
+__global__ void __launch_bounds__(256) k_bp_classify_boxes(const Accum* __restrict__ acc, uint32_t n_boxes, const float* __restrict__ box,
+                                                           uint32_t* __restrict__ counters, uint32_t* __restrict__ big_list,
+                                                           uint32_t* __restrict__ grid_list)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_boxes) return;
+    BoxCells c;
+    if (!box_cells(acc->grid, box + 6ull * i, c)) return;
+    const unsigned long long cells = static_cast<unsigned long long>(c.n[0]) * c.n[1] * c.n[2];
+    if (cells <= kQueryMaxCells) grid_list[atomicAdd(&counters[2], 1u)] = i;
+    else big_list[atomicAdd(&counters[1], 1u)] = i;
+}
+
+// One wave per box; each lane walks one row (consecutive cells in x = consecutive sorted records) of the box's cell range.
+// A hit is (box index, body entity), appended behind one atomic per ballot — the format of the all-bodies pass.
+template <bool COMPACT>
+__global__ void __launch_bounds__(256) k_bp_query_boxes(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
+                                                        const float4* __restrict__ sorted, const uint4* __restrict__ filter_table,
+                                                        const float* __restrict__ box, const uint32_t* __restrict__ box_group,
+                                                        const uint32_t* __restrict__ box_mask, const uint32_t* __restrict__ box_entity,
+                                                        const uint32_t* __restrict__ grid_list, uint32_t* __restrict__ counters,
+                                                        const uint32_t* __restrict__ large_list, const float* __restrict__ aabb,
+                                                        const uint32_t* __restrict__ flags, const uint32_t* __restrict__ group,
+                                                        const uint32_t* __restrict__ mask, const uint32_t* __restrict__ entity_of_slot,
+                                                        uint2* __restrict__ out, uint32_t cap)
+{
+    constexpr uint32_t RS = COMPACT ? 2u : 3u;
+    const GridParams g = acc->grid;
+    const uint32_t n_grid = counters[2];
+    const uint32_t n_large = acc->n_large;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    auto emit = [&](bool hit, uint32_t i, uint32_t ent) {
+        const unsigned long long m = __ballot(hit);
+        if (m == 0) return;
+        const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counters[0], static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, static_cast<int>(leader), 64);
+        if (hit) {
+            const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+            if (at < cap) out[at] = make_uint2(i, ent);
+        }
+    };
+    for (uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < n_grid; k += waves) {
+        const uint32_t i = grid_list[k];
+        float b[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) b[a] = box[6ull * i + a];
+        BoxCells c;
+        if (!box_cells(g, b, c)) continue; // (classified with the same function: not taken)
+        const float4 blo = make_float4(b[0], b[1], b[2], 0), bhi = make_float4(b[3], b[4], b[5], 0);
+        const uint32_t tg = box_group[i], tm = box_mask[i], te = box_entity[i];
+        const uint32_t rows = c.n[1] * c.n[2];
+        for (uint32_t r0 = 0; r0 < rows; r0 += 64u) {
+            const uint32_t r = r0 + lane;
+            uint32_t j = 0, end = 0;
+            if (r < rows) {
+                const uint32_t c0 = c.lo[0] + g.dim_x * (c.lo[1] + r % c.n[1]) + g.dim_xy * (c.lo[2] + r / c.n[1]);
+                j = cell_start[c0];
+                end = cell_start[c0 + c.n[0]];
+            }
+            while (__any(j < end)) {
+                bool hit = false;
+                uint32_t ent = 0;
+                if (j < end) {
+                    const float4 lo = sorted[static_cast<uint64_t>(RS) * j], hi = sorted[static_cast<uint64_t>(RS) * j + 1];
+                    if (overlap(blo, bhi, lo, hi)) {
+                        uint4 e; // (group, mask, static)
+                        if (COMPACT) {
+                            e = filter_table[__float_as_uint(hi.w) & 255u];
+                        } else {
+                            const float4 f = sorted[3ull * j + 2];
+                            e = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), 0u);
+                        }
+                        ent = __float_as_uint(lo.w);
+                        // the ghost is a static object: static bodies never pair with it
+                        hit = e.z == 0u && ent != te && (tg & e.y) != 0u && (e.x & tm) != 0u;
+                    }
+                    ++j;
+                }
+                emit(hit, i, ent);
+            }
+        }
+        // the bodies too wide for the grid
+        for (uint32_t l0 = 0; l0 < n_large; l0 += 64u) {
+            bool hit = false;
+            uint32_t ent = 0;
+            if (l0 + lane < n_large) {
+                const uint32_t L = large_list[l0 + lane];
+                const float* q = aabb + 6ull * L;
+                if (overlap(blo, bhi, make_float4(q[0], q[1], q[2], 0), make_float4(q[3], q[4], q[5], 0))) {
+                    ent = entity_of_slot[L];
+                    hit = (flags[L] & kTypeMask) >= 2u && ent != te && (tg & mask[L]) != 0u && (group[L] & tm) != 0u;
+                }
+            }
+            emit(hit, i, ent);
+        }
+    }
+}
+
 // Shard slices -> one compact list.  Block (shard, part): offset of the shard = sum of the kept counts before it.
 constexpr uint32_t kCompactParts = 32;
 __global__ void __launch_bounds__(256) k_bp_compact(Accum* acc, const uint2* __restrict__ staged, uint64_t shard_cap,
@@ -1642,6 +1815,7 @@ int Broadphase::configure(uint64_t n_slots, uint64_t pair_capacity)
     sort_groups_ = kSortGroups;
     if (const char* e = std::getenv("BGE_BP_SORT_GROUPS")) sort_groups_ = std::min<uint32_t>(kSortGroups, std::max(1, std::atoi(e))); // tests: several passes per workgroup at small n
     if (const char* e = std::getenv("BGE_BP_BOUNDS")) fused_bounds_ = std::string(e) != "pass"; // A/B and tests: k_bp_bounds' own pass over the AABBs
+    if (const char* e = std::getenv("BGE_BP_PARAMS")) fused_params_ = std::string(e) != "split"; // A/B: k_bp_params as its own launch
     if (const char* e = std::getenv("BGE_BP_FILTER")) small_palette_ = std::string(e) != "table"; // A/B and tests: keep the (group, mask) table
     if (const char* e = std::getenv("BGE_BP_COARSE")) transposed_coarse_ = std::string(e) != "scatter"; // A/B: per-thread scattered record writes
     if (const char* e = std::getenv("BGE_BP_RECORDS")) full_records_ = std::atoi(e) == 48;  // A/B: BGE_BP_RECORDS=48 keeps full records
@@ -1715,6 +1889,7 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     const PairSink sink{&acc->shard_count[0][0], static_cast<uint2*>(scan_stage_), shard_cap,
                         window ? window->axis : 0u, window ? window->lo : -INFINITY, window ? window->hi : INFINITY};
     ran_ = true;
+    last_compact_ = compact_records;
     if (n == 0) {
         BP_TRY(hipMemsetAsync(counters_, 0, sizeof(Accum), stream));
         return BGE_OK;
@@ -1729,11 +1904,13 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
         // the tick kernel left one partial per wave beside the AABBs: 32 bytes per 64 slots instead of 28 per slot
         const uint32_t n_partials = static_cast<uint32_t>(n / 64);
         bounds_blocks = std::min<uint32_t>(kReduceBlocks, blocks_for(n_partials, 256));
-        hipLaunchKernelGGL(k_bp_reduce_partials, dim3(bounds_blocks), dim3(256), 0, stream, wave_partials, n_partials, acc);
+        hipLaunchKernelGGL(k_bp_reduce_partials, dim3(bounds_blocks), dim3(256), 0, stream, wave_partials, n_partials, acc, table_size_,
+                           fused_params_ ? 1u : 0u);
+        if (!fused_params_) hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(kParamsThreads), 0, stream, acc, table_size_, bounds_blocks);
     } else {
         hipLaunchKernelGGL(k_bp_bounds, dim3(bounds_blocks), dim3(256), 0, stream, n, w.flags, w.aabb, acc);
+        hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(kParamsThreads), 0, stream, acc, table_size_, bounds_blocks);
     }
-    hipLaunchKernelGGL(k_bp_params, dim3(1), dim3(kParamsThreads), 0, stream, acc, table_size_, bounds_blocks);
     if (lds_sort_) {
         const uint32_t groups = std::min<uint32_t>(sort_groups_, blocks_for(n, kSortThreads));
         const uint64_t chunk = (n + groups - 1) / groups;
@@ -1825,6 +2002,33 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
     // The pairs now sit in 64 shard slices; the compact list is built on demand (compact()): a tick whose pairs nobody
     // downloads does not pay the 49 us copy (4 M bodies, 12.6 M pairs).
     compacted_ = false;
+    BP_TRY(hipGetLastError());
+    return BGE_OK;
+}
+
+int Broadphase::query_boxes(hipStream_t stream, const WorldView& w, const uint32_t* entity_of_slot, const FilterPalette* palette,
+                            const BoxQuery& q)
+{
+    if (!ran_) {
+        error_ = "query_boxes before run";
+        return BGE_ERR_STATE;
+    }
+    if (q.n_boxes == 0) return BGE_OK;
+    const Accum* acc = static_cast<const Accum*>(counters_);
+    hipLaunchKernelGGL(k_bp_classify_boxes, dim3(blocks_for(q.n_boxes, 256)), dim3(256), 0, stream, acc, q.n_boxes, q.aabb, q.counters,
+                       q.big_list, q.grid_list);
+    const dim3 grid(std::min<uint32_t>(blocks_for(q.n_boxes, 4), 2048u));
+    const uint32_t* cell_start = static_cast<const uint32_t*>(cell_start_);
+    const float4* sorted = static_cast<const float4*>(sorted_aabb_);
+    const uint32_t* large_list = static_cast<const uint32_t*>(large_list_);
+    if (last_compact_) {
+        hipLaunchKernelGGL(k_bp_query_boxes<true>, grid, dim3(256), 0, stream, acc, cell_start, sorted, palette->table, q.aabb, q.group, q.mask,
+                           q.entity, q.grid_list, q.counters, large_list, w.aabb, w.flags, w.group, w.mask, entity_of_slot, q.out, q.cap);
+    } else {
+        hipLaunchKernelGGL(k_bp_query_boxes<false>, grid, dim3(256), 0, stream, acc, cell_start, sorted, static_cast<const uint4*>(nullptr),
+                           q.aabb, q.group, q.mask, q.entity, q.grid_list, q.counters, large_list, w.aabb, w.flags, w.group, w.mask,
+                           entity_of_slot, q.out, q.cap);
+    }
     BP_TRY(hipGetLastError());
     return BGE_OK;
 }

@@ -23,6 +23,23 @@ struct FilterPalette {
     uint32_t n_classes = 256;      // entries in use
 };
 
+// Boxes (trigger ghosts) against the bodies of the last run(): hits are (box index, body entity) appended at
+// out[counters[0]++].  Boxes that span too many cells for a walk of the grid are listed in big_list (counters[1] of them)
+// for the caller's own pass over all bodies.  A body pairs with a box when it is not Static, is not the box's own entity and
+// (box.group & body.mask) && (body.group & box.mask).
+struct BoxQuery {
+    uint32_t n_boxes;
+    const float* aabb;       // [n][6]; min > max: not in the world
+    const uint32_t* group;   // [n]
+    const uint32_t* mask;    // [n]
+    const uint32_t* entity;  // [n]
+    uint32_t* counters;      // [3], zeroed by the caller: hits, boxes in big_list, boxes walked through the grid
+    uint32_t* big_list;      // [n]
+    uint32_t* grid_list;     // [n] scratch
+    uint2* out;
+    uint32_t cap;
+};
+
 class Broadphase {
 public:
     // n_slots: upper bound of bodies; pair_capacity: pairs kept per tick
@@ -30,6 +47,7 @@ public:
     // Collect the overlapping pairs of the AABBs the tick kernel just wrote.
     int run(hipStream_t stream, const WorldView& w, uint64_t n_slots_ticked, const uint32_t* entity_of_slot,
             const PairWindow* window = nullptr, const FilterPalette* palette = nullptr, const float4* wave_partials = nullptr);
+    int query_boxes(hipStream_t stream, const WorldView& w, const uint32_t* entity_of_slot, const FilterPalette* palette, const BoxQuery& q);
     int download(hipStream_t stream, uint32_t* pairs2, uint64_t cap, uint64_t* total);
     // The search leaves the pairs in 64 shard slices; this builds the compact list (idempotent until the next run).
     int compact(hipStream_t stream);
@@ -61,6 +79,7 @@ private:
     void *sort_matrix_ = nullptr, *sort_offsets_ = nullptr, *sort_status_ = nullptr, *coarse_ = nullptr;
     bool block_pairs_ = false;
     bool fused_bounds_ = true;      // grid from the tick kernel's per-wave partials (TickParams::bp_partial) when the caller has them; BGE_BP_BOUNDS=pass for A/B
+    bool fused_params_ = true;      // the last workgroup of k_bp_reduce_partials chooses the grid; BGE_BP_PARAMS=split launches k_bp_params instead
     uint32_t sort_groups_ = 512;    // chunk workgroups of the coarse passes (BGE_BP_SORT_GROUPS lowers it: tests)
     uint32_t fine_window_[2] = {0, 0}; // records in k_sort_fine_t's LDS window: [0] 48-byte records, [1] 32-byte records
     bool small_palette_ = true;     // wave search: one compatibility word per class when the palette has <= 32 classes
@@ -70,6 +89,7 @@ private:
     void* body_cell_ = nullptr;   // int32[n_slots][4]
     void* large_list_ = nullptr;  // uint32[n_slots]
     bool ran_ = false;
+    bool last_compact_ = false;   // record format of the last run (32-byte records with a filter class)
     bool compacted_ = false;
 };
 

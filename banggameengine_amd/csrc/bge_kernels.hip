@@ -785,11 +785,15 @@ __global__ void k_trigger_aabb(uint32_t n_triggers, TriggerView t, WorldView w)
 }
 
 // every body against every trigger (scenes carry a handful of triggers; n_bodies x n_triggers box tests); hits are
-// ballot-compacted per wave and appended behind one atomic per wave and trigger
+// ballot-compacted per wave and appended behind one atomic per wave and trigger.  With `list` only the list[0 .. *list_count)
+// triggers are tested: the ones Broadphase::query_boxes left over (boxes that span too much of the grid to walk it).
 __global__ void __launch_bounds__(256) k_trigger_pairs(uint64_t n_slots, uint32_t n_triggers, TriggerView t, WorldView w,
                                                        const uint32_t* __restrict__ entity_of_slot, uint32_t* __restrict__ count,
-                                                       uint2* __restrict__ out, uint32_t cap)
+                                                       uint2* __restrict__ out, uint32_t cap, const uint32_t* __restrict__ list,
+                                                       const uint32_t* __restrict__ list_count)
 {
+    const uint32_t n_tested = list ? *list_count : n_triggers;
+    if (n_tested == 0) return;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     const uint64_t first = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     const uint64_t rounds = (n_slots + stride - 1) / stride; // uniform trip count: the ballot needs every lane
@@ -814,7 +818,8 @@ __global__ void __launch_bounds__(256) k_trigger_pairs(uint64_t n_slots, uint32_
                 ent = entity_of_slot[s];
             }
         }
-        for (uint32_t i = 0; i < n_triggers; ++i) {
+        for (uint32_t k = 0; k < n_tested; ++k) {
+            const uint32_t i = list ? list[k] : k;
             const float* tb = t.aabb + 6ull * i;
             bool hit = body && ent != t.entity[i] && (t.group[i] & msk) != 0 && (grp & t.mask[i]) != 0;
             if (hit) {
@@ -942,12 +947,13 @@ hipError_t launch_trigger_aabb(hipStream_t stream, uint32_t n_triggers, const Tr
 }
 
 hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n_triggers, const TriggerView& t, const WorldView& w,
-                                const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap)
+                                const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap, const uint32_t* list,
+                                const uint32_t* list_count)
 {
     if (n_triggers == 0 || n_slots == 0) return hipSuccess;
     const uint64_t blocks = (n_slots + 255) / 256;
     hipLaunchKernelGGL(k_trigger_pairs, dim3(static_cast<uint32_t>(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, n_slots,
-                       n_triggers, t, w, entity_of_slot, count, static_cast<uint2*>(out_pairs), cap);
+                       n_triggers, t, w, entity_of_slot, count, static_cast<uint2*>(out_pairs), cap, list, list_count);
     return hipGetLastError();
 }
 

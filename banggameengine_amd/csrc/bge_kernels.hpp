@@ -113,7 +113,8 @@ hipError_t launch_dirty_bytes(hipStream_t stream, const uint32_t* slot_of_entity
                               const uint32_t* flags, uint8_t* out);
 hipError_t launch_trigger_aabb(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, const WorldView& w);
 hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n_triggers, const TriggerView& t, const WorldView& w,
-                                const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap);
+                                const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap,
+                                const uint32_t* list = nullptr, const uint32_t* list_count = nullptr);
 // compact: 12 floats per root (4x3, the constant fourth column dropped) instead of 16
 hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst,
                              bool compact = false);

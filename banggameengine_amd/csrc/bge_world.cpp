@@ -209,7 +209,9 @@ struct bge_world {
     std::vector<Trigger> triggers;
     std::vector<bge_trigger_event> trigger_events; // since the last bge_world_trigger_events
     bool triggers_device_stale = true;
-    DevBuf trig_slot, trig_entity, trig_he, trig_group, trig_mask, trig_active, trig_aabb, trig_pairs, trig_count;
+    DevBuf trig_slot, trig_entity, trig_he, trig_group, trig_mask, trig_active, trig_aabb, trig_pairs, trig_count, trig_lists;
+    uint32_t trigger_grid_min = 64;       // more ghosts than this: the broadphase grid answers for the small ones
+    uint32_t trig_through_grid = 0, trig_against_all = 0; // how the last tick split them
     bge::TriggerView trigger_view() const
     {
         bge::TriggerView t{};
@@ -279,7 +281,7 @@ struct bge_world {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
                           &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &trig_slot, &trig_entity, &trig_he, &trig_group,
-                          &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count}) {
+                          &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists}) {
             b->release();
         }
         broadphase.release();
@@ -443,9 +445,12 @@ void ensure_triggers(bge_world* w)
 // ProcessTriggerEvents on the pair list the device produced for this tick
 int process_trigger_pairs(bge_world* w)
 {
-    uint32_t n_pairs = 0;
-    HIP_TRY(hipMemcpyAsync(&n_pairs, w->trig_count.p, 4, hipMemcpyDeviceToHost, w->stream));
+    uint32_t counters[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(counters, w->trig_count.p, 12, hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    const uint32_t n_pairs = counters[0];
+    w->trig_against_all = counters[1];
+    w->trig_through_grid = counters[2];
     if (n_pairs > kTriggerPairCap) return fail(BGE_ERR_OOM, "%u trigger overlaps in one tick exceed the buffer of %u", n_pairs, kTriggerPairCap);
     std::vector<uint32_t> pairs(2 * static_cast<size_t>(n_pairs));
     if (n_pairs) {
@@ -522,6 +527,7 @@ try {
     bge_world* w = new (std::nothrow) bge_world();
     if (!w) return fail(BGE_ERR_OOM, "host allocation failed");
     w->device = device;
+    if (const char* e = std::getenv("BGE_TRIGGER_GRID_MIN")) w->trigger_grid_min = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
     DeviceGuard guard(device);
     if (desc && desc->stream) {
         w->stream = static_cast<hipStream_t>(desc->stream);
@@ -1193,11 +1199,26 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
             if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
             w->pairs_from_slab = false;
             if (with_triggers) {
-                HIP_TRY(hipMemsetAsync(w->trig_count.p, 0, 4, w->stream));
-                HIP_TRY(bge::launch_trigger_pairs(w->stream, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
-                                                  static_cast<uint32_t>(w->triggers.size()), w->trigger_view(), w->view,
-                                                  w->entity_of_slot.as<uint32_t>(), w->trig_count.as<uint32_t>(), w->trig_pairs.p,
-                                                  kTriggerPairCap));
+                // counters: [0] overlaps found, [1] ghosts left to the all-bodies pass, [2] ghosts walked through the grid
+                HIP_TRY(hipMemsetAsync(w->trig_count.p, 0, 12, w->stream));
+                const uint32_t n_trig = static_cast<uint32_t>(w->triggers.size());
+                const uint32_t* big_list = nullptr;
+                if (n_trig > w->trigger_grid_min) {
+                    // many ghosts: the ones that cover few cells look their bodies up in the broadphase's sorted grid
+                    // (n_bodies x n_triggers box tests otherwise: 4 M bodies x 1000 ghosts = 4 G tests a tick)
+                    HIP_TRY(w->trig_lists.ensure(static_cast<size_t>(n_trig) * 8));
+                    const bge::TriggerView tv = w->trigger_view();
+                    const bge::BoxQuery q{n_trig, tv.aabb, tv.group, tv.mask, tv.entity, w->trig_count.as<uint32_t>(),
+                                          w->trig_lists.as<uint32_t>(), w->trig_lists.as<uint32_t>() + n_trig,
+                                          static_cast<uint2*>(w->trig_pairs.p), kTriggerPairCap};
+                    rc = w->broadphase.query_boxes(w->stream, w->view, w->entity_of_slot.as<uint32_t>(), &palette, q);
+                    if (rc != BGE_OK) return fail(rc, "trigger query failed: %s", w->broadphase.error());
+                    big_list = w->trig_lists.as<uint32_t>();
+                }
+                HIP_TRY(bge::launch_trigger_pairs(w->stream, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile, n_trig,
+                                                  w->trigger_view(), w->view, w->entity_of_slot.as<uint32_t>(), w->trig_count.as<uint32_t>(),
+                                                  w->trig_pairs.p, kTriggerPairCap, big_list,
+                                                  big_list ? w->trig_count.as<uint32_t>() + 1 : nullptr));
                 if (int rc2 = process_trigger_pairs(w)) return rc2;
             }
         }
@@ -1863,6 +1884,15 @@ try {
     return BGE_OK;
 }
 BGE_CATCH_ALL("bge_world_trigger_active")
+
+int bge_world_trigger_query_stats(bge_world* w, uint32_t* through_grid, uint32_t* against_all_bodies)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "NULL world");
+    if (through_grid) *through_grid = w->trig_through_grid;
+    if (against_all_bodies) *against_all_bodies = w->trig_against_all;
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_trigger_query_stats")
 
 int bge_world_pack_roots(bge_world* w, void* dst_device)
 try {

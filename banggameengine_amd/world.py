@@ -247,6 +247,12 @@ class World:
         check(lib().bge_world_trigger_active(self._h, len(e), _p(e), _p(out)))
         return out.astype(bool)
 
+    def trigger_query_stats(self):
+        """(ghosts that walked the broadphase grid, ghosts tested against every body) in the last tick."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        check(lib().bge_world_trigger_query_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # -- multi-GPU support / device-resident consumers
     def pack_roots(self, dst_device_ptr: int | None = None):
         check(lib().bge_world_pack_roots(self._h, C.c_void_p(dst_device_ptr) if dst_device_ptr else None))

@@ -279,6 +279,10 @@ BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, ui
  *       stream (the events are for host code).
  *   bge_world_trigger_events returns (and clears) the events accumulated since the previous call.
  *   bge_world_trigger_active reports TriggerVolume::active per queried entity (0 after a one-shot fired, or no trigger).
+ *   With more than 64 triggers (BGE_TRIGGER_GRID_MIN overrides the number) step (b) changes: a ghost whose box covers at
+ *       most 8192 cells of the broadphase grid looks up the bodies sorted into those cells (plus the bodies too wide for the
+ *       grid) instead of being tested against every body; wider ghosts keep the all-bodies test.  The overlap sets are the
+ *       same either way.  bge_world_trigger_query_stats reports how the last tick split the ghosts that are in the world.
  */
 typedef struct bge_trigger_event {
     uint32_t type;    /* 0 Enter, 1 Stay, 2 Exit (PhysicsSystem::TriggerEvent::Type, src/physics/PhysicsSystem.h:50-62) */
@@ -290,6 +294,7 @@ BGE_API int bge_world_upload_triggers(bge_world* world, uint64_t count, const ui
                                       const uint8_t* one_shot, const uint8_t* active);
 BGE_API int bge_world_trigger_events(bge_world* world, bge_trigger_event* out, uint64_t cap, uint64_t* total);
 BGE_API int bge_world_trigger_active(bge_world* world, uint64_t count, const uint32_t* entity_index, uint8_t* active);
+BGE_API int bge_world_trigger_query_stats(bge_world* world, uint32_t* through_grid, uint32_t* against_all_bodies);
 
 /* Multi-GPU support: compact the world matrices of all roots (entity order) into one buffer that the
  * caller all-gathers across ranks (one collective per frame).  dst = NULL packs into the world's own

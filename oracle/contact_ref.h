@@ -30,8 +30,15 @@
 //     deltaImpulse = fnmadd(deltaVelDotn, jacDiagABInv, rhs - appliedImpulse·cfm), the limit selection by blendvps
 //     (lower < sum, sum < upper), velocity updates by fmadd(normal·invMass, deltaImpulse, deltaLinearVelocity) — ResolveRow
 //     below follows that instruction sequence (and with it the btSolverConstraint / btSolverBody field layout);
-//   * that the exe also holds the scalar split-impulse row (VA 0x1401c9380); Bullet installs the sse2 variant when USE_SIMD
-//     is defined (MSVC x64), whose dot products add x·x' + (y·y' + z·z') — followed here from the published source.
+//   * the split-impulse row Bullet installs when USE_SIMD is defined (MSVC x64), gResolveSplitPenetrationImpulse_sse2 at
+//     VA 0x1401c9790 (the one that bumps gNumSplitImpulseRecoveries and reads m_rhsPenetration at +0x98): mulps + shufps
+//     dot products summed (z·z' + y·y') + x·x', linear dot + angular dot, deltaImpulse = ((rhsPenetration − push·cfm) −
+//     dv1·jacDiagABInv) − dv2·jacDiagABInv, the lower-limit select by cmpltps/andps/andnps, velocity updates as separate
+//     mulps then addps ((normal·invMass)·deltaImpulse + pushVelocity; no FMA) — ResolveSplitPenetration below follows it
+//     (the exe's scalar variant at VA 0x1401c9380 is not the one installed);
+//   * contraction: a scan of the whole exe's disassembly finds exactly 12 fused multiply-adds (vfmadd / vfnmadd), all
+//     inside those two _sse4_1_fma3 row solvers, and no other VEX-encoded arithmetic — every other float operation of the
+//     engine, glm and Bullet in that build is an unfused SSE mul/add/sub/div, which is what -ffp-contract=off restates.
 // Everything else is from the published source with scalar left-to-right arithmetic; the compiled operation order of
 // setupContactConstraint, the manifold functions and computeGyroscopicImpulseImplicit_Body has NOT been checked.
 //
@@ -406,7 +413,7 @@ inline void ResolveRow(SolverBody& a, SolverRow& c, bool withUpperLimit)
     a.dAng = V(Fma(c.angularComp.x, deltaImpulse, a.dAng.x), Fma(c.angularComp.y, deltaImpulse, a.dAng.y), Fma(c.angularComp.z, deltaImpulse, a.dAng.z));
 }
 
-// gResolveSplitPenetrationImpulse_sse2 (published source; btSimdDot3 adds x + (y + z))
+// gResolveSplitPenetrationImpulse_sse2 (exe VA 0x1401c9790: each dot product is (z + y) + x, no FMA anywhere)
 inline void ResolveSplitPenetration(SolverBody& a, SolverRow& c)
 {
     if (!c.rhsPenetration) return;

@@ -44,7 +44,9 @@
 // fixedTimeStep = max(config.fixedStep, 1/240)), PhysicsSystem.cpp:855-863) is restated behind `accumulate`:
 //   m_localTime += timeStep;  if (m_localTime >= fixedTimeStep) { n = int(m_localTime / fixedTimeStep);
 //   m_localTime -= n * fixedTimeStep; }   min(n, maxSubSteps) x internalSingleStepSimulation(fixedTimeStep)
-// (published Bullet code, binary32; applyGravity before and clearForces after the sub-steps make no difference to a
+// (binary32; pinned against the compiled stepSimulation at VA 0x1401c31d0 of the reference's exe by
+// oracle/tools/check_solver_rows.py: truncating conversion, (float)n * fixedTimeStep unfused, the UNclamped n is returned;
+// applyGravity before and clearForces after the sub-steps make no difference to a
 // free body: the force is re-derived per sub-step here).  With n == 0 nothing is simulated, no collision detection runs —
 // the ghosts' pair caches keep last call's content, so ProcessTriggerEvents reports Stay for every remembered overlap —
 // while the re-pose rule before and the write-back + MarkDirty after the step still run.

@@ -510,9 +510,13 @@ def test_graph_replayed_ticks_match_oracle(name, n, monkeypatch):
         assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world after a second graph with another dt")
 
 
-def test_trigger_events_match_oracle_every_tick():
+@pytest.mark.parametrize("grid_min", [None, 0])
+def test_trigger_events_match_oracle_every_tick(grid_min, monkeypatch):
     """Enter / Stay / Exit events of trigger volumes (ProcessTriggerEvents), tick by tick, incl.
-    one-shot triggers, layer/mask filters, inactive triggers, a trigger riding on a moving Dynamic body, capsules."""
+    one-shot triggers, layer/mask filters, inactive triggers, a trigger riding on a moving Dynamic body, capsules.
+    grid_min = 0: the ghosts look their bodies up in the broadphase grid (what a scene with more than 64 of them does)."""
+    if grid_min is not None:
+        monkeypatch.setenv("BGE_TRIGGER_GRID_MIN", str(grid_min))
     n = 3000
     wl = synth.Workload("cube", synth.FLAT, n, 4242, pos_box=synth.CUBE)
     wl.pos = (wl.pos * np.float32(20.0 / 262.0)).astype(np.float32)
@@ -555,6 +559,60 @@ def test_trigger_events_match_oracle_every_tick():
             want_active = np.array([ref.TriggerIsActive(int(e) + 1) for e in trig_entities])
             assert np.array_equal(w.trigger_active(trig_entities), want_active), f"tick {tick}: one-shot state"
     assert seen_types == {0, 1, 2}                              # the scene really produced Enter, Stay and Exit
+
+
+def test_many_triggers_through_the_grid_match_oracle():
+    """with more than 64 trigger volumes the ghosts that cover few cells walk the broadphase's sorted
+    grid (Broadphase::query_boxes) and only the wide ones are tested against every body.  600 ghosts from 0.2 to 60 units
+    wide over 60 k bodies — a few of them so wide that the sort keeps them on its large list, Static and Kinematic bodies,
+    three layers — Enter / Stay / Exit equal the oracle's every tick, and both paths are really taken."""
+    n = 60000
+    wl = synth.Workload("cube", synth.FLAT, n, 99, pos_box=synth.CUBE)
+    wl.pos = (wl.pos * np.float32(60.0 / 262.0)).astype(np.float32)
+    rng = np.random.default_rng(5)
+    wl.body_type = rng.choice([0, 1, 1, 1, 2], n).astype(np.uint8)
+    wl.scale = np.ones((n, 3), np.float32)
+    wide = rng.choice(n, 6, replace=False)
+    wl.scale[wide] = rng.uniform(8.0, 30.0, (6, 3)).astype(np.float32)      # far wider than a cell: the sort's large list
+    layer = rng.choice([1, 2, 4], n).astype(np.uint32)
+    mask = rng.choice([0xFFFFFFFF, 0xFFFFFFFB, 3], n).astype(np.uint32)
+    n_trig = 600
+    trig_entities = rng.choice(n, n_trig, replace=False).astype(np.uint32)
+    t_shape = rng.choice([0, 0, 1], n_trig).astype(np.uint8)
+    t_size = np.exp(rng.uniform(np.log(0.2), np.log(8.0), (n_trig, 3))).astype(np.float32)
+    t_size[:8] = rng.uniform(30.0, 60.0, (8, 3)).astype(np.float32)         # ghosts that span most of the scene
+    t_layer = rng.choice([0, 4, 2], n_trig).astype(np.uint32)
+    t_mask = rng.choice([0xFFFFFFFF, 1, 6], n_trig).astype(np.uint32)
+    t_oneshot = (rng.random(n_trig) < 0.2).astype(np.uint8)
+    t_active = (rng.random(n_trig) < 0.95).astype(np.uint8)
+    ref = build_oracle(wl, aabbs=True, layer=layer, mask=mask)
+    for k in range(n_trig):
+        ref.AddTriggerVolume(int(trig_entities[k]) + 1, int(t_shape[k]), t_size[k], int(t_layer[k]), int(t_mask[k]),
+                             bool(t_oneshot[k]), bool(t_active[k]))
+    flags = B.TICK_ALL | B.TICK_BROADPHASE
+    seen_types, total = set(), 0
+    with B.World(pair_capacity=64 * n) as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, layer=layer, mask=mask)
+        w.upload_triggers(trig_entities, t_shape, t_size, t_layer, t_mask, t_oneshot, t_active)
+        for tick in range(14):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, flags=flags)
+            if tick == 0:
+                ref.bulk_set_velocity(wl.vel * np.float32(6.0))
+                w.set_velocities(wl.vel * np.float32(6.0))
+            want = ref.TriggerEvents()
+            want[:, 1:] -= 1
+            got = w.trigger_events()
+            assert np.array_equal(got, want), f"tick {tick}: {len(got)} vs {len(want)} events"
+            seen_types |= set(got[:, 0].tolist())
+            total += len(got)
+            through_grid, against_all = w.trigger_query_stats()
+            assert through_grid > 400 and against_all >= 4, (through_grid, against_all)   # (some of the 8 wide ones are inactive)
+            assert through_grid + against_all <= n_trig
+    assert seen_types == {0, 1, 2} and total > 5000
 
 
 @pytest.mark.parametrize("basis", [False, True])
