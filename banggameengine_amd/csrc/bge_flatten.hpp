@@ -39,9 +39,11 @@ constexpr uint32_t kLevelMask = 0xff00u;
 constexpr uint32_t kParentShift = 16;    // bits 16..23: in-tile index of the parent (when kHasParent && !kExtParent)
 constexpr uint32_t kParentMask = 0xff0000u;
 constexpr uint32_t kDrowsy = 1u << 24;   // the body's deactivation record is non-zero (timer running, wants to sleep, asleep)
-constexpr uint32_t kMassShift = 25;      // bits 25..31: mass class (index into the world's mass palette);
-constexpr uint32_t kMassMask = 0xfe000000u; //            127 = read the per-slot inv_mass array instead
-constexpr uint32_t kMassClassArray = 127;
+constexpr uint32_t kSettled = 1u << 25;  // (BGE_TICK_BULLET_BASIS) the stored quaternion is a fixed point of Bullet's orientation round trip at zero angular
+                                         // velocity and rotationEuler holds its angles: the step leaves both alone.  Cleared by whatever writes the quaternion.
+constexpr uint32_t kMassShift = 26;      // bits 26..31: mass class (index into the world's mass palette);
+constexpr uint32_t kMassMask = 0xfc000000u; //            63 = read the per-slot inv_mass array instead
+constexpr uint32_t kMassClassArray = 63;
 
 // Deactivation record (one 32-bit word per slot, read only while kDrowsy is set): the bits of btCollisionObject's
 // m_deactivationTime (a float >= 0) while the body is ACTIVE_TAG, or one of two negative-NaN sentinels.

@@ -148,19 +148,27 @@ template <bool PHYS, bool XFORM, bool AABB, bool NORMAL, bool BASIS>
 __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES : (BASIS ? BGE_BASIS_MIN_WAVES : (XFORM ? BGE_XFORM_MIN_WAVES : 8)))) k_tick(WorldView w, TickParams p)
 {
     __shared__ float4 lds[kTile * 4];
-    // BASIS: the euler write-back (getRotation -> setRotation -> getEulerZYX: two square roots, six divisions, asin, two atan2
-    // per body) is only needed by bodies whose quaternion changed in this step — 12 % of non-spinning bodies in steady state,
-    // scattered over all waves, so no wave could skip it.  Those lanes queue (lane, quaternion) here; after a barrier the first
-    // n threads of the workgroup compute the angles for the n queued bodies (usually one wave instead of four) and hand them back.
+    // BASIS: Bullet's orientation step (getRotation -> exponential map -> safeNormalize -> setRotation: four square roots, ten
+    // divisions) and the euler write-back behind it (asin, two atan2) change nothing for a body whose quaternion is a fixed
+    // point of that round trip and does not spin — 88 % of the bodies in steady state; those carry kSettled and skip both.
+    // The others are scattered over all waves, so no wave could skip the code: they queue (quaternion, angular velocity) here
+    // and, after a barrier, the first n threads of the workgroup do the step for the n queued bodies (usually one wave
+    // instead of four), writing the results over their queue entries, where the owners pick them up.
+    // The queue lives in the matrix staging area, which the transform stage only touches after the barrier that ends its use.
     __shared__ uint32_t eq_count;
-    __shared__ uint32_t eq_lane[(PHYS && BASIS) ? kTile : 1];
-    __shared__ float4 eq_quat[(PHYS && BASIS) ? kTile : 1];
-    __shared__ float4 eq_euler[(PHYS && BASIS) ? kTile : 1];
+    float4* const eq_quat = lds;        // [kTile] in: quaternion; out: the new one
+    float4* const eq_av = lds + kTile;  // [kTile] in: angular velocity | kEq* bits; out: euler angles | kEq* bits
     if (PHYS && BASIS) {
         if (threadIdx.x == 0) eq_count = 0;
         __syncthreads();
     }
-    bool euler_deferred = false;
+    constexpr uint32_t kEqNone = 0xffffffffu;
+    constexpr uint32_t kEqIntegrate = 1u;  // in: run the orientation step (else only the angles are wanted)
+    constexpr uint32_t kEqForce = 2u;      // in: the pose was set or corrected in this tick: the angles are rewritten whatever the step does
+    constexpr uint32_t kEqStoreQuat = 4u;  // out: the quaternion changed
+    constexpr uint32_t kEqStoreEuler = 8u; // out: the angles are new
+    constexpr uint32_t kEqSettled = 16u;   // out: the step left the quaternion of a non-spinning body as it was
+    uint32_t eq_at = kEqNone; // this lane's queue entry
 
     const uint32_t tile = p.tile_begin + blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -212,13 +220,15 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             // goes basis -> getRotation -> exponential map -> safeNormalize -> setRotation for EVERY non-static body, spinning
             // or not.  The basis is always setRotation(q) of a stored quaternion, so q stays the state here and the basis
             // is recomputed from it: same bits, 16 instead of 36 bytes.
-            const bool turn = BASIS ? dynamic : spin;
             bool advanced = false;
             // ground plane on: k_ground collided this body with the plane before this kernel ran and, if it is in contact (or
             // spinning), solved it — its velocities are final (gravity impulse included), its fed AABB is written
             uint32_t ci = 0;
             if (p.cinfo_in && dynamic) ci = p.cinfo_in[slot];
             const bool solved = (ci & kCiSolved) != 0;
+            // whatever writes the quaternion (re-pose, spin, the split impulse) takes kSettled away
+            if (repose || spin || (ci & kCiMoved)) f &= ~kSettled;
+            const bool turn = BASIS ? (dynamic && !(f & kSettled)) : spin;
             Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
             F3 v{0.0f, 0.0f, 0.0f};
             F3 av{0.0f, 0.0f, 0.0f};
@@ -280,7 +290,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
 
             if (dynamic) {
                 // mass class -> (gravity force, inv_mass) from the world's palette (a few distinct masses per scene,
-                // L1/L2-resident); class 127 falls back to the per-slot array.  The force is btRigidBody::setGravity's
+                // L1/L2-resident); class 63 falls back to the per-slot array.  The force is btRigidBody::setGravity's
                 // m_gravity = acceleration / m_inverseMass — a DIVISION per component in the reference's build
                 // (oracle/tools/check_bullet_order.py) — which the host evaluates once per class and gravity vector.
                 const uint32_t cls = f >> kMassShift;
@@ -320,7 +330,12 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     pos.x = pos.x + v.x * p.dt;
                     pos.y = pos.y + v.y * p.dt;
                     pos.z = pos.z + v.z * p.dt;
-                    if (turn) {
+                    if (turn && BASIS && !AABB) {
+                        // queued: the first threads of the workgroup run the step after the barrier below
+                        eq_at = atomicAdd(&eq_count, 1u);
+                        eq_quat[eq_at] = make_float4(q.x, q.y, q.z, q.w);
+                        eq_av[eq_at] = make_float4(av.x, av.y, av.z, __uint_as_float(kEqIntegrate | ((repose || (ci & kCiMoved)) ? kEqForce : 0u)));
+                    } else if (turn) {
                         const Q4 qn = bt_integrate_orientation(BASIS ? bt_quat_from_mat(bt_mat_from_quat(q)) : q, av, p.dt);
                         // BASIS: a quaternion the round trip maps onto itself (88 % of the non-spinning bodies in steady state)
                         // needs neither the store nor new angles — rotationEuler already holds getEulerZYX of exactly these bits
@@ -330,6 +345,8 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                         if (!same) {
                             st4(w.quat, slot, q);
                             advanced = true;
+                        } else if (!spin && !(ci & kCiMoved)) {
+                            f |= kSettled;
                         }
                     }
                     st3(w.vel, slot, v);
@@ -358,13 +375,12 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 }
                 // SyncRigidBodiesFromPhysics: rotationEuler <- getEulerZYX(basis) whenever the orientation was
                 // (re)posed or advanced; a non-spinning body keeps its euler triple bit for bit
-                if (repose || advanced || (ci & kCiMoved)) {
-                    if (!(repose || advanced)) q = ld4(w.quat, slot); // the split impulse moved a body that does not spin
+                if (eq_at == kEqNone && (repose || advanced || (ci & kCiMoved))) {
+                    if (!(repose || advanced) && !(turn || AABB)) q = ld4(w.quat, slot); // the split impulse moved a body whose quaternion was not read
                     if (BASIS) {
-                        const uint32_t at = atomicAdd(&eq_count, 1u);
-                        eq_lane[at] = tid;
-                        eq_quat[at] = make_float4(q.x, q.y, q.z, q.w);
-                        euler_deferred = true;
+                        eq_at = atomicAdd(&eq_count, 1u);
+                        eq_quat[eq_at] = make_float4(q.x, q.y, q.z, q.w);
+                        eq_av[eq_at] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEqForce));
                     } else {
                         eul = bt_transform_euler_from_mat(bt_mat_from_quat(q));
                         st3(w.euler, slot, eul);
@@ -380,17 +396,47 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
     if (PHYS && BASIS) {
         __syncthreads();
         const uint32_t n_queued = eq_count;
-        if (tid < n_queued) {
-            const float4 qq = eq_quat[tid];
-            const F3 e = bt_transform_euler_from_mat(bt_mat_from_quat(Q4{qq.x, qq.y, qq.z, qq.w}));
-            eq_euler[eq_lane[tid]] = make_float4(e.x, e.y, e.z, 0.0f);
+        // (rotating the wave that takes the first 64 entries with the workgroup index, so that not every resident workgroup's
+        //  wave 0 does this work, changed nothing: 32.1 against 31.8 us)
+        const uint32_t et = tid;
+#ifndef BGE_EXPERIMENT_BASIS /* timing-only A/B builds (results are wrong): 1 = no orientation step for the queued bodies, 2 = no euler angles either */
+#define BGE_EXPERIMENT_BASIS 0
+#endif
+        if (et < n_queued) {
+            const float4 qq = eq_quat[et], aa = eq_av[et];
+            const uint32_t in = __float_as_uint(aa.w);
+            Q4 q{qq.x, qq.y, qq.z, qq.w};
+            uint32_t out = (in & kEqForce) ? kEqStoreEuler : 0u;
+            if ((in & kEqIntegrate) && BGE_EXPERIMENT_BASIS == 0) {
+                const Q4 qn = bt_integrate_orientation(bt_quat_from_mat(bt_mat_from_quat(q)), F3{aa.x, aa.y, aa.z}, p.dt);
+                const bool same = !(in & kEqForce) && __float_as_uint(qn.x) == __float_as_uint(q.x) && __float_as_uint(qn.y) == __float_as_uint(q.y) &&
+                                  __float_as_uint(qn.z) == __float_as_uint(q.z) && __float_as_uint(qn.w) == __float_as_uint(q.w);
+                // (a re-posed or corrected body stores what the step made of its quaternion even when the bits did not move:
+                //  what the inline form of this step does, and the next tick finds it settled)
+                if (!same) out |= kEqStoreQuat | kEqStoreEuler;
+                else if (aa.x == 0.0f && aa.y == 0.0f && aa.z == 0.0f) out |= kEqSettled;
+                q = qn;
+            }
+            F3 e{0.0f, 0.0f, 0.0f};
+            if ((out & kEqStoreEuler) && BGE_EXPERIMENT_BASIS < 2) e = bt_transform_euler_from_mat(bt_mat_from_quat(q));
+            eq_quat[et] = make_float4(q.x, q.y, q.z, q.w);
+            eq_av[et] = make_float4(e.x, e.y, e.z, __uint_as_float(out));
         }
         __syncthreads();
-        if (euler_deferred) {
-            const float4 e = eq_euler[tid];
-            eul = F3{e.x, e.y, e.z};
-            st3(w.euler, slot, eul);
+        if (eq_at != kEqNone) {
+            const float4 e = eq_av[eq_at];
+            const uint32_t out = __float_as_uint(e.w);
+            if (out & kEqStoreQuat) {
+                const float4 qq = eq_quat[eq_at];
+                st4(w.quat, slot, Q4{qq.x, qq.y, qq.z, qq.w});
+            }
+            if (out & kEqStoreEuler) {
+                eul = F3{e.x, e.y, e.z};
+                st3(w.euler, slot, eul);
+            }
+            if (out & kEqSettled) f |= kSettled;
         }
+        if (XFORM) __syncthreads(); // the staging area is handed to the transform stage
     }
 
     if (AABB && PHYS) {
@@ -568,6 +614,7 @@ __global__ void __launch_bounds__(256) k_pose_only(WorldView w, uint64_t n_slots
     if (repose) {
         q = bt_quat_from_transform_euler(ld3(w.euler, slot));
         st4(w.quat, slot, q);
+        f &= ~kSettled;
         if (dynamic) {
             const F3 zero{0.0f, 0.0f, 0.0f};
             st3(w.vel, slot, zero);

@@ -24,7 +24,7 @@ struct WorldView {
     float* vel;               // [slots][3]
     float* angvel;            // [slots][3]
     float* quat;              // [slots][4]
-    float* inv_mass;          // [slots]     only read for mass class 127 (more than 126 distinct masses)
+    float* inv_mass;          // [slots]     only read for mass class 63 (more than 62 distinct masses)
     const float2* mass_palette; // [128]     (inv_mass, 1/inv_mass) per mass class (host bookkeeping; the kernel reads grav_palette)
     const float4* grav_palette; // [256]     (gravity / inv_mass, inv_mass) per mass class for the gravity vector of the tick
     uint32_t* deact;          // [slots]     deactivation record (bge_flatten.hpp), only touched while a body is slow or asleep

@@ -298,7 +298,7 @@ struct bge_world {
 namespace {
 
 // Mass class of an inverse mass: scenes use a handful of distinct masses, so the kernel reads (inv_mass, mass)
-// from a 128-entry palette instead of 4 B per body; the 127th distinct value onwards uses the per-slot array.
+// from a 64-entry palette instead of 4 B per body; the 63rd distinct value onwards uses the per-slot array.
 uint32_t mass_class(bge_world* w, float inv_mass, bool& palette_changed)
 {
     uint32_t bits;

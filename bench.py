@@ -41,10 +41,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# BGE_TICK_BULLET_BASIS: every Dynamic body also reads its quaternion (16 B).  The quaternion and rotationEuler are written back
-# (16 + 12 B) only for bodies whose quaternion changed in the step — Bullet rewrites all of them, with the same bits — so the
-# algorithmic minimum counts the read only (conservative for the roofline fraction: a spinning scene writes 28 B more per body)
-BASIS_EXTRA_BYTES = 16.0
+# BGE_TICK_BULLET_BASIS: Bullet reads and rewrites basis and rotationEuler of every Dynamic body each step, mostly with the bits
+# they already hold.  The kernel touches quaternion (16 B in, 16 B out) and rotationEuler (12 B out) only for the bodies the
+# step can change: 12 % of a scene of non-spinning bodies in steady state (limit cycles of the normalisation, DESIGN.md 4.2;
+# all of them in the first ticks after a re-pose, and every spinning body) — 0.12 x 44 B on top of the default scheme's bytes.
+BASIS_EXTRA_BYTES = 5.3
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 STUB = os.environ.get("BGE_BENCH_STUB") == "1"  # tests/test_bench_launcher.py only: control flow over gloo, no GPU work
 
@@ -571,7 +572,7 @@ def run_rank(args):
             kernel_name += " [bullet basis]"
         alg_bytes = bytes_per_update * per_gpu  # per step on one GPU
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = load_traffic(name, per_gpu)
+        traffic, traffic_source = load_traffic(name + "_basis" if args.bullet_basis else name, per_gpu)
         out = {
             "metric": "entity-updates/sec (transform+physics tick)",
             "value": 0.0 if STUB else value,

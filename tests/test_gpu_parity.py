@@ -210,7 +210,7 @@ def test_trig_edge_angles_match_oracle_bitwise():
 
 @pytest.mark.parametrize("distinct", [5, 3000])
 def test_mass_palette_and_per_slot_fallback(distinct):
-    """Masses ride an 8-bit class in the flag word (palette of (inv_mass, mass)); beyond 254 distinct values the
+    """Masses ride a 6-bit class in the flag word (palette of (inv_mass, mass)); beyond 62 distinct values the
     kernel falls back to the per-slot array.  Gravity goes through F = g*m, v += (F*inv_m)*dt, so mass matters."""
     n = 3000
     wl = synth.config("flat10k", n=n)
@@ -351,6 +351,65 @@ def test_bullet_basis_scheme_under_gravity_in_hierarchies(variant):
     iq = ideal.bulk_bodies()["quat"]
     assert (bits(bodies["quat"][still]) != bits(iq[still])).any()
     assert matrix_rel_err(world, ideal.bulk_world()[0]) < 1e-5
+
+
+@pytest.mark.parametrize("variant", ["fused", "split", "aabbs"])
+def test_bullet_basis_settled_bodies_are_unsettled_by_whatever_touches_them(variant):
+    """In Bullet's orientation scheme a body whose quaternion the round trip maps onto itself carries kSettled and skips the
+    step.  Everything that can make the step matter again must take the bit away: angular velocity switched on
+    and off from outside, an angular velocity too small to move the quaternion, teleports (new rotationEuler), a re-pose without
+    a change (MarkDirty), re-created bodies.  Quaternion, rotationEuler, position and world matrix equal the oracle's
+    kOrientBasis after EVERY tick of the script, in the queued form of the step (fused / split) and the inline one (with AABBs)."""
+    n = 4000
+    wl = synth.config("flat1m", n=n)
+    rng = np.random.default_rng(17)
+    wl.body_type = rng.choice([0, 1, 1, 1, 1, 2], n).astype(np.uint8)
+    ref = build_oracle(wl, orient_mode=po.ORIENT_BASIS, aabbs=variant == "aabbs")
+    ang_a = np.zeros((n, 3), np.float32)
+    sel = rng.random(n) < 0.3
+    ang_a[sel] = rng.normal(size=(int(sel.sum()), 3)).astype(np.float32)
+    ang_tiny = np.zeros((n, 3), np.float32)
+    sel2 = rng.random(n) < 0.3
+    ang_tiny[sel2] = (rng.normal(size=(int(sel2.sum()), 3)) * 1e-7).astype(np.float32)
+    zero = np.zeros((n, 3), np.float32)
+    tele_euler = rng.uniform(-180.0, 180.0, (500, 3)).astype(np.float32)
+    tele_pos = rng.uniform(-50.0, 50.0, (500, 3)).astype(np.float32)
+    script = {0: ("vel", ang_a), 8: ("vel", zero), 20: ("teleport", None), 30: ("vel", ang_tiny), 36: ("vel", zero),
+              44: ("dirty", None), 50: ("bodies", None)}
+    flags = (B.TICK_ALL | B.TICK_AABBS if variant == "aabbs" else B.TICK_ALL) | B.TICK_BULLET_BASIS
+    with B.World() as w:
+        w.load(wl)
+        for tick in range(60):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            if variant == "split":
+                w.tick(dt=DT, flags=B.TICK_PHYSICS | B.TICK_BULLET_BASIS)
+                w.tick(flags=B.TICK_TRANSFORMS)
+            else:
+                w.tick(dt=DT, flags=flags)
+            pos, euler = w.download_pose()
+            bodies = w.download_bodies()
+            rb = ref.bulk_bodies()
+            ex = rb["exists"]
+            assert_bits_equal(bodies["quat"][ex], rb["quat"][ex], f"tick {tick}: quaternion")
+            assert_bits_equal(euler, ref.bulk_pose()[1], f"tick {tick}: rotationEuler")
+            assert_bits_equal(pos, ref.bulk_pose()[0], f"tick {tick}: position")
+            assert_bits_equal(w.download_world(), ref.bulk_world()[0], f"tick {tick}: world")
+            what, arg = script.get(tick, (None, None))
+            if what == "vel":
+                ref.bulk_set_velocity(wl.vel, arg)
+                w.set_velocities(wl.vel, arg)
+            elif what == "teleport":
+                ref.bulk_set_trs(700, tele_pos, tele_euler, None)
+                w.upload_trs(tele_pos, tele_euler, None, first=700)
+            elif what == "dirty":
+                for e in range(1500, 2500):
+                    ref.MarkDirty(e + 1)
+                w.mark_dirty(1500, 1000)
+            elif what == "bodies":
+                for e in range(3000, 3400):
+                    ref.MarkBodyDirty(e + 1)
+                w.upload_bodies(wl.body_type[3000:3400], first=3000)
 
 
 def test_demo_scene_fixture():
