@@ -58,6 +58,7 @@ constexpr uint32_t kHdrExt = 1u << 17;      // some node has an external parent
 constexpr uint32_t kHdrWaveLocal = 1u << 18; // every in-tile parent sits in its child's 64-slot group: no workgroup barrier
 constexpr uint32_t kHdrAllDynamic = 1u << 19; // every valid slot of the tile carries a Dynamic body (set by bge_world_upload_bodies):
                                               // the tick kernel then loads the velocities without waiting for the flag words
+constexpr uint32_t kHdrFrozen = 1u << 20; // some root of the tile keeps its stored world matrix while it is clean (WorldView::frozen has the slots)
 constexpr uint32_t kGroup = 64;             // slots per wave64
 
 struct Flattened {

@@ -81,6 +81,23 @@ __device__ __forceinline__ void store_root(float* __restrict__ root_out, uint32_
     dst[2] = make_float4(m[10], m[12], m[13], m[14]);
 }
 
+// A frozen root (WorldView::frozen): its stored world matrix goes where the freshly built local matrix would have gone — a
+// row at a time, so that the rare path costs the kernel no registers.
+__device__ __forceinline__ void lds_put_stored(float4* lds, uint32_t n, const float* __restrict__ world, uint32_t slot)
+{
+    const float4* src = reinterpret_cast<const float4*>(world) + 4ull * slot;
+#pragma unroll 1
+    for (uint32_t r = 0; r < 4; ++r) lds[lds_row(n, r)] = src[r];
+}
+__device__ __forceinline__ void store_root_stored(float* __restrict__ root_out, uint32_t index, const float* __restrict__ world, uint32_t slot)
+{
+    const float* m = world + 16ull * slot;
+    float* dst = root_out + 12ull * index; // the packing of store_root
+    const int pick[12] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14};
+#pragma unroll 1
+    for (int k = 0; k < 12; ++k) dst[k] = m[pick[k]];
+}
+
 // Stores of results the tick never reads again (world / normal matrices).  Non-temporal when the host asks for it:
 // measured on MI355X, plain stores win while the tick's working set fits the 256 MiB Infinity Cache (1 M entities:
 // 22.6 us plain, 24.5 us nt) and nt stores win beyond it (4 M: 95.0 us plain, 89.5 us nt) — the 64 B/entity output
@@ -228,7 +245,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             const bool solved = (ci & kCiSolved) != 0;
             // whatever writes the quaternion (re-pose, spin, the split impulse) takes kSettled away
             if (repose || spin || (ci & kCiMoved)) f &= ~kSettled;
-            const bool turn = BASIS ? (dynamic && !(f & kSettled)) : spin;
+            bool turn = BASIS ? (dynamic && !(f & kSettled)) : spin;
             Q4 q{0.0f, 0.0f, 0.0f, 1.0f};
             F3 v{0.0f, 0.0f, 0.0f};
             F3 av{0.0f, 0.0f, 0.0f};
@@ -236,10 +253,11 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 // SyncKinematicBodiesToPhysics / EnsureRigidBody: pose from the LOCAL Transform, zero velocities
                 q = bt_quat_from_transform_euler(eul);
                 st4(w.quat, slot, q);
-                if (dynamic && spin) {
+                if (spin) { // (of whatever type the re-created body is: the record the download reads is the new body's)
                     st3(w.angvel, slot, av);
                     spin = false;
                     f &= ~kSpin;
+                    if (!BASIS) turn = false; // its angular velocity is zero now: the default scheme leaves the re-posed quaternion alone
                 }
             } else {
                 if (dynamic) v = (BGE_SPECULATIVE_LOADS && (hdr & kHdrAllDynamic)) ? vel_early : ld3(w.vel, slot);
@@ -466,6 +484,16 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
         bx_mtx_srt(local, scl, eul, pos);
         const uint32_t level = (f & kLevelMask) >> kLevelShift;
         float4* dst = reinterpret_cast<float4*>(w.world) + 4ull * kTile * tile;
+        bool keep_world = false;
+        // A root that became one because its parent entity lost its Transform: the reference does not recompute it until it is
+        // dirty (nothing marked it), so it keeps the stored parent * local matrix; the first dirty tick ends that.
+        if ((hdr & kHdrFrozen) && valid && level == 0 && !(f & kExtParent)) { // (the header bit is uniform and almost never set)
+            const uint32_t bit = 1u << (slot & 31u);
+            if (w.frozen[slot >> 5] & bit) {
+                if (f & kTDirty) atomicAnd(&w.frozen[slot >> 5], ~bit);
+                else keep_world = true;
+            }
+        }
 
         if (hdr & kHdrWaveLocal) {
             // Every parent sits in its child's own 64-slot group (one wave64): the level loop and the write-out
@@ -479,7 +507,11 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     lds_put(lds, tid, world);
                 } else {
                     lds_put(lds, tid, local); // root: world = local (Transform.cpp:32-35)
-                    if (p.root_out && !(f & kHasParent)) store_root(p.root_out, w.root_index[slot], local);
+                    if (keep_world) lds_put_stored(lds, tid, w.world, slot);
+                    if (p.root_out && !(f & kHasParent)) {
+                        if (keep_world) store_root_stored(p.root_out, w.root_index[slot], w.world, slot);
+                        else store_root(p.root_out, w.root_index[slot], local);
+                    }
                 }
             }
             if (max_level != 0) {
@@ -544,7 +576,11 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     lds_put(lds, tid, world);
                 } else {
                     lds_put(lds, tid, local);
-                    if (p.root_out && !(f & kHasParent)) store_root(p.root_out, w.root_index[slot], local);
+                    if (keep_world) lds_put_stored(lds, tid, w.world, slot);
+                    if (p.root_out && !(f & kHasParent)) {
+                        if (keep_world) store_root_stored(p.root_out, w.root_index[slot], w.world, slot);
+                        else store_root(p.root_out, w.root_index[slot], local);
+                    }
                 }
             }
             for (uint32_t d = 1; d <= max_level; ++d) {
@@ -615,13 +651,11 @@ __global__ void __launch_bounds__(256) k_pose_only(WorldView w, uint64_t n_slots
         q = bt_quat_from_transform_euler(ld3(w.euler, slot));
         st4(w.quat, slot, q);
         f &= ~kSettled;
-        if (dynamic) {
-            const F3 zero{0.0f, 0.0f, 0.0f};
-            st3(w.vel, slot, zero);
-            if (f & kSpin) {
-                st3(w.angvel, slot, zero);
-                f &= ~kSpin;
-            }
+        const F3 zero{0.0f, 0.0f, 0.0f};
+        if (dynamic) st3(w.vel, slot, zero);
+        if (f & kSpin) {
+            st3(w.angvel, slot, zero);
+            f &= ~kSpin;
         }
     }
     if (dynamic) {
@@ -685,8 +719,11 @@ __global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, co
     }
     w.filter_class[slot] = filter_class[i];
     uint32_t f = w.flags[slot];
-    f &= ~(kTypeMask | kBDirty | kSpin | kMassMask | kDrowsy); // a (re)created body is ACTIVE_TAG with its timer at zero
+    // a (re)created body is ACTIVE_TAG with its timer at zero.  kSpin stays: the body is re-created by the next physics tick
+    // (EnsureRigidBody), whose re-pose rule zeroes the angular velocity record and takes the bit away
+    f &= ~(kTypeMask | kBDirty | kMassMask | kDrowsy);
     f |= type_bits[i]; // body type, kBDirty and the mass class
+    if ((f & kTypeMask) == 0) f &= ~kSpin;
     w.flags[slot] = f;
     w.inv_mass[slot] = inv_mass[i];
     w.half_extent[3ull * slot + 0] = half_extent3[3 * i + 0];

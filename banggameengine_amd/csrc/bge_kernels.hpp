@@ -42,6 +42,9 @@ struct WorldView {
     uint32_t* cinfo;          // [slots]     kCi* bits below
     float* manifold;          // [slots][32] four contact points x (localA.xyz, appliedImpulse, localB.x, distance, localB.z, appliedImpulseLateral1);
                               //             allocated when the ground plane is switched on
+    uint32_t* frozen;         // [slots / 32] bit per slot, or null: a root whose parent entity lost its Transform keeps the world matrix it had
+                              //             (parent * local) until something marks it dirty — TransformSystem::Update recomputes a node only when
+                              //             it or an ancestor is dirty, and Scene::RemoveTransform marks nobody (tiles with kHdrFrozen look here)
 };
 
 // per-slot contact word (the flag word has no bit left)

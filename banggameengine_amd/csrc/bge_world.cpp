@@ -134,7 +134,9 @@ struct bge_world {
     uint64_t pair_capacity_req = 0;
 
     bge::Flattened flat;
-    std::vector<uint32_t> parent_entity; // effective topology input of the last set_topology
+    std::vector<uint32_t> parent_entity; // entity-level parents (Scene::m_parents) as of the last set_topology
+    DevBuf frozen;                       // WorldView::frozen (allocated with the first frozen root)
+    bool any_frozen = false;
     std::vector<uint8_t> body_type_host; // bge_body_type per entity index as last uploaded (BGE_BODY_NONE = no body)
     bool has_topology = false;
     bool maybe_dirty = true;
@@ -275,12 +277,13 @@ struct bge_world {
         view.cfriction = cfriction.as<float>();
         view.cinfo = cinfo.as<uint32_t>();
         view.manifold = manifold.as<float>();
+        view.frozen = frozen.as<uint32_t>();
     }
     void release_all()
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &frozen, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists}) {
             b->release();
         }
@@ -593,40 +596,52 @@ try {
         HIP_TRY(bge::launch_gather_rows(w->stream, w->slot_of_entity.as<uint32_t>(), 0, n_keep, 1, w->flags.p, old_flags_tmp.p));
         HIP_TRY(hipStreamSynchronize(w->stream));
     }
-
-    // ---- which surviving transforms changed parent (Scene::SetParent marks the subtree dirty, Scene.cpp:392)
-    std::vector<uint8_t> keep_mask(n_keep, 0); // 1 = carried over, 2 = carried over but hierarchy-dirty
-    if (n_keep) {
-        std::vector<uint32_t> eff_new(n, bge::kNone);
-        for (uint64_t i = 0; i < n; ++i) {
-            const bool tf = !has_transform || has_transform[i];
-            const uint32_t p = parent ? parent[i] : bge::kNone;
-            if (tf && p != bge::kNone && p < n && (!has_transform || has_transform[p])) eff_new[i] = p;
+    std::vector<uint32_t> old_flags(n_keep);
+    if (n_keep) HIP_TRY(hipMemcpy(old_flags.data(), old_flags_tmp.p, n_keep * 4, hipMemcpyDeviceToHost));
+    // roots that still keep their stored world matrix (the kernel clears a bit when its root turns dirty), per entity
+    std::vector<uint8_t> was_frozen(n_keep, 0);
+    if (n_keep && w->any_frozen) {
+        std::vector<uint32_t> bits((w->flat.n_slots + 31) / 32);
+        HIP_TRY(hipMemcpy(bits.data(), w->frozen.p, bits.size() * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n_keep; ++i) {
+            const uint32_t s = w->flat.slot_of_entity[i];
+            if (s != bge::kNone && ((bits[s >> 5] >> (s & 31u)) & 1u)) was_frozen[i] = 1;
         }
-        std::vector<uint32_t> order; // BFS over the new forest so that dirtiness flows parent -> child
+    }
+
+    // ---- which surviving transforms became dirty through the hierarchy.  Scene::SetParent (Scene.cpp:354-393) works on
+    // ENTITIES: a changed parent — whether or not either parent owns a Transform — ends in MarkHierarchyDirty(child), which walks
+    // the children lists (through Transform-less entities too) and marks every Transform on the way (Scene.cpp:535-550).  A
+    // Transform that merely gained or lost an effective parent because that parent's Transform came or went is NOT marked.
+    std::vector<uint8_t> keep_mask(n_keep, 0); // 1 = carried over, 2 = carried over but hierarchy-dirty
+    std::vector<uint32_t> raw_new(n, bge::kNone);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t p = parent ? parent[i] : bge::kNone;
+        if (p != bge::kNone && p < n) raw_new[i] = p; // (SetParent ignores a parent that is not alive)
+    }
+    if (n_keep) {
+        std::vector<uint32_t> order; // BFS over the new entity forest so that dirtiness flows parent -> child
         order.reserve(n);
         std::vector<uint32_t> child_begin(n + 1, 0), child_list;
         for (uint64_t i = 0; i < n; ++i) {
-            if (eff_new[i] != bge::kNone) child_begin[eff_new[i] + 1]++;
+            if (raw_new[i] != bge::kNone) child_begin[raw_new[i] + 1]++;
         }
         for (uint64_t i = 0; i < n; ++i) child_begin[i + 1] += child_begin[i];
         child_list.resize(child_begin[n]);
         {
             std::vector<uint32_t> cur(child_begin.begin(), child_begin.end() - 1);
             for (uint64_t i = 0; i < n; ++i) {
-                if (eff_new[i] != bge::kNone) child_list[cur[eff_new[i]]++] = static_cast<uint32_t>(i);
+                if (raw_new[i] != bge::kNone) child_list[cur[raw_new[i]]++] = static_cast<uint32_t>(i);
             }
         }
         std::vector<uint8_t> hdirty(n, 0);
         for (uint64_t i = 0; i < n; ++i) {
-            if (nf.slot_of_entity[i] != bge::kNone && eff_new[i] == bge::kNone) order.push_back(static_cast<uint32_t>(i));
+            if (raw_new[i] == bge::kNone) order.push_back(static_cast<uint32_t>(i));
         }
-        for (size_t h = 0; h < order.size(); ++h) {
+        for (size_t h = 0; h < order.size(); ++h) { // (entities inside a parent cycle are never reached: nothing marks them)
             const uint32_t u = order[h];
-            const bool survived = u < n_keep && w->flat.slot_of_entity[u] != bge::kNone;
-            const uint32_t old_parent = (u < w->parent_entity.size()) ? w->parent_entity[u] : bge::kNone;
-            bool d = !survived || old_parent != eff_new[u];
-            if (eff_new[u] != bge::kNone && hdirty[eff_new[u]]) d = true;
+            bool d = u >= w->parent_entity.size() || w->parent_entity[u] != raw_new[u];
+            if (raw_new[u] != bge::kNone && hdirty[raw_new[u]]) d = true;
             hdirty[u] = d ? 1 : 0;
             for (uint32_t c = child_begin[u]; c < child_begin[u + 1]; ++c) order.push_back(child_list[c]);
         }
@@ -634,15 +649,26 @@ try {
             if (nf.slot_of_entity[i] == bge::kNone || w->flat.slot_of_entity[i] == bge::kNone) continue;
             keep_mask[i] = hdirty[i] ? 2 : 1;
         }
-        w->parent_entity.swap(eff_new);
-    } else {
-        w->parent_entity.assign(n, bge::kNone);
-        for (uint64_t i = 0; i < n; ++i) {
-            const bool tf = !has_transform || has_transform[i];
-            const uint32_t p = parent ? parent[i] : bge::kNone;
-            if (tf && p != bge::kNone && p < n && (!has_transform || has_transform[p])) w->parent_entity[i] = p;
-        }
     }
+    // A clean Transform whose parent ENTITY stays but no longer owns a Transform becomes a root without being marked dirty:
+    // TransformSystem::Update will not recompute it (UpdateNode recomputes a node only when it or an ancestor is dirty,
+    // TransformSystem.cpp:18-40), so its world matrix stays parent * local until something dirties it.  Such roots — and the
+    // ones that were already in that state and still have no Transform above them — are listed for the kernel.
+    std::vector<uint32_t> frozen_bits;
+    bool any_frozen = false;
+    for (uint64_t i = 0; i < n_keep; ++i) {
+        if (keep_mask[i] != 1 || (old_flags[i] & bge::kTDirty)) continue;
+        const uint32_t p = raw_new[i];
+        if (p == bge::kNone || nf.slot_of_entity[p] != bge::kNone) continue; // no parent entity, or it owns a Transform (again)
+        const bool parent_had_transform = p < w->flat.n_entities && w->flat.slot_of_entity[p] != bge::kNone;
+        if (!parent_had_transform && !was_frozen[i]) continue;
+        if (frozen_bits.empty()) frozen_bits.assign((std::max<uint64_t>(nf.n_slots, bge::kTile) + 31) / 32, 0u);
+        const uint32_t sl = nf.slot_of_entity[i];
+        frozen_bits[sl >> 5] |= 1u << (sl & 31u);
+        nf.tile_hdr[sl / bge::kTile] |= bge::kHdrFrozen;
+        any_frozen = true;
+    }
+    w->parent_entity.swap(raw_new);
 
     // ---- (re)allocate for the new layout
     const uint64_t S = std::max<uint64_t>(nf.n_slots, bge::kTile);
@@ -717,8 +743,6 @@ try {
             HIP_TRY(bge::launch_scatter_rows(w->stream, map_dev.as<uint32_t>(), 0, n_keep, c.width, c.tmp.p, c.buf->p, nullptr, 0));
         }
         // flags: keep body type / dirty / spin / shape bits of the old word, structure from the new one
-        std::vector<uint32_t> old_flags(n_keep);
-        HIP_TRY(hipMemcpy(old_flags.data(), old_flags_tmp.p, n_keep * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> merged(nf.flags);
         const uint32_t keep_bits = bge::kTypeMask | bge::kTDirty | bge::kBDirty | bge::kSpin | bge::kMassMask | bge::kDrowsy;
         for (uint64_t s = 0; s < nf.n_slots; ++s) {
@@ -738,6 +762,12 @@ try {
         map_dev.release();
     }
 
+    if (any_frozen) {
+        HIP_TRY(w->frozen.ensure(frozen_bits.size() * 4));
+        HIP_TRY(hipMemcpy(w->frozen.p, frozen_bits.data(), frozen_bits.size() * 4, hipMemcpyHostToDevice));
+        w->rebuild_view();
+    }
+    w->any_frozen = any_frozen;
     w->flat = std::move(nf);
     w->body_type_host.resize(n, BGE_BODY_NONE); // surviving indices keep their body, new ones have none
     for (uint64_t i = 0; i < n; ++i) {

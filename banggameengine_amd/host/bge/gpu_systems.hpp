@@ -369,9 +369,8 @@ private:
             fresh_.push_back(i);
         }
         for (auto& kv : transforms) parent_[index_of_[kv.first]] = ParentIndex(scene, kv.first);
-        for (size_t i = 0; i < ids_.size(); ++i) {
-            if (!has_tf_[i]) parent_[i] = BGE_NO_PARENT;
-        }
+        // (an index whose entity lost its Transform keeps the parent it had: to the device that entity's place in the
+        //  hierarchy has not changed, so nothing below it is taken for re-parented)
         live_ = transforms.size();
         if (bge_world_set_topology(world_, ids_.size(), parent_.data(), has_tf_.data()) != BGE_OK) return Log("bge_world_set_topology");
         // a reused index must not inherit the previous owner's device state: force a full upload
@@ -385,7 +384,15 @@ private:
     uint32_t ParentIndex(SceneT& scene, Id id)
     {
         const Id p = scene.GetParent(id);
-        if (p == 0 || !scene.HasTransform(p)) return BGE_NO_PARENT; // Scene.cpp:528
+        if (p == 0) return BGE_NO_PARENT;
+        if (!scene.HasTransform(p)) {
+            // The child is a root (Scene.cpp:528).  If the parent entity owned a Transform before, the device is told the SAME
+            // parent index (has_transform = 0 there) for as long as nobody else has taken it: bge_world_set_topology then sees
+            // an unchanged parent entity that lost its Transform — it neither marks the child dirty nor recomputes its world
+            // matrix, as the reference does not (Scene::RemoveTransform marks nobody) — instead of a changed parent.
+            auto r = retired_.find(p);
+            return (r != retired_.end() && is_free_[r->second]) ? r->second : BGE_NO_PARENT;
+        }
         auto it = index_of_.find(p);
         return it == index_of_.end() ? 0xfffffffeu /* not indexed yet: forces a refresh */ : it->second;
     }

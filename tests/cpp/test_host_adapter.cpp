@@ -246,6 +246,38 @@ int main(int argc, char** argv)
     for (auto& kv : w.gpu.GetRigidBodies()) { if (kv.first % 7 == 0) kv.second.dirty = true; }
     for (int k = 0; k < 3; ++k) w.Tick();
 
+    // Transforms removed from live parents, and given back.  Scene::RemoveTransform marks nobody: the children become roots
+    // (Scene.cpp:528) but TransformSystem::Update recomputes a node only when it or an ancestor is dirty, so a clean child keeps
+    // its parent * local world matrix, and a child with a body is NOT re-posed.  (The RigidBody goes first: the reference keeps
+    // stepping the Bullet body of an entity that lost only its Transform, this library drops it — DESIGN.md 7.)
+    {
+        std::vector<uint32_t> parents;
+        for (auto& kv : w.ref.GetTransforms()) {
+            if (parents.size() < 24 && kv.first % 5 == 1 && !w.ref.GetChildren(kv.first).empty() && !w.ref.GetTriggerVolume(kv.first)) parents.push_back(kv.first);
+        }
+        CHECK(parents.size() >= 12, "only %zu parents found for the RemoveTransform phase", parents.size());
+        size_t clean_children = 0;
+        for (uint32_t id : parents) {
+            for (uint32_t c : w.ref.GetChildren(id)) {
+                const auto* t = w.ref.GetTransform(c);
+                clean_children += t && !t->dirty;
+            }
+            w.ref.RemoveRigidBody(id); w.gpu.RemoveRigidBody(id);
+            w.ref.RemoveTransform(id); w.gpu.RemoveTransform(id);
+        }
+        CHECK(clean_children > 0, "no clean child under the parents that lose their Transform");
+        for (int k = 0; k < 3; ++k) w.Tick();
+        for (size_t k = 0; k < parents.size(); k += 2) {   // half of them come back, somewhere else
+            float p[3], e[3], s[3];
+            orc::synth::trs(0xABCD, static_cast<uint32_t>(k), 0, p, e, s);
+            orc::RefTransform* rt = w.ref.AddTransform(parents[k]);
+            bge::Transform* gt = w.gpu.AddTransform(parents[k]);
+            Put(&rt->position, p); Put(&rt->rotationEuler, e); Put(&rt->scale, s);
+            Put(&gt->position, p); Put(&gt->rotationEuler, e); Put(&gt->scale, s);
+        }
+        for (int k = 0; k < 3; ++k) w.Tick();
+    }
+
     CHECK(w.events_seen > 0, "the scripted scene produced no trigger events");
     // resident mode: nothing is copied back by Update, FetchWorld brings exactly what is asked for
     {

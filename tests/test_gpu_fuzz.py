@@ -1,0 +1,245 @@
+"""Randomised scenes through the C ABI against the oracle, every tick (GPU).
+
+Each seed draws a forest, bodies (types, shapes, sizes, masses, layers / masks, friction), trigger volumes and a feature set —
+ground plane, Bullet's orientation scheme, broadphase, Bullet's sub-step clock — and then a script of edits between ticks:
+teleports, velocity sets (linear and angular), re-created bodies, bodies whose type / shape / size / mass / filter change or
+that are removed, MarkDirty, re-parenting, trigger volumes added and removed.  Some entities have no Transform (their
+children are roots).  After EVERY tick the complete
+observable state must equal the oracle's bit for bit: Transforms, dirty flags, world matrices, body state, activation,
+contact counts, pair set, trigger events.  The directed tests cover each feature alone; this one covers their combinations.
+"""
+import numpy as np
+import pytest
+
+import banggameengine_amd as B
+from banggameengine_amd import synth
+from helpers import DT, assert_bits_equal, build_oracle
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _forest(rng, n):
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    p_child = rng.choice([0.0, 0.5, 0.8, 0.95])
+    window = int(rng.choice([3, 40, 400]))
+    for i in range(1, n):
+        if rng.random() < p_child:
+            parent[i] = rng.integers(max(0, i - window), i)
+    return parent
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(300, 3000))
+    ground = bool(seed & 1)
+    basis = bool(seed & 2)
+    broadphase = bool(seed & 4) or seed % 12 >= 8
+    clock = seed % 12 in (3, 6, 9, 11)       # Bullet's stepSimulation accumulator with varying dt
+    wl = synth.Workload("fuzz", synth.FLAT, n, 500 + seed)
+    wl.parent = _forest(rng, n)
+    side = float(rng.choice([6.0, 20.0, 60.0]))
+    wl.pos = rng.uniform(-side, side, (n, 3)).astype(np.float32)
+    if ground:
+        wl.pos[:, 1] = rng.uniform(0.1, 3.0, n).astype(np.float32)
+    wl.euler = rng.uniform(-180.0, 180.0, (n, 3)).astype(np.float32)
+    wl.euler[rng.random(n) < 0.2] = 0.0
+    wl.scale = np.ones((n, 3), np.float32)
+    odd = rng.random(n) < 0.2
+    wl.scale[odd] = rng.uniform(0.3, 3.0, (int(odd.sum()), 3)).astype(np.float32)
+    wl.body_type = rng.choice([255, 255, 0, 1, 1, 1, 2], n).astype(np.uint8)
+    n_bare = int(rng.integers(0, 12))        # the first entities have no Transform: whoever hangs under them is a root
+    has_transform = np.ones(n, np.uint8)
+    has_transform[:n_bare] = 0
+    wl.body_type[:n_bare] = 255
+    shape = rng.choice([0, 0, 1], n).astype(np.uint8)
+    size = rng.uniform(0.1, 1.2, (n, 3)).astype(np.float32)
+    if seed % 3 == 0:
+        mass = rng.uniform(0.05, 30.0, n).astype(np.float32)          # more distinct masses than the palette holds
+    else:
+        mass = rng.choice([0.25, 1.0, 1.0, 3.0, 50.0], n).astype(np.float32)
+    layer = rng.choice([1, 1, 2, 4, 8], n).astype(np.uint32)
+    mask = rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFD, 0xFFFFFFFB, 3], n).astype(np.uint32)
+    friction = rng.choice([0.5, 0.5, 0.1, 1.0], n).astype(np.float32)
+    body_kw = dict(mass=mass, shape=shape, size=size, layer=layer, mask=mask)
+
+    ref = build_oracle(wl, orient_mode=po.ORIENT_BASIS if basis else po.ORIENT_IDEAL, aabbs=broadphase, has_transform=has_transform, **body_kw)
+    n_trig = int(rng.integers(0, 9)) if broadphase else 0
+    trig = None
+    if n_trig:
+        te = (n_bare + rng.choice(n - n_bare, n_trig, replace=False)).astype(np.uint32)
+        trig = (te, rng.choice([0, 1], n_trig).astype(np.uint8), rng.uniform(0.5, side / 2, (n_trig, 3)).astype(np.float32),
+                rng.choice([0, 4, 2], n_trig).astype(np.uint32), rng.choice([0xFFFFFFFF, 1, 6], n_trig).astype(np.uint32),
+                (rng.random(n_trig) < 0.3).astype(np.uint8), (rng.random(n_trig) < 0.9).astype(np.uint8))
+        for k in range(n_trig):
+            ref.AddTriggerVolume(int(te[k]) + 1, int(trig[1][k]), trig[2][k], int(trig[3][k]), int(trig[4][k]), bool(trig[5][k]), bool(trig[6][k]))
+    if ground:
+        for i in range(n):
+            ref.SetFriction(i + 1, float(friction[i]))
+        ref.SetGroundPlane(True)
+    if clock:
+        ref.SetAccumulator(True, DT, 4)
+    flags = B.TICK_ALL | (B.TICK_BULLET_BASIS if basis else 0) | (B.TICK_BROADPHASE if broadphase else 0)
+    vel = (rng.normal(size=(n, 3)) * 3.0).astype(np.float32)
+
+    with B.World(pair_capacity=max(64 * n, 4096)) as w:
+        w.set_topology(wl.parent, has_transform)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, **body_kw)
+        if trig:
+            w.upload_triggers(*trig)
+        if ground:
+            w.upload_friction(friction)
+            w.set_ground_plane(True)
+        parent = wl.parent.copy()
+        for tick in range(40):
+            # ---- an edit between ticks, mirrored on both sides
+            what = rng.choice(["none", "none", "teleport", "velocity", "spin", "recreate", "change", "dirty", "reparent", "triggers", "transform"])
+            if what == "teleport":
+                first, cnt = int(rng.integers(n_bare, n - 20)), int(rng.integers(1, 20))
+                p = rng.uniform(-side, side, (cnt, 3)).astype(np.float32)
+                if ground:
+                    p[:, 1] = np.abs(p[:, 1]) * np.float32(0.1) + np.float32(0.2)
+                e = rng.uniform(-180.0, 180.0, (cnt, 3)).astype(np.float32)
+                ref.bulk_set_trs(first, p, e, None)
+                w.upload_trs(p, e, None, first=first)
+            elif what in ("velocity", "spin"):
+                ang = np.zeros((n, 3), np.float32)      # (the oracle's bulk call zeroes what it is not given)
+                if what == "spin":
+                    sel = rng.random(n) < 0.3
+                    ang[sel] = rng.normal(size=(int(sel.sum()), 3)).astype(np.float32)
+                lin = vel * np.float32(rng.uniform(0.2, 2.0))
+                ref.bulk_set_velocity(lin, ang)
+                w.set_velocities(lin, ang)
+            elif what == "recreate":
+                first, cnt = int(rng.integers(n_bare, n - 30)), int(rng.integers(1, 30))
+                for e in range(first, first + cnt):
+                    ref.MarkBodyDirty(e + 1)
+                w.upload_bodies(wl.body_type[first:first + cnt], first=first, **{k: v[first:first + cnt] for k, v in body_kw.items()})
+            elif what == "change":
+                # other components on the same entities: type (incl. none: the body is removed), collider, mass, filter
+                first, cnt = int(rng.integers(n_bare, n - 30)), int(rng.integers(1, 30))
+                sl = slice(first, first + cnt)
+                wl.body_type[sl] = rng.choice([255, 0, 1, 1, 2], cnt).astype(np.uint8)
+                shape[sl] = rng.choice([0, 1], cnt).astype(np.uint8)
+                size[sl] = rng.uniform(0.1, 1.2, (cnt, 3)).astype(np.float32)
+                mass[sl] = rng.choice([0.5, 2.0, 7.0], cnt).astype(np.float32)
+                layer[sl] = rng.choice([1, 2, 4], cnt).astype(np.uint32)
+                mask[sl] = rng.choice([0xFFFFFFFF, 0xFFFFFFFD, 5], cnt).astype(np.uint32)
+                for e in range(first, first + cnt):
+                    if wl.body_type[e] == 255:
+                        ref.RemoveRigidBody(e + 1)
+                    else:
+                        ref.AddCollider(e + 1, int(shape[e]), size[e])
+                        ref.AddRigidBody(e + 1, int(wl.body_type[e]), float(mass[e]), int(layer[e]), int(mask[e]))
+                        if ground:
+                            ref.SetFriction(e + 1, float(friction[e]))
+                w.upload_bodies(wl.body_type[sl], first=first, **{k: v[sl] for k, v in body_kw.items()})
+                if ground:
+                    w.upload_friction(friction[sl], first=first)
+            elif what == "triggers" and trig:
+                # one trigger volume goes, another entity gets one
+                te = trig[0]
+                gone = int(rng.integers(0, len(te)))
+                ref.RemoveTriggerVolume(int(te[gone]) + 1)
+                fresh = int(rng.integers(n_bare, n))
+                while fresh in te:
+                    fresh = int(rng.integers(n_bare, n))
+                new_size = rng.uniform(0.5, side / 2, 3).astype(np.float32)
+                ref.AddTriggerVolume(fresh + 1, 0, new_size, 0, 0xFFFFFFFF, False, True)
+                keep = [k for k in range(len(te)) if k != gone]
+                still_active = w.trigger_active(te[keep]).astype(np.uint8)   # TriggerVolume::active as the system left it (one-shots that fired)
+                trig = (np.append(te[keep], np.uint32(fresh)).astype(np.uint32), np.append(trig[1][keep], np.uint8(0)).astype(np.uint8),
+                        np.vstack([trig[2][keep], new_size[None, :]]).astype(np.float32), np.append(trig[3][keep], np.uint32(0)).astype(np.uint32),
+                        np.append(trig[4][keep], np.uint32(0xFFFFFFFF)).astype(np.uint32), np.append(trig[5][keep], np.uint8(0)).astype(np.uint8),
+                        np.append(still_active, np.uint8(1)).astype(np.uint8))
+                w.upload_triggers(*trig)
+            elif what == "transform":
+                # Transforms come and go (RemoveTransform / AddTransform): children of an entity that loses its Transform become
+                # roots WITHOUT being marked dirty, a new Transform starts from what is uploaded, and — as the adapter does for
+                # a fresh index — the entity's body components are uploaded again
+                for _ in range(int(rng.integers(1, 4))):
+                    e = int(rng.integers(0, n))
+                    if trig is not None and e in trig[0]:
+                        continue
+                    if has_transform[e]:
+                        # (the RigidBody goes first: the reference keeps stepping the Bullet body of an entity that lost only its
+                        #  Transform — EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393 — where this
+                        #  library drops the body with the Transform; DESIGN.md 7, a documented difference)
+                        ref.RemoveRigidBody(e + 1)
+                        wl.body_type[e] = 255
+                        ref.RemoveTransform(e + 1)
+                        has_transform[e] = 0
+                        w.set_topology(parent, has_transform)
+                    else:
+                        p3 = rng.uniform(-side, side, (1, 3)).astype(np.float32)
+                        if ground:
+                            p3[:, 1] = np.float32(0.5)
+                        e3 = rng.uniform(-180.0, 180.0, (1, 3)).astype(np.float32)
+                        s3 = np.ones((1, 3), np.float32)
+                        ref.AddTransform(e + 1, p3[0], e3[0], s3[0])
+                        has_transform[e] = 1
+                        w.set_topology(parent, has_transform)
+                        w.upload_trs(p3, e3, s3, first=e)
+                        if wl.body_type[e] != 255 and e >= n_bare:
+                            w.upload_bodies(wl.body_type[e:e + 1], first=e, **{k: v[e:e + 1] for k, v in body_kw.items()})
+                            if ground:
+                                w.upload_friction(friction[e:e + 1], first=e)
+            elif what == "dirty":
+                first, cnt = int(rng.integers(n_bare, n - 50)), int(rng.integers(1, 50))
+                for e in range(first, first + cnt):
+                    ref.MarkDirty(e + 1)
+                w.mark_dirty(first, cnt)
+            elif what == "reparent":
+                for _ in range(int(rng.integers(1, 6))):
+                    c = int(rng.integers(1, n))
+                    p = int(rng.integers(0, c)) if rng.random() < 0.8 else None     # (a parent below the child: no cycles)
+                    parent[c] = 0xFFFFFFFF if p is None else p
+                    ref.SetParent(c + 1, 0 if p is None else p + 1)
+                w.set_topology(parent, has_transform)
+
+            # ---- the tick
+            if clock:
+                dt = float(np.float64(rng.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.5, 5.5])) * np.float64(DT))
+                ref.PhysicsSystemUpdate(dt)
+                got_n = w.step_simulation(dt, 4, DT, flags=flags)
+                assert got_n == ref.LastSubSteps(), f"tick {tick}: {got_n} sub-steps, oracle {ref.LastSubSteps()}"
+            else:
+                ref.PhysicsSystemUpdate(DT)
+                w.tick(dt=DT, flags=flags)
+                got_n = 1
+            ref.TransformSystemUpdate()
+
+            # ---- everything observable
+            tag = f"seed {seed} tick {tick} (after {what})"
+            pos, euler = w.download_pose()
+            rpos, reuler = ref.bulk_pose()
+            assert_bits_equal(pos, rpos, f"{tag}: position")
+            assert_bits_equal(euler, reuler, f"{tag}: rotationEuler")
+            want_world, want_dirty = ref.bulk_world()
+            assert_bits_equal(w.download_world(), want_world, f"{tag}: world")
+            assert np.array_equal(w.download_dirty(), want_dirty.astype(bool)), f"{tag}: dirty flags"
+            assert w.dirty_count() == ref.CountDirtyTransforms(), f"{tag}: CountDirtyTransforms"
+            rb, gb = ref.bulk_bodies(), w.download_bodies()
+            ex = rb["exists"]
+            dyn = ex & (wl.body_type == 1)      # (the oracle's bulk velocity seeding also writes static / kinematic records)
+            assert_bits_equal(gb["linvel"][dyn], rb["linvel"][dyn], f"{tag}: linear velocity")
+            assert_bits_equal(gb["angvel"][dyn], rb["angvel"][dyn], f"{tag}: angular velocity")
+            assert_bits_equal(gb["quat"][ex], rb["quat"][ex], f"{tag}: quaternion")
+            st, tm = w.download_activation()
+            rst, rtm = ref.bulk_activation()
+            assert np.array_equal(st[ex], rst[ex].astype(np.uint8)), f"{tag}: activation states"
+            assert_bits_equal(tm[ex & (rst == 1)], rtm[ex & (rst == 1)], f"{tag}: deactivation timers")
+            if ground:
+                cn, _ = w.download_contacts()
+                for e in np.flatnonzero(dyn)[::5]:
+                    rn, _ = ref.GroundContacts(int(e) + 1)
+                    assert cn[e] == rn, f"{tag}: body {e} has {cn[e]} ground contacts, oracle {rn}"
+            if broadphase and got_n > 0:
+                assert_bits_equal(gb["aabb"][ex], rb["aabb"][ex], f"{tag}: fed AABBs")
+                assert np.array_equal(w.pairs(cap=max(64 * n, 4096)), ref.pairs("sweep")), f"{tag}: pair set"
+            if trig:
+                want_ev = ref.TriggerEvents()
+                want_ev[:, 1:] -= 1
+                assert np.array_equal(w.trigger_events(), want_ev), f"{tag}: trigger events"
