@@ -29,17 +29,31 @@ def _forest(rng, n):
     return parent
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(300, 3000))
+    # seeds 24..39: larger scenes with long parent chains (tiles that overflow into further passes), hundreds of collision
+    # filter combinations (the palette's 32-class and 255-class boundaries), physics and transforms as separate calls (the
+    # adapter's pattern), normal matrices, several ticks per call, and two long runs in which bodies come to rest and sleep
+    style_b = seed >= 24
+    n = int(rng.integers(300, 3000)) if not style_b else int(rng.integers(3000, 9000))
+    split = style_b and bool(seed & 1)
+    normals = style_b and seed % 4 in (0, 1)
+    n_ticks = 40 if seed not in (29, 33) else 330
     ground = bool(seed & 1)
     basis = bool(seed & 2)
     broadphase = bool(seed & 4) or seed % 12 >= 8
     clock = seed % 12 in (3, 6, 9, 11)       # Bullet's stepSimulation accumulator with varying dt
     wl = synth.Workload("fuzz", synth.FLAT, n, 500 + seed)
     wl.parent = _forest(rng, n)
-    side = float(rng.choice([6.0, 20.0, 60.0]))
+    if style_b:
+        at = 1
+        while at < n - 10:                                   # chain segments up to 700 deep
+            length = int(rng.integers(2, rng.choice([8, 80, 700])))
+            for i in range(at + 1, min(at + length, n)):
+                wl.parent[i] = i - 1
+            at += length + int(rng.integers(1, 50))
+    side = float(rng.choice([6.0, 20.0, 60.0])) if not style_b else float(rng.choice([25.0, 80.0]))
     wl.pos = rng.uniform(-side, side, (n, 3)).astype(np.float32)
     if ground:
         wl.pos[:, 1] = rng.uniform(0.1, 3.0, n).astype(np.float32)
@@ -61,6 +75,10 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
         mass = rng.choice([0.25, 1.0, 1.0, 3.0, 50.0], n).astype(np.float32)
     layer = rng.choice([1, 1, 2, 4, 8], n).astype(np.uint32)
     mask = rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFD, 0xFFFFFFFB, 3], n).astype(np.uint32)
+    if style_b:
+        kinds = int(rng.choice([40, 40, 400]))               # (layer, mask) combinations: beyond 32, beyond 255
+        layer = (np.uint32(1) << rng.integers(0, 8, n).astype(np.uint32)) | (rng.integers(0, kinds, n).astype(np.uint32) << np.uint32(8))
+        mask = np.where(rng.random(n) < 0.8, 0xFFFFFFFF, 0xFFFF00FF | (rng.integers(0, 255, n) << 8)).astype(np.uint32)
     friction = rng.choice([0.5, 0.5, 0.1, 1.0], n).astype(np.float32)
     body_kw = dict(mass=mass, shape=shape, size=size, layer=layer, mask=mask)
 
@@ -81,9 +99,12 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
     if clock:
         ref.SetAccumulator(True, DT, 4)
     flags = B.TICK_ALL | (B.TICK_BULLET_BASIS if basis else 0) | (B.TICK_BROADPHASE if broadphase else 0)
+    if normals:
+        flags |= B.TICK_NORMAL_MATRICES
     vel = (rng.normal(size=(n, 3)) * 3.0).astype(np.float32)
 
-    with B.World(pair_capacity=max(64 * n, 4096)) as w:
+    pair_cap = max(256 * n, 4096)
+    with B.World(pair_capacity=pair_cap) as w:
         w.set_topology(wl.parent, has_transform)
         w.upload_trs(wl.pos, wl.euler, wl.scale)
         w.upload_bodies(wl.body_type, **body_kw)
@@ -93,9 +114,12 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
             w.upload_friction(friction)
             w.set_ground_plane(True)
         parent = wl.parent.copy()
-        for tick in range(40):
+        most_asleep = 0
+        for tick in range(n_ticks):
             # ---- an edit between ticks, mirrored on both sides
             what = rng.choice(["none", "none", "teleport", "velocity", "spin", "recreate", "change", "dirty", "reparent", "triggers", "transform"])
+            if n_ticks > 40 and (rng.random() < 0.93 or (tick > 20 and what in ("velocity", "spin"))):
+                what = "none"                                  # the long runs are mostly left alone: bodies settle and fall asleep
             if what == "teleport":
                 first, cnt = int(rng.integers(n_bare, n - 20)), int(rng.integers(1, 20))
                 p = rng.uniform(-side, side, (cnt, 3)).astype(np.float32)
@@ -205,9 +229,20 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                 ref.PhysicsSystemUpdate(dt)
                 got_n = w.step_simulation(dt, 4, DT, flags=flags)
                 assert got_n == ref.LastSubSteps(), f"tick {tick}: {got_n} sub-steps, oracle {ref.LastSubSteps()}"
-            else:
+            elif split:
                 ref.PhysicsSystemUpdate(DT)
-                w.tick(dt=DT, flags=flags)
+                w.tick(dt=DT, flags=flags & ~(B.TICK_TRANSFORMS | B.TICK_NORMAL_MATRICES))
+                assert_bits_equal(w.download_pose()[0], ref.bulk_pose()[0], f"seed {seed} tick {tick}: position after the physics call")
+                assert np.array_equal(w.download_dirty(), ref.bulk_world()[1].astype(bool)), f"seed {seed} tick {tick}: dirty after the physics call"
+                w.tick(dt=DT, flags=B.TICK_TRANSFORMS | (B.TICK_NORMAL_MATRICES if normals else 0))
+                got_n = 1
+            else:
+                reps = 1 if not style_b or trig or rng.random() < 0.7 else int(rng.integers(2, 5))   # several ticks in one call
+                for _ in range(reps):
+                    ref.PhysicsSystemUpdate(DT)
+                    if _ + 1 < reps:
+                        ref.TransformSystemUpdate()
+                w.tick(dt=DT, flags=flags, ticks=reps)
                 got_n = 1
             ref.TransformSystemUpdate()
 
@@ -220,6 +255,9 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
             want_world, want_dirty = ref.bulk_world()
             assert_bits_equal(w.download_world(), want_world, f"{tag}: world")
             assert np.array_equal(w.download_dirty(), want_dirty.astype(bool)), f"{tag}: dirty flags"
+            if normals:
+                tf = has_transform.astype(bool)
+                assert_bits_equal(w.download_normal()[tf], po.normal_matrices(want_world)[tf], f"{tag}: normal matrices")
             assert w.dirty_count() == ref.CountDirtyTransforms(), f"{tag}: CountDirtyTransforms"
             rb, gb = ref.bulk_bodies(), w.download_bodies()
             ex = rb["exists"]
@@ -230,6 +268,7 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
             st, tm = w.download_activation()
             rst, rtm = ref.bulk_activation()
             assert np.array_equal(st[ex], rst[ex].astype(np.uint8)), f"{tag}: activation states"
+            most_asleep = max(most_asleep, int((st[dyn] == 2).sum()))
             assert_bits_equal(tm[ex & (rst == 1)], rtm[ex & (rst == 1)], f"{tag}: deactivation timers")
             if ground:
                 cn, _ = w.download_contacts()
@@ -238,8 +277,10 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                     assert cn[e] == rn, f"{tag}: body {e} has {cn[e]} ground contacts, oracle {rn}"
             if broadphase and got_n > 0:
                 assert_bits_equal(gb["aabb"][ex], rb["aabb"][ex], f"{tag}: fed AABBs")
-                assert np.array_equal(w.pairs(cap=max(64 * n, 4096)), ref.pairs("sweep")), f"{tag}: pair set"
+                assert np.array_equal(w.pairs(cap=pair_cap), ref.pairs("sweep")), f"{tag}: pair set"
             if trig:
                 want_ev = ref.TriggerEvents()
                 want_ev[:, 1:] -= 1
                 assert np.array_equal(w.trigger_events(), want_ev), f"{tag}: trigger events"
+        if n_ticks > 40:
+            assert most_asleep > 20, f"seed {seed}: only {most_asleep} bodies ever slept in the long run"
