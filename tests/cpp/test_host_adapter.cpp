@@ -408,6 +408,107 @@ int main(int argc, char** argv)
         w.useReferenceShape = false;
     }
 
+    // Random edits, one per tick, through every path of the adapter at once: index reuse, topology refreshes, sparse uploads,
+    // body / collider / trigger components coming and going, Transforms removed and given back, in Bullet's orientation scheme
+    // with the ground plane on.  (Parents are never chosen among a node's descendants: Scene::SetParent does not check.)
+    {
+        std::mt19937 r2(77);
+        // (Transform fields edited WITHOUT MarkDirty — the "stale edits" above — are flushed first and not made again here: the
+        //  reference's physics reads such fields when it (re)creates a body or poses a ghost, the adapter uploads a Transform
+        //  only when it is dirty — DESIGN.md 3, a documented difference)
+        for (auto& kv : w.ref.GetTransforms()) kv.second.MarkDirty();
+        for (auto& kv : w.gpu.GetTransforms()) kv.second.MarkDirty();
+        w.Tick();
+        auto pick_alive = [&]() -> uint32_t {
+            for (int tries = 0; tries < 64; ++tries) {
+                const uint32_t id = 1 + r2() % static_cast<uint32_t>(n + 40);
+                if (w.ref.IsAlive(id)) return id;
+            }
+            return 0;
+        };
+        int done[10] = {0};
+        std::vector<std::array<uint32_t, 3>> history;
+        for (int round = 0; round < 160; ++round) {
+            const int op = static_cast<int>(r2() % 10);
+            const uint32_t id = pick_alive();
+            if (!id) continue;
+            if (op == 0) {
+                uint32_t p = r2() % 5 == 0 ? 0 : pick_alive();
+                for (uint32_t a = p; a != 0; a = w.ref.GetParent(a)) {
+                    if (a == id) { p = 0; break; }
+                }
+                w.SetParent(id, p);
+            } else if (op == 1) {
+                w.Destroy(id);
+            } else if (op == 2) {
+                float p[3], e[3], s[3];
+                orc::synth::trs(0xC0DE, static_cast<uint32_t>(round), 0, p, e, s);
+                p[1] = 1.0f + static_cast<float>(round % 7);
+                const uint32_t fresh = w.Create(p, e, s);
+                if (round % 2) {
+                    float size[3] = {0.3f + 0.1f * (round % 5), 0.6f, 0.4f};
+                    w.Body(fresh, static_cast<int>(r2() % 3), 0.5f + static_cast<float>(r2() % 4), size, static_cast<int>(r2() % 2), 1u << (r2() % 3), 0xffffffffu);
+                }
+                if (round % 3 == 0) w.SetParent(fresh, id);
+            } else if (op == 3) {
+                float p[3] = {static_cast<float>(round) - 80.0f, 2.0f + static_cast<float>(round % 9), static_cast<float>(r2() % 100) - 50.0f};
+                w.Move(id, p, true);
+            } else if (op == 4) {
+                if (auto* b = w.ref.GetRigidBody(id)) b->dirty = true;
+                if (auto* b = w.gpu.GetRigidBody(id)) b->dirty = true;
+            } else if (op == 5) {
+                if (r2() % 2) { w.ref.RemoveRigidBody(id); w.gpu.RemoveRigidBody(id); }
+                else { w.ref.RemoveCollider(id); w.gpu.RemoveCollider(id); }
+            } else if (op == 6) {
+                if (w.ref.GetTransform(id)) {
+                    if (w.ref.GetTriggerVolume(id)) continue;
+                    w.ref.RemoveRigidBody(id); w.gpu.RemoveRigidBody(id);
+                    w.ref.RemoveTransform(id); w.gpu.RemoveTransform(id);
+                } else {
+                    float p[3], e[3], s[3];
+                    orc::synth::trs(0xBEEF, static_cast<uint32_t>(round), 0, p, e, s);
+                    p[1] = 3.0f;
+                    orc::RefTransform* rt = w.ref.AddTransform(id);
+                    bge::Transform* gt = w.gpu.AddTransform(id);
+                    Put(&rt->position, p); Put(&rt->rotationEuler, e); Put(&rt->scale, s);
+                    Put(&gt->position, p); Put(&gt->rotationEuler, e); Put(&gt->scale, s);
+                }
+            } else if (op == 7) {
+                const float s3[3] = {0.5f + 0.25f * static_cast<float>(r2() % 6), 1.0f, 0.75f + 0.25f * static_cast<float>(r2() % 4)};
+                auto* rt = w.ref.GetTransform(id);
+                auto* gt = w.gpu.GetTransform(id);
+                if (!rt || !gt) continue;
+                Put(&rt->scale, s3); rt->MarkDirty();
+                Put(&gt->scale, s3); gt->MarkDirty();
+            } else if (op == 8) {
+                if (!w.ref.GetTransform(id)) continue;
+                float size[3] = {0.2f + 0.1f * static_cast<float>(r2() % 8), 0.2f + 0.1f * static_cast<float>(r2() % 8), 0.2f + 0.1f * static_cast<float>(r2() % 8)};
+                w.Body(id, static_cast<int>(r2() % 3), 0.25f * static_cast<float>(1 + r2() % 12), size, static_cast<int>(r2() % 2), 1u << (r2() % 3),
+                       r2() % 4 ? 0xffffffffu : 0xfffffffdu);
+                w.ref.GetRigidBody(id)->dirty = true; w.gpu.GetRigidBody(id)->dirty = true;
+                w.ref.GetCollider(id)->dirty = true; w.gpu.GetCollider(id)->dirty = true;
+            } else {
+                if (w.ref.GetTriggerVolume(id)) {
+                    w.ref.RemoveTriggerVolume(id); w.gpu.RemoveTriggerVolume(id);
+                } else if (w.ref.GetTransform(id)) {
+                    float size[3] = {4.0f + static_cast<float>(r2() % 9), 8.0f, 4.0f + static_cast<float>(r2() % 7)};
+                    w.Trigger(id, static_cast<int>(r2() % 2), size, r2() % 3 ? 4u : 0u, 0xffffffffu, r2() % 4 == 0);
+                }
+            }
+            ++done[op];
+            const int failures_before = g_failures;
+            w.Tick();
+            history.push_back({static_cast<uint32_t>(round), static_cast<uint32_t>(op), id});
+            if (g_failures != failures_before) {
+                std::printf("random edits: first failure in round %d; the operations so far (round op entity):", round);
+                for (const auto& h : history) std::printf(" %u:%u:%u", h[0], h[1], h[2]);
+                std::printf("\n");
+                break;
+            }
+        }
+        for (int op = 0; op < 10 && history.size() >= 150; ++op) CHECK(done[op] > 3, "random edits: operation %d ran only %d times", op, done[op]);
+    }
+
     if (g_failures == 0) std::printf("host adapter: all checks passed (%zu transforms, %d ticks, %zu trigger events)\n", w.gpu.GetTransformCount(), w.ticks, w.events_seen);
     return g_failures ? 1 : 0;
 }
