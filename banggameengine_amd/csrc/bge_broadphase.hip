@@ -1259,6 +1259,51 @@ __device__ __forceinline__ void emit_pairs(const PairSink& sink, WaveStage& st, 
     if (st.fill >= kFlush) stage_flush(sink, st, kFlush);
 }
 
+// Lane-private pair lists (wave search).  emit_pairs costs a ballot, a rank, an LDS write, a cursor update and a flush test
+// per candidate, hit or not — in a loop whose useful part is six comparisons.  Here a hit is one exec-masked ds_write into
+// the lane's own column of a [kLaneCap][64] LDS array (no lane ever reads another's entries) and a counter increment; the
+// lists of a 64-body block are written out together — one scan of the counts, ONE global atomic, every lane storing its own
+// entries — at the end of the block, or earlier if a lane could overflow in the next trip.
+#ifndef BGE_LANE_CAP
+#define BGE_LANE_CAP 8
+#endif
+constexpr uint32_t kLaneCap = BGE_LANE_CAP;
+struct LaneList {
+    uint32_t* buf; // LDS, [kLaneCap][64], this wave's
+    uint32_t cnt;  // this lane's entries
+};
+__device__ __forceinline__ void lane_push(LaneList& l, bool hit, uint32_t partner)
+{
+    if (hit) {
+        l.buf[(threadIdx.x & 63u) + 64u * l.cnt] = partner;
+        ++l.cnt;
+    }
+}
+__device__ __forceinline__ void lane_flush(const PairSink& sink, LaneList& l, uint32_t own_entity)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = l.cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= static_cast<uint32_t>(off)) incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0) return;
+    const uint32_t shard = blockIdx.x % kShards;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&sink.shard_count[shard * 8u], static_cast<unsigned long long>(total));
+    base = __shfl(base, 0, 64) + (incl - l.cnt);
+    uint2* dst = sink.pairs + static_cast<uint64_t>(shard) * sink.shard_cap;
+    for (uint32_t k = 0; __any(k < l.cnt); ++k) {
+        if (k < l.cnt) {
+            const uint32_t partner = l.buf[lane + 64u * k];
+            if (base + k < sink.shard_cap) dst[base + k] = make_uint2(min(own_entity, partner), max(own_entity, partner));
+        }
+    }
+    l.cnt = 0;
+}
+
 __device__ __forceinline__ bool overlap(const float4& alo, const float4& ahi, const float4& blo, const float4& bhi)
 {
     // All six comparisons, no short circuit: for `&&` the compiler builds a cascade of exec-mask branches (one per axis, the
@@ -1415,20 +1460,23 @@ __global__ void __launch_bounds__(256) k_bp_pairs(const Accum* __restrict__ acc,
                              96 -> 583 us (7 per CU), 88 -> 577, 80 -> 586, 72 -> 604 (more rows need a second chunk) */
 #endif
 constexpr uint32_t kWaveChunk = BGE_WAVE_CHUNK; // records per staged chunk and wave (a row's union range is ~70 records at 0.7 bodies per cell)
-// workgroups per CU the LDS footprint allows (wave chunk regions + 6 KiB pair staging + 2 KiB filter table)
-constexpr uint32_t kWaveResidentCompact = (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + 6144u + 2048u + 96u) > 8u ? 8u : (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + 6144u + 2048u + 96u);
-constexpr uint32_t kWaveResidentFull = (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + 6144u + 64u) > 8u ? 8u : (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + 6144u + 64u);
+constexpr uint32_t kListBytes = 4u * kLaneCap * 64u * 4u; // the four waves' pair lists
+// workgroups per CU the LDS footprint allows (wave chunk regions + the pair lists + 2 KiB filter table)
+constexpr uint32_t kWaveResidentCompact = (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + kListBytes + 2048u + 96u) > 8u ? 8u : (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + kListBytes + 2048u + 96u);
+constexpr uint32_t kWaveResidentFull = (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + kListBytes + 64u) > 8u ? 8u : (160u * 1024u) / (4u * 3u * kWaveChunk * 16u + kListBytes + 64u);
 // SMALL (with COMPACT): at most 32 filter classes in the scene — the usual case.  Instead of the (group, mask, static) table
 // the workgroup keeps one 32-bit word per class, bit c = "may pair with class c"; a lane holds its own class's word and the
 // filter of a candidate is one shift instead of two dependent LDS reads and a dozen bit operations.
+// (the SMALL variant has no 2 KiB filter table)
+constexpr uint32_t kWaveResidentSmall = (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + kListBytes + 128u + 96u) > 8u ? 8u : (160u * 1024u) / (4u * 2u * kWaveChunk * 16u + kListBytes + 128u + 96u);
 template <bool WINDOW, bool COMPACT, bool SMALL = false>
-__global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveResidentFull) k_bp_pairs_wave(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
+__global__ void __launch_bounds__(256, SMALL ? kWaveResidentSmall : (COMPACT ? kWaveResidentCompact : kWaveResidentFull)) k_bp_pairs_wave(const Accum* __restrict__ acc, const uint32_t* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, const uint4* __restrict__ filter_table,
                                                        PairSink sink)
 {
     constexpr uint32_t RS = COMPACT ? 2u : 3u; // float4 per record
     __shared__ float4 cand_all[4][RS * kWaveChunk];
-    __shared__ uint2 stage_lds[4][kStage];
+    __shared__ uint32_t lists_lds[4][kLaneCap * 64];
     __shared__ uint2 s_tab[(COMPACT && !SMALL) ? 256 : 1];      // (group, mask) per filter class
     __shared__ uint32_t s_static[(COMPACT && !SMALL) ? 8 : 1];  // static bit per filter class
     __shared__ uint32_t s_compat[SMALL ? 32 : 1];               // SMALL: classes a class may pair with
@@ -1456,7 +1504,7 @@ __global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveRes
     const uint32_t n_blocks = (n_sorted + 63u) / 64u;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     float4* cand = cand_all[wave];
-    WaveStage st{stage_lds[wave], 0u};
+    LaneList found{lists_lds[wave], 0u};
 
     for (uint32_t blk = blockIdx.x * 4u + wave; blk < n_blocks; blk += gridDim.x * 4u) {
         const uint32_t i = blk * 64u + lane;
@@ -1517,6 +1565,9 @@ __global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveRes
                 const uint32_t e0 = min(end, top);
                 if (!__any(jj0 < e0)) continue;
                 wave_sync(); // the previous chunk has been consumed
+                // (staging the corners as separate arrays — all min corners, then all max corners — so that the lanes of a
+                //  ds_read_b128 pass hit consecutive 16-byte bank groups was measured: SQ_LDS_BANK_CONFLICT 11.3 M -> 10.6 M, step
+                //  0.504 -> 0.520 ms; rejected)
                 for (uint32_t k = lane; k < RS * (top - base); k += 64u) cand[k] = sorted[static_cast<uint64_t>(RS) * base + k];
                 wave_sync();
                 uint32_t jj = jj0;
@@ -1544,15 +1595,14 @@ __global__ void __launch_bounds__(256, COMPACT ? kWaveResidentCompact : kWaveRes
                         }
                         jj += 2u;
                     }
-                    if (__any(hit0 || hit1)) {
-                        emit_pairs(sink, st, hit0, entity_i, e0j);
-                        emit_pairs(sink, st, hit1, entity_i, e1j);
-                    }
+                    lane_push(found, hit0, e0j);
+                    lane_push(found, hit1, e1j);
+                    if (__any(found.cnt + 2u > kLaneCap)) lane_flush(sink, found, entity_i); // (a trip adds at most two)
                 }
             }
         }
+        lane_flush(sink, found, entity_i);
     }
-    if (st.fill) stage_flush(sink, st, st.fill);
 }
 
 __global__ void __launch_bounds__(256) k_bp_large(uint64_t n_slots, const Accum* __restrict__ acc,
@@ -1980,7 +2030,8 @@ int Broadphase::run(hipStream_t stream, const WorldView& w, uint64_t n, const ui
         // wave-granular search, persistent grid sized to residency (LDS: 26 KiB per workgroup with 32-byte records, 30 KiB
         // with full ones).  A software-pipelined variant (all five rows' cell_start loads up front, the next row's chunk
         // prefetched into registers during the tests) was measured SLOWER: 324 us against 308 us — it needs 95 VGPRs.
-        const dim3 wgrid(std::min<uint32_t>(blocks_for(n, 256), (compact_records ? kWaveResidentCompact : kWaveResidentFull) * 256));
+        const bool small = compact_records && !window && palette->n_classes <= 32u && small_palette_;
+        const dim3 wgrid(std::min<uint32_t>(blocks_for(n, 256), (small ? kWaveResidentSmall : (compact_records ? kWaveResidentCompact : kWaveResidentFull)) * 256));
         if (window) {
             hipLaunchKernelGGL((k_bp_pairs_wave<true, false>), wgrid, dim3(256), 0, stream, acc, cell_start, sorted, no_table, sink);
         } else if (compact_records && palette->n_classes <= 32u && small_palette_) {
