@@ -52,7 +52,7 @@ def main():
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
     entities = {"flat1m": 1_000_000, "chains4": 1_000_000, "subtree64": 2_000_000, "cube4m": 4_000_000, "flat1m_basis": 1_000_000, "flat16m": 16_000_000}
-    algorithmic = {"flat1m": 140.0, "chains4": 113.0, "subtree64": (140.0 + 63 * 104.0) / 64.0, "flat1m_basis": 184.0}
+    algorithmic = {"flat1m": 140.0, "chains4": 113.0, "subtree64": (140.0 + 63 * 104.0) / 64.0, "flat1m_basis": 140.0 + 0.12 * 44.0}  # basis: steady state; the PMC pass ends 25 ticks after the re-pose, when ~30 % of the bodies still step
     for name in entities:
         stats = newest(os.path.join(src, f"stats_{name}", "**", "*kernel_stats.csv"))
         if stats:
