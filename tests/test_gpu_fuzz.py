@@ -329,3 +329,64 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                 assert np.array_equal(w.trigger_events(), want_ev), f"{tag}: trigger events"
         if n_ticks > 40:
             assert most_asleep > 20, f"seed {seed}: only {most_asleep} bodies ever slept in the long run"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_sharded_over_several_worlds_equals_the_unsharded_oracle(seed):
+    """SURVEY 8(e) + 8(f) rank 4 under random scenes: a forest is partitioned by subtree over 2..6 worlds (all on this GPU),
+    each world ticks its shard, and (i) every entity's pose and world matrix equals the ONE unsharded oracle's bit for bit,
+    (ii) the slab exchange reproduces the unsharded pair set, each pair once — with bodies far wider than a slab, bodies on
+    children, static / kinematic bodies and filter masks in the mix."""
+    from banggameengine_amd import sharding
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.integers(3000, 20000))
+    wl = synth.Workload("fuzz", synth.FLAT, n, 900 + seed)
+    wl.parent = _forest(rng, n)
+    side = float(rng.choice([15.0, 40.0]))
+    wl.pos = rng.uniform(-side, side, (n, 3)).astype(np.float32)
+    wl.euler = rng.uniform(-180.0, 180.0, (n, 3)).astype(np.float32)
+    wl.scale = np.ones((n, 3), np.float32)
+    wl.body_type = rng.choice([255, 0, 1, 1, 1, 2], n).astype(np.uint8)
+    size = rng.uniform(0.2, 1.0, (n, 3)).astype(np.float32)
+    wide = rng.choice(n, 5, replace=False)
+    size[wide] = rng.uniform(5.0, 2.0 * side, (5, 3)).astype(np.float32)        # wider than a slab: routed to several
+    kw = dict(size=size, shape=rng.choice([0, 0, 1], n).astype(np.uint8), layer=rng.choice([1, 2, 4], n).astype(np.uint32),
+              mask=rng.choice([0xFFFFFFFF, 3, 6], n).astype(np.uint32))
+    vel = (rng.normal(size=(n, 3)) * 2.0).astype(np.float32)
+    nshards, axis, ticks = int(rng.integers(2, 7)), int(rng.integers(0, 3)), int(rng.integers(2, 6))
+    ref = build_oracle(wl, aabbs=True, **kw)
+    for k in range(ticks):
+        ref.PhysicsSystemUpdate(DT)
+        ref.TransformSystemUpdate()
+        if k == 0:
+            ref.bulk_set_velocity(vel, np.zeros((n, 3), np.float32))
+    want_pairs = ref.pairs("sweep")
+    want_pos, want_euler = ref.bulk_pose()
+    want_world = ref.bulk_world()[0]
+    rank_of, load, shards = sharding.shard_scene(wl.parent, nshards)
+    worlds = []
+    try:
+        for ids, local_parent in shards:
+            w = B.World(pair_capacity=max(256 * len(ids), 4096))
+            w.set_topology(local_parent)
+            w.upload_trs(wl.pos[ids], wl.euler[ids], wl.scale[ids])
+            w.upload_bodies(wl.body_type[ids], **{k: v[ids] for k, v in kw.items()})
+            w.set_global_ids(ids)
+            for k in range(ticks):
+                w.tick(dt=DT, flags=B.TICK_ALL | B.TICK_AABBS)
+                if k == 0:
+                    w.set_velocities(vel[ids], np.zeros((len(ids), 3), np.float32))
+            worlds.append(w)
+            pos, euler = w.download_pose()
+            assert_bits_equal(pos, want_pos[ids], f"seed {seed}: positions of a shard")
+            assert_bits_equal(euler, want_euler[ids], f"seed {seed}: rotationEuler of a shard")
+            assert_bits_equal(w.download_world(), want_world[ids], f"seed {seed}: world matrices of a shard")
+        sharding.slab_broadphase_local(worlds, axis=axis)
+        got = np.concatenate([w.pairs(cap=max(256 * n, 4096)) for w in worlds])
+    finally:
+        for w in worlds:
+            w.close()
+    assert sorted(np.concatenate([ids for ids, _ in shards]).tolist()) == list(range(n))   # every entity lives in exactly one shard
+    key = got[:, 0].astype(np.uint64) << np.uint64(32) | got[:, 1]
+    assert len(np.unique(key)) == len(key), f"seed {seed}: a pair was reported by two slabs"
+    assert len(want_pairs) > 100 and np.array_equal(got[np.argsort(key)], want_pairs), f"seed {seed}: {len(got)} pairs, oracle {len(want_pairs)}"
