@@ -149,6 +149,29 @@ __device__ __forceinline__ void bx_mtx_mul(float (&o)[16], const float (&a)[16],
 #endif
 }
 
+// One row of bx_mtx_mul: row i of a * b from row i of a — the same operations on the same operands, so the same bits.  Used where
+// `a` arrives a row at a time (from LDS or memory) and the product leaves a row at a time: 8 live registers besides b
+// instead of 32.
+__device__ __forceinline__ float4 bx_mtx_mul_row(const float4& a, const float (&b)[16])
+{
+#ifdef BGE_EXPERIMENT_SCALAR_MTXMUL
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ((a.x * b[j] + a.y * b[4 + j]) + a.z * b[8 + j]) + a.w * b[12 + j];
+    return make_float4(o[0], o[1], o[2], o[3]);
+#else
+    const f32x2 a0 = {a.x, a.x}, a1 = {a.y, a.y}, a2 = {a.z, a.z}, a3 = {a.w, a.w};
+    f32x2 r[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 b0 = {b[2 * h], b[2 * h + 1]}, b1 = {b[4 + 2 * h], b[5 + 2 * h]};
+        const f32x2 b2 = {b[8 + 2 * h], b[9 + 2 * h]}, b3 = {b[12 + 2 * h], b[13 + 2 * h]};
+        r[h] = ((a0 * b0 + a1 * b1) + a2 * b2) + a3 * b3;
+    }
+    return make_float4(r[0].x, r[0].y, r[1].x, r[1].y);
+#endif
+}
+
 // normalMtx = transpose(inverse(world)) as Renderer::BeginFrame computes it per mesh entity
 // (src/render/Renderer.cpp:633-636: bx::mtxInverse then bx::mtxTranspose).  bx::mtxInverse is the adjugate over the
 // determinant with the cofactors expanded along the first row of each minor; the transpose is folded into the stores.

@@ -56,17 +56,19 @@ __device__ __forceinline__ void lds_get(const float4* lds, uint32_t n, float (&m
     }
 }
 
-__device__ __forceinline__ void load_world(const float* __restrict__ world, uint32_t slot, float (&m)[16])
+// world = parent * local, a row at a time: the parent's row comes from the LDS image (or from memory, for a parent resolved by
+// an earlier launch), the product's row goes straight into this node's place in the image.  (bx_mtx_mul on whole matrices held
+// 48 registers here — parent, local, product — and with them the kernel's register allocation.)
+__device__ __forceinline__ void lds_mul_put(float4* lds, uint32_t parent, uint32_t self, const float (&local)[16])
 {
-    const float4* src = reinterpret_cast<const float4*>(world) + 4ull * slot;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float4 t = src[r];
-        m[4 * r] = t.x;
-        m[4 * r + 1] = t.y;
-        m[4 * r + 2] = t.z;
-        m[4 * r + 3] = t.w;
-    }
+    for (uint32_t r = 0; r < 4; ++r) lds[lds_row(self, r)] = bx_mtx_mul_row(lds[lds_row(parent, r)], local);
+}
+__device__ __forceinline__ void world_mul_put(float4* lds, const float* __restrict__ world, uint32_t parent_slot, uint32_t self, const float (&local)[16])
+{
+    const float4* src = reinterpret_cast<const float4*>(world) + 4ull * parent_slot;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) lds[lds_row(self, r)] = bx_mtx_mul_row(src[r], local);
 }
 
 // Root table for the per-frame all-gather, filled by the roots themselves (consecutive roots of a tile are
@@ -154,10 +156,10 @@ constexpr bool kSleepEnabled = true;
 #define BGE_AABB_MIN_WAVES 4 /* waves per SIMD the AABB variant is compiled for: at 8 it spills 20 VGPRs (measured ~2 % slower at 4 M bodies) */
 #endif
 #ifndef BGE_BASIS_MIN_WAVES
-#define BGE_BASIS_MIN_WAVES 6 /* the BGE_TICK_BULLET_BASIS variants without AABBs / normal matrices: 80 VGPRs; measured at 1 M bodies 35.1 us at 4, 34.8 at 6, 36.4 at 8 (64 VGPRs + 12 B scratch) */
+#define BGE_BASIS_MIN_WAVES 8 /* the BGE_TICK_BULLET_BASIS variants without AABBs / normal matrices: 55 VGPRs since parent * local is formed a row at a time (80 before, 6 waves per SIMD) */
 #endif
 #ifndef BGE_XFORM_MIN_WAVES
-#define BGE_XFORM_MIN_WAVES 7 /* the variants with the transform part and nothing else heavy (the headline kernel): at 8 waves per SIMD they get 64 VGPRs and spill 12 B per lane — 8 B per entity of scratch writes that rocprofv3 WRITE_SIZE showed (96 instead of 88 B); at 7 (72 VGPRs, no scratch) 1 M flat bodies tick in 22.9 us instead of 23.9, 2 M in 64-node subtrees in 37.9 instead of 38.7; 6 gives 23.2 */
+#define BGE_XFORM_MIN_WAVES 8 /* the variants with the transform part and nothing else heavy (the headline kernel).  While parent * local was formed on whole matrices (48 registers) they needed 72 VGPRs — at 64 they spilled 12 B per lane, 8 B per entity of scratch writes that rocprofv3 WRITE_SIZE showed — and ran at 7 waves per SIMD; with the product formed a row at a time (lds_mul_put) they need 55 / 48 */
 #endif
 template <bool PHYS, bool XFORM, bool AABB, bool NORMAL, bool BASIS>
 // 8 waves per SIMD (<= 64 VGPRs): the kernel waits on memory and, in block tiles, on barriers; occupancy hides both
@@ -208,7 +210,10 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
         pos = ld3(w.pos, slot);
         eul = ld3(w.euler, slot);
         if (XFORM) scl = ld3(w.scale, slot);
-        if (PHYS && (hdr & kHdrAllDynamic)) vel_early = ld3(w.vel, slot); // (elsewhere most slots have no velocity to read)
+#ifndef BGE_SPECULATIVE_VEL
+#define BGE_SPECULATIVE_VEL 1
+#endif
+        if (BGE_SPECULATIVE_VEL && PHYS && (hdr & kHdrAllDynamic)) vel_early = ld3(w.vel, slot); // (elsewhere most slots have no velocity to read)
     }
     uint32_t f = f0;
     const bool valid = (f & kValid) != 0;
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     if (!BASIS) turn = false; // its angular velocity is zero now: the default scheme leaves the re-posed quaternion alone
                 }
             } else {
-                if (dynamic) v = (BGE_SPECULATIVE_LOADS && (hdr & kHdrAllDynamic)) ? vel_early : ld3(w.vel, slot);
+                if (dynamic) v = (BGE_SPECULATIVE_LOADS && BGE_SPECULATIVE_VEL && (hdr & kHdrAllDynamic)) ? vel_early : ld3(w.vel, slot);
                 if (spin) av = ld3(w.angvel, slot);
                 if (turn || AABB) q = ld4(w.quat, slot);
             }
@@ -498,13 +503,9 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
         if (hdr & kHdrWaveLocal) {
             // Every parent sits in its child's own 64-slot group (one wave64): the level loop and the write-out
             // need no workgroup barrier — DS operations of one wave execute in order.
-            float world[16];
             if (valid && level == 0) {
                 if (f & kExtParent) {
-                    float pw[16];
-                    load_world(w.world, w.parent[slot], pw);
-                    bx_mtx_mul(world, pw, local);
-                    lds_put(lds, tid, world);
+                    world_mul_put(lds, w.world, w.parent[slot], tid, local);
                 } else {
                     lds_put(lds, tid, local); // root: world = local (Transform.cpp:32-35)
                     if (keep_world) lds_put_stored(lds, tid, w.world, slot);
@@ -521,12 +522,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 for (int off = 32; off > 0; off >>= 1) wave_max = max(wave_max, static_cast<uint32_t>(__shfl_xor(wave_max, off, 64)));
                 for (uint32_t d = 1; d <= wave_max; ++d) {
                     wave_lds_sync();
-                    if (valid && level == d) {
-                        float pw[16];
-                        lds_get(lds, parent, pw);
-                        bx_mtx_mul(world, pw, local); // parent * local — the reference's order
-                        lds_put(lds, tid, world);
-                    }
+                    if (valid && level == d) lds_mul_put(lds, parent, tid, local); // parent * local — the reference's order
                 }
             }
             wave_lds_sync();
@@ -566,14 +562,10 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             // block tile (a subtree of 65..256 nodes, or the breadth-first prefix of a larger one): levels are
             // separated by workgroup barriers, parents staged in LDS
             const uint32_t parent = (f & kParentMask) >> kParentShift;
-            float world[16];
             if (valid && level == 0) {
                 if (f & kExtParent) {
                     // parent resolved by an earlier launch: read its world matrix from memory
-                    float pw[16];
-                    load_world(w.world, w.parent[slot], pw);
-                    bx_mtx_mul(world, pw, local);
-                    lds_put(lds, tid, world);
+                    world_mul_put(lds, w.world, w.parent[slot], tid, local);
                 } else {
                     lds_put(lds, tid, local);
                     if (keep_world) lds_put_stored(lds, tid, w.world, slot);
@@ -587,12 +579,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
 #ifndef BGE_EXPERIMENT_NO_LEVEL_BARRIER /* timing-only A/B build: results are wrong without the barrier */
                 __syncthreads();
 #endif
-                if (valid && level == d) {
-                    float pw[16];
-                    lds_get(lds, parent, pw);
-                    bx_mtx_mul(world, pw, local); // parent * local — the reference's order
-                    lds_put(lds, tid, world);
-                }
+                if (valid && level == d) lds_mul_put(lds, parent, tid, local); // parent * local — the reference's order
             }
             __syncthreads();
             // coalesced write-out: lane t stores float4 #(t + 256k) of the tile's 16 KiB image
