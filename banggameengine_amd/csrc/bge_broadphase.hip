@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t f2ord(float f)
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ bool is_body(uint32_t f) { return (f & kValid) && (f & kTypeMask) != 0; }
+__device__ __forceinline__ bool is_body(uint32_t f) { return (f & kTypeMask) != 0; } // (type bits exist only on slots that carry a body — with a Transform, or orphaned)
 
 __global__ void __launch_bounds__(256) k_bp_bounds(uint64_t n_slots, const uint32_t* __restrict__ flags,
                                                    const float* __restrict__ aabb, Accum* acc)

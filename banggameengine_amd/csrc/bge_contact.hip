@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(128) k_ground(WorldView w, GroundParams g)
     if (slot64 >= g.n_slots) return;
     const uint32_t slot = static_cast<uint32_t>(slot64);
     const uint32_t f0 = w.flags[slot];
-    if (!(f0 & kValid) || (f0 & kTypeMask) != 2u) return; // Dynamic bodies only: nothing else responds to a contact
+    if ((f0 & kTypeMask) != 2u) return; // Dynamic bodies only (with a Transform, or orphaned): nothing else responds to a contact
     const uint32_t ci0 = w.cinfo[slot];
     if (!(ci0 & kCiGroundMask)) return; // the body's mask excludes the ground's group (StaticFilter)
     if (f0 & kDrowsy) {

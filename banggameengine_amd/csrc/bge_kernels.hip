@@ -217,12 +217,17 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
     }
     uint32_t f = f0;
     const bool valid = (f & kValid) != 0;
+    // A slot with a body but no Transform: the entity lost its Transform while its RigidBody stayed.  The reference keeps that
+    // Bullet body in the world (EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393; nothing
+    // removes it while the component exists): it is stepped, collides and enters trigger volumes like any other, but it is
+    // never re-posed or re-created and nothing is written back.  Here: the physics part runs, the transform part does not.
+    const bool orphan_body = PHYS && !valid && (f & kTypeMask) != 0;
     if (BGE_SPECULATIVE_LOADS) {
-        if (!valid) {
+        if (!valid && !orphan_body) {
             pos = eul = F3{0.0f, 0.0f, 0.0f};
             scl = F3{1.0f, 1.0f, 1.0f};
         }
-    } else if (valid) {
+    } else if (valid || orphan_body) {
         pos = ld3(w.pos, slot);
         eul = ld3(w.euler, slot);
         if (XFORM) scl = ld3(w.scale, slot);
@@ -233,10 +238,10 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
     bool has_box = false;
     if (PHYS) {
         const uint32_t type = f & kTypeMask;
-        if (valid && type != 0) {
+        if (type != 0) { // (type bits exist only on slots that carry a body: with a Transform, or orphaned)
             const bool dynamic = type == 2u;
             // (p.no_repose: a later sub-step of the same stepSimulation call — the teleport rule ran before the first one)
-            const bool repose = p.no_repose == 0u && (f & (kTDirty | kBDirty)) != 0;
+            const bool repose = valid && p.no_repose == 0u && (f & (kTDirty | kBDirty)) != 0;
             bool spin = (f & kSpin) != 0;
             // BASIS (BGE_TICK_BULLET_BASIS): Bullet's own orientation scheme.  Its state is the 3x3 basis, which every step
             // goes basis -> getRotation -> exponential map -> safeNormalize -> setRotation for EVERY non-static body, spinning
@@ -410,9 +415,9 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                     }
                 }
                 if (ci & (kCiSolved | kCiMoved)) w.cinfo[slot] = ci & ~(kCiSolved | kCiMoved); // consumed
-                f |= kTDirty; // transform->MarkDirty()
+                if (valid) f |= kTDirty; // transform->MarkDirty()
             }
-            f &= ~kBDirty;
+            if (valid) f &= ~kBDirty; // (an orphaned body is not re-created: its dirty bit waits for the Transform)
         }
     }
 
@@ -662,12 +667,15 @@ __global__ void __launch_bounds__(256) k_pose_only(WorldView w, uint64_t n_slots
 __global__ void k_scatter_rows(const uint32_t* __restrict__ slot_of_entity, const uint32_t* __restrict__ index,
                                uint64_t first, uint64_t count,
                                uint32_t width, const uint32_t* __restrict__ stage, uint32_t* __restrict__ dst,
-                               uint32_t* __restrict__ flags, uint32_t or_bits)
+                               uint32_t* __restrict__ flags, uint32_t or_bits, uint32_t need_bits)
 {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (i >= count) return;
     const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
+    // need_bits = kValid: Transform data and dirty marks go to slots that hold a Transform — not to a body whose entity lost its
+    // Transform (there the position array is the body's origin, and nothing marks what does not exist)
+    if (need_bits && (flags[slot] & need_bits) != need_bits) return;
     if (dst) {
         for (uint32_t k = 0; k < width; ++k) dst[static_cast<uint64_t>(slot) * width + k] = stage[i * width + k];
     }
@@ -698,6 +706,8 @@ __global__ void k_scatter_bodies(const uint32_t* __restrict__ slot_of_entity, co
     if (i >= count) return;
     const uint32_t slot = slot_of_entity[index ? index[i] : first + i];
     if (slot == kNone) return;
+    // a body whose entity has no Transform is never re-created (EnsureRigidBody returns first): only its removal reaches it
+    if (!(w.flags[slot] & kValid) && (type_bits[i] & kTypeMask) != 0) return;
     if (cdims3) {
         // a (re)created body starts without contacts: removeRigidBody dropped its pair with the ground and the manifold with it
         w.cshape[slot] = make_float4(cdims3[3 * i], cdims3[3 * i + 1], cdims3[3 * i + 2], 0.0f);
@@ -877,7 +887,7 @@ __global__ void __launch_bounds__(256) k_trigger_pairs(uint64_t n_slots, uint32_
         if (s < n_slots) {
             const uint32_t f = w.flags[s];
             // the ghost is a static object: static bodies never pair with it
-            body = (f & kValid) && (f & kTypeMask) >= 2u;
+            body = (f & kTypeMask) >= 2u; // (with or without a Transform: an orphaned body is still in the world)
             if (body) {
                 const float* b = w.aabb + 6 * s;
                 for (int a = 0; a < 3; ++a) {
@@ -949,11 +959,11 @@ hipError_t launch_pose_only(hipStream_t stream, const WorldView& w, uint64_t n_s
 
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits,
-                               const uint32_t* index)
+                               const uint32_t* index, uint32_t need_bits)
 {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_rows, grid_for(count, 256), dim3(256), 0, stream, slot_of_entity, index, first, count, width,
-                       static_cast<const uint32_t*>(stage), static_cast<uint32_t*>(dst), flags, or_bits);
+                       static_cast<const uint32_t*>(stage), static_cast<uint32_t*>(dst), flags, or_bits, need_bits);
     return hipGetLastError();
 }
 

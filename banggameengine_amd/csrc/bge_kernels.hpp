@@ -100,7 +100,7 @@ hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundPar
 
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                                uint32_t width, const void* stage, void* dst, uint32_t* flags, uint32_t or_bits,
-                               const uint32_t* index = nullptr);
+                               const uint32_t* index = nullptr, uint32_t need_bits = 0);
 hipError_t launch_gather_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,
                               uint32_t width, const void* src, void* stage, const uint32_t* index = nullptr);
 hipError_t launch_scatter_bodies(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,

@@ -37,7 +37,7 @@ struct RouteScalars {
     unsigned long long n_bodies;
 };
 
-__device__ __forceinline__ bool is_body(uint32_t f) { return (f & kValid) && (f & kTypeMask) != 0; }
+__device__ __forceinline__ bool is_body(uint32_t f) { return (f & kTypeMask) != 0; }
 
 __device__ __forceinline__ uint32_t f2ord(float f)
 {

@@ -138,6 +138,12 @@ struct bge_world {
     DevBuf frozen;                       // WorldView::frozen (allocated with the first frozen root)
     bool any_frozen = false;
     std::vector<uint8_t> body_type_host; // bge_body_type per entity index as last uploaded (BGE_BODY_NONE = no body)
+    std::vector<uint8_t> orphan_host;    // 1: the entity lost its Transform while it had a body; the body kept its slot (kValid clear)
+    // A body exists in the reference's world from the first PhysicsSystem::Update that sees its components AND a Transform
+    // (EnsureRigidBody); an entity that loses its Transform before that has no body to keep.  body_since[e]: the value of
+    // physics_updates when the body of entity e was (last) uploaded onto a slot with a Transform; it exists once a later update ran.
+    std::vector<uint64_t> body_since;
+    uint64_t physics_updates = 0;
     bool has_topology = false;
     bool maybe_dirty = true;
     float local_time = 0.0f; // btDiscreteDynamicsWorld::m_localTime (bge_world_step_simulation)
@@ -359,13 +365,13 @@ int stage_index(bge_world* w, uint64_t count, const uint32_t* index, const uint3
 }
 
 int upload_rows(bge_world* w, uint64_t first, uint64_t count, uint32_t width, const void* host, void* dst,
-                uint32_t or_bits, const uint32_t* dev_index = nullptr)
+                uint32_t or_bits, const uint32_t* dev_index = nullptr, uint32_t need_bits = 0)
 {
     const size_t bytes = static_cast<size_t>(count) * width * 4;
     HIP_TRY(w->stage.ensure(bytes));
     HIP_TRY(hipMemcpyAsync(w->stage.p, host, bytes, hipMemcpyHostToDevice, w->stream));
     HIP_TRY(bge::launch_scatter_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, width, w->stage.p, dst,
-                                     w->flags.as<uint32_t>(), or_bits, dev_index));
+                                     w->flags.as<uint32_t>(), or_bits, dev_index, need_bits));
     // the staging buffer is reused by the next call
     HIP_TRY(hipStreamSynchronize(w->stream));
     return BGE_OK;
@@ -564,11 +570,44 @@ try {
     if (n >= 0xfffffff0ull) return fail(BGE_ERR_INVALID, "too many entities (%llu)", (unsigned long long)n);
     DeviceGuard guard(w->device);
 
+    // An entity that loses its Transform while its body exists keeps a slot for the body (kValid clear): the reference keeps
+    // stepping that Bullet body (PhysicsSystem.cpp:389-393).  To the hierarchy it is an entity without a Transform: it is
+    // nobody's effective parent and has none itself.
+    std::vector<uint8_t> orphan(n, 0);
+    bool any_orphan = false;
+    if (w->has_topology && has_transform) {
+        const uint64_t lim = std::min<uint64_t>(n, w->flat.n_entities);
+        for (uint64_t i = 0; i < lim; ++i) {
+            const bool was_orphan = i < w->orphan_host.size() && w->orphan_host[i];
+            const bool created = was_orphan || (i < w->body_since.size() && w->physics_updates > w->body_since[i]);
+            if (!has_transform[i] && w->flat.slot_of_entity[i] != bge::kNone && i < w->body_type_host.size() &&
+                w->body_type_host[i] != BGE_BODY_NONE && created) {
+                orphan[i] = 1;
+                any_orphan = true;
+            }
+        }
+    }
+    std::vector<uint32_t> parent_flat;
+    std::vector<uint8_t> tf_flat;
+    if (any_orphan) {
+        parent_flat.assign(n, bge::kNone);
+        tf_flat.assign(n, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            tf_flat[i] = (has_transform[i] || orphan[i]) ? 1 : 0;
+            const uint32_t p = parent ? parent[i] : bge::kNone;
+            if (!orphan[i] && p != bge::kNone && p < n && !orphan[p]) parent_flat[i] = p;
+        }
+    }
     bge::Flattened nf;
     try {
-        bge::flatten_topology(n, parent, has_transform, nf);
+        bge::flatten_topology(n, any_orphan ? parent_flat.data() : parent, any_orphan ? tf_flat.data() : has_transform, nf);
     } catch (const std::bad_alloc&) {
         return fail(BGE_ERR_OOM, "host allocation failed while flattening %llu entities", (unsigned long long)n);
+    }
+    if (any_orphan) {
+        for (uint64_t i = 0; i < n; ++i) {
+            if (orphan[i]) nf.flags[nf.slot_of_entity[i]] &= ~bge::kValid;
+        }
     }
 
     // ---- carry component state of surviving entity indices over to the new layout
@@ -658,9 +697,12 @@ try {
     bool any_frozen = false;
     for (uint64_t i = 0; i < n_keep; ++i) {
         if (keep_mask[i] != 1 || (old_flags[i] & bge::kTDirty)) continue;
+        if (orphan[i]) continue;                    // (a body without a Transform has no world matrix to keep)
         const uint32_t p = raw_new[i];
-        if (p == bge::kNone || nf.slot_of_entity[p] != bge::kNone) continue; // no parent entity, or it owns a Transform (again)
-        const bool parent_had_transform = p < w->flat.n_entities && w->flat.slot_of_entity[p] != bge::kNone;
+        const bool parent_owns_transform = p != bge::kNone && nf.slot_of_entity[p] != bge::kNone && !orphan[p];
+        if (p == bge::kNone || parent_owns_transform) continue; // no parent entity, or it owns a Transform (again)
+        const bool parent_had_transform = p < w->flat.n_entities && w->flat.slot_of_entity[p] != bge::kNone &&
+                                          !(p < w->orphan_host.size() && w->orphan_host[p]);
         if (!parent_had_transform && !was_frozen[i]) continue;
         if (frozen_bits.empty()) frozen_bits.assign((std::max<uint64_t>(nf.n_slots, bge::kTile) + 31) / 32, 0u);
         const uint32_t sl = nf.slot_of_entity[i];
@@ -753,6 +795,7 @@ try {
             const uint32_t s = nf.slot_of_entity[i];
             uint32_t f = (nf.flags[s] & ~keep_bits) | (old_flags[i] & keep_bits);
             if (keep_mask[i] == 2) f |= bge::kTDirty;
+            if (orphan[i]) f &= ~(bge::kValid | bge::kTDirty); // the body's slot: no Transform here, nothing to be dirty
             merged[s] = f;
         }
         HIP_TRY(hipMemcpyAsync(w->flags.p, merged.data(), nf.n_slots * 4, hipMemcpyHostToDevice, w->stream));
@@ -769,6 +812,7 @@ try {
     }
     w->any_frozen = any_frozen;
     w->flat = std::move(nf);
+    w->orphan_host.swap(orphan);
     w->body_type_host.resize(n, BGE_BODY_NONE); // surviving indices keep their body, new ones have none
     for (uint64_t i = 0; i < n; ++i) {
         if (w->flat.slot_of_entity[i] == bge::kNone) w->body_type_host[i] = BGE_BODY_NONE; // no Transform, no body
@@ -790,16 +834,16 @@ static int upload_trs_impl(bge_world* w, uint64_t first, uint64_t count, const u
     const uint32_t* di = nullptr;
     if (int rc = stage_index(w, count, index, &di)) return rc;
     if (pos3) {
-        if (int rc = upload_rows(w, first, count, 3, pos3, w->pos.p, 0, di)) return rc;
+        if (int rc = upload_rows(w, first, count, 3, pos3, w->pos.p, 0, di, bge::kValid)) return rc;
     }
     if (euler3) {
-        if (int rc = upload_rows(w, first, count, 3, euler3, w->euler.p, 0, di)) return rc;
+        if (int rc = upload_rows(w, first, count, 3, euler3, w->euler.p, 0, di, bge::kValid)) return rc;
     }
     if (scale3) {
-        if (int rc = upload_rows(w, first, count, 3, scale3, w->scale.p, 0, di)) return rc;
+        if (int rc = upload_rows(w, first, count, 3, scale3, w->scale.p, 0, di, bge::kValid)) return rc;
     }
     HIP_TRY(bge::launch_scatter_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, 0, nullptr, nullptr,
-                                     w->flags.as<uint32_t>(), bge::kTDirty, di));
+                                     w->flags.as<uint32_t>(), bge::kTDirty, di, bge::kValid));
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->maybe_dirty = true;
     return BGE_OK;
@@ -828,7 +872,7 @@ try {
     if (count == 0) return BGE_OK;
     DeviceGuard guard(w->device);
     HIP_TRY(bge::launch_scatter_rows(w->stream, w->slot_of_entity.as<uint32_t>(), first, count, 0, nullptr, nullptr,
-                                     w->flags.as<uint32_t>(), bge::kTDirty));
+                                     w->flags.as<uint32_t>(), bge::kTDirty, nullptr, bge::kValid));
     w->maybe_dirty = true;
     return BGE_OK;
 }
@@ -899,7 +943,15 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
         }
         {
             const uint64_t e = index ? index[i] : first + i;
-            if (e < w->body_type_host.size()) w->body_type_host[e] = w->flat.slot_of_entity[e] == bge::kNone ? BGE_BODY_NONE : t;
+            const bool orphan = e < w->orphan_host.size() && w->orphan_host[e];
+            if (e < w->body_type_host.size() && !(orphan && t != BGE_BODY_NONE)) {
+                const uint8_t now = w->flat.slot_of_entity[e] == bge::kNone ? BGE_BODY_NONE : t;
+                if (w->body_type_host[e] == BGE_BODY_NONE && now != BGE_BODY_NONE) {
+                    if (w->body_since.size() < w->body_type_host.size()) w->body_since.resize(w->body_type_host.size(), 0);
+                    w->body_since[e] = w->physics_updates; // not in the reference's world before the next update
+                }
+                w->body_type_host[e] = now;
+            }
         }
         collider_half_extents(sh, sz, he + 3 * i);
         const uint32_t l = layer ? layer[i] : 1u;
@@ -1022,6 +1074,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
     }
     const bool phys = (flags & BGE_TICK_PHYSICS) != 0;
     const bool xform = (flags & BGE_TICK_TRANSFORMS) != 0;
+    if (phys) w->physics_updates += ticks; // (bodies uploaded before this call are in the world from now on)
     if (phys && (w->grav_palette_stale || gravity[0] != w->grav_cached[0] || gravity[1] != w->grav_cached[1] ||
                  gravity[2] != w->grav_cached[2] || std::memcmp(gravity, w->grav_cached, 12) != 0)) {
         // btRigidBody::setGravity: m_gravity = acceleration / m_inverseMass, one IEEE division per component (the same
@@ -1307,6 +1360,7 @@ try {
         sub.ghosts_posed = true;
     }
     if (run == 0) {
+        w->physics_updates += 1; // EnsureRigidBody runs in every PhysicsSystem::Update, sub-steps or not
         // no sub-step: no collision detection, no integration — but the calls around stepSimulation still run
         if (!w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
         DeviceGuard guard(w->device);

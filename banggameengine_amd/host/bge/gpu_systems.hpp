@@ -299,7 +299,8 @@ private:
     bool RefreshTopology(SceneT& scene)
     {
         auto& transforms = scene.GetTransforms();
-        bool changed = transforms.size() != live_;
+        bool changed = transforms.size() != live_ || topology_stale_;
+        topology_stale_ = false;
         if (!changed) {
             for (auto& kv : transforms) {
                 auto it = index_of_.find(kv.first);
@@ -317,19 +318,46 @@ private:
         for (auto it = index_of_.begin(); it != index_of_.end();) {
             if (!scene.HasTransform(it->first)) {
                 has_tf_[it->second] = 0;
-                ids_[it->second] = 0;
-                body_[it->second] = BodyState{};
-                free_.push_back(it->second);
-                is_free_[it->second] = 1;
-                retired_[it->first] = it->second;
+                if (body_[it->second].exists && scene.GetRigidBody(it->first) && scene.GetCollider(it->first)) {
+                    // The entity lost its Transform but keeps its body components: the reference keeps stepping the Bullet body
+                    // (EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393).  The index stays the
+                    // entity's — the world keeps the body on it — until the components go (UploadBodies) or the Transform returns.
+                    orphan_of_[it->first] = it->second;
+                } else {
+                    // (the world keeps the body of an index that merely loses its Transform: one whose components went too —
+                    //  a destroyed entity — is taken out explicitly, while its slot still exists)
+                    if (body_[it->second].exists) gone_bodies_.push_back(it->second);
+                    ids_[it->second] = 0;
+                    body_[it->second] = BodyState{};
+                    free_.push_back(it->second);
+                    is_free_[it->second] = 1;
+                    retired_[it->first] = it->second;
+                }
                 it = index_of_.erase(it);
             } else {
                 ++it;
             }
         }
+        if (!gone_bodies_.empty()) {
+            const std::vector<uint8_t> none(gone_bodies_.size(), BGE_BODY_NONE);
+            if (bge_world_upload_bodies_indexed(world_, gone_bodies_.size(), gone_bodies_.data(), none.data(), nullptr, nullptr, nullptr, nullptr,
+                                                nullptr) != BGE_OK) {
+                return Log("bge_world_upload_bodies_indexed (bodies of entities that are gone)");
+            }
+            gone_bodies_.clear();
+        }
         // first the ids that come back, so that nobody else takes their index
         for (auto& kv : transforms) {
             if (index_of_.count(kv.first)) continue;
+            auto o = orphan_of_.find(kv.first);
+            if (o != orphan_of_.end()) { // the Transform returns to a body that lived on without one: same index, body state kept
+                const uint32_t i = o->second;
+                has_tf_[i] = 1;
+                written_[i] = 0;
+                index_of_[kv.first] = i;
+                orphan_of_.erase(o);
+                continue;
+            }
             auto r = retired_.find(kv.first);
             if (r == retired_.end() || !is_free_[r->second]) continue;
             const uint32_t i = r->second;
@@ -390,6 +418,8 @@ private:
             // parent index (has_transform = 0 there) for as long as nobody else has taken it: bge_world_set_topology then sees
             // an unchanged parent entity that lost its Transform — it neither marks the child dirty nor recomputes its world
             // matrix, as the reference does not (Scene::RemoveTransform marks nobody) — instead of a changed parent.
+            auto o = orphan_of_.find(p);
+            if (o != orphan_of_.end()) return o->second; // (its body still holds the index)
             auto r = retired_.find(p);
             return (r != retired_.end() && is_free_[r->second]) ? r->second : BGE_NO_PARENT;
         }
@@ -444,7 +474,13 @@ private:
         for (auto& kv : scene.GetRigidBodies()) {
             auto it = index_of_.find(kv.first);
             auto* col = scene.GetCollider(kv.first);
-            if (it == index_of_.end() || !col) continue;
+            if (it == index_of_.end()) {
+                // no Transform: nothing is (re)created (its dirty flags wait); a body that lives on without one stays as it is
+                auto o = orphan_of_.find(kv.first);
+                if (o != orphan_of_.end() && col) seen_[o->second] = 1;
+                continue;
+            }
+            if (!col) continue;
             const uint32_t i = it->second;
             seen_[i] = 1;
             auto& rb = kv.second;
@@ -472,6 +508,14 @@ private:
                 b_mask_.push_back(0xffffffffu);
                 b_friction_.push_back(0.5f);
                 body_[i].exists = false;
+                if (!has_tf_[i] && ids_[i] != 0) { // the body of an entity without a Transform is gone: the index goes too
+                    orphan_of_.erase(ids_[i]);
+                    retired_[ids_[i]] = i;
+                    ids_[i] = 0;
+                    free_.push_back(i);
+                    is_free_[i] = 1;
+                    topology_stale_ = true;
+                }
             }
         }
         if (index_list_.empty()) return true;
@@ -489,9 +533,11 @@ private:
     std::vector<Id> ids_;                       // dense index -> EntityId (0 = free)
     std::vector<Id> last_ids_;                  // dense index -> the id it last belonged to
     std::unordered_map<Id, uint32_t> index_of_;
-    std::vector<uint32_t> parent_, free_, fresh_, index_list_;
+    std::vector<uint32_t> parent_, free_, fresh_, index_list_, gone_bodies_;
     std::vector<uint8_t> has_tf_, written_, limbo_, seen_, is_free_;
     std::unordered_map<Id, uint32_t> retired_;  // last index of ids that lost their Transform
+    std::unordered_map<Id, uint32_t> orphan_of_; // ids without a Transform whose body lives on, on the index they had
+    bool topology_stale_ = false;               // an index was given up outside RefreshTopology
     std::vector<BodyState> body_;
     std::vector<float> last_pose_;              // position + euler the physics write-back stored (6 floats per index)
     std::vector<float> last_scale_;             // scale as last uploaded (3 floats per index)

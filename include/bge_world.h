@@ -123,6 +123,18 @@ BGE_API void bge_world_destroy(bge_world* world);
  * Entities in a parent cycle are never reached by the reference's DFS; they are kept, never updated,
  * and stay dirty.  Calling this again re-flattens and keeps all component state of surviving indices.
  * All Transforms start dirty with TRS = (0, 0, 1) as a default-constructed Transform (Transform.h:14-16).
+ * On a live world the call also does what the reference's scene edits do to what stays:
+ *   - a changed parent ENTITY marks the child's subtree dirty, through Transform-less entities too (Scene::SetParent ->
+ *     MarkHierarchyDirty, Scene.cpp:354-393, 535-550);
+ *   - a clean Transform whose parent entity stays but lost its Transform becomes a root WITHOUT being marked, and keeps its
+ *     world matrix until something marks it (Scene::RemoveTransform marks nobody; TransformSystem::Update recomputes a node
+ *     only when it or an ancestor is dirty);
+ *   - an entity that loses its Transform while its body is in the world (uploaded, and a physics tick has run since) keeps
+ *     the body: it is stepped, collides and enters trigger volumes as before, is never re-posed or re-created, nothing is
+ *     written back, and uploads of Transform or body data to it are ignored — except BGE_BODY_NONE, which removes it
+ *     (PhysicsSystem::EnsureRigidBody returns before it looks at the runtime of an entity without a Transform,
+ *     PhysicsSystem.cpp:389-393, and only the RigidBody component's removal takes the body out).  A caller that drops an
+ *     entity altogether uploads BGE_BODY_NONE for it before the call.
  */
 BGE_API int bge_world_set_topology(bge_world* world, uint64_t n, const uint32_t* parent, const uint8_t* has_transform);
 

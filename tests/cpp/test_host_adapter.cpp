@@ -85,7 +85,7 @@ struct Pair {
         for (const auto& e : gpuPhysics.TriggerEvents(gpu)) b.push_back({static_cast<uint32_t>(e.type), e.trigger, e.other});
         std::sort(a.begin(), a.end());
         std::sort(b.begin(), b.end());
-        CHECK(a == b, "trigger events differ: %zu (oracle) vs %zu (gpu)", a.size(), b.size());
+        CHECK(a == b, "tick %d: trigger events differ: %zu (oracle) vs %zu (gpu)", ticks, a.size(), b.size());
         if (a != b) {
             std::vector<std::array<uint32_t, 3>> only_a, only_b;
             std::set_difference(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(only_a));
@@ -248,8 +248,8 @@ int main(int argc, char** argv)
 
     // Transforms removed from live parents, and given back.  Scene::RemoveTransform marks nobody: the children become roots
     // (Scene.cpp:528) but TransformSystem::Update recomputes a node only when it or an ancestor is dirty, so a clean child keeps
-    // its parent * local world matrix, and a child with a body is NOT re-posed.  (The RigidBody goes first: the reference keeps
-    // stepping the Bullet body of an entity that lost only its Transform, this library drops it — DESIGN.md 7.)
+    // its parent * local world matrix, and a child with a body is NOT re-posed.  A body on the parent itself lives on without the
+    // Transform (the reference keeps stepping it; so does the world, on the index the entity had).
     {
         std::vector<uint32_t> parents;
         for (auto& kv : w.ref.GetTransforms()) {
@@ -262,8 +262,7 @@ int main(int argc, char** argv)
                 const auto* t = w.ref.GetTransform(c);
                 clean_children += t && !t->dirty;
             }
-            w.ref.RemoveRigidBody(id); w.gpu.RemoveRigidBody(id);
-            w.ref.RemoveTransform(id); w.gpu.RemoveTransform(id);
+            w.ref.RemoveTransform(id); w.gpu.RemoveTransform(id); // (a body on it lives on: the reference keeps stepping it)
         }
         CHECK(clean_children > 0, "no clean child under the parents that lose their Transform");
         for (int k = 0; k < 3; ++k) w.Tick();
@@ -462,7 +461,6 @@ int main(int argc, char** argv)
             } else if (op == 6) {
                 if (w.ref.GetTransform(id)) {
                     if (w.ref.GetTriggerVolume(id)) continue;
-                    w.ref.RemoveRigidBody(id); w.gpu.RemoveRigidBody(id);
                     w.ref.RemoveTransform(id); w.gpu.RemoveTransform(id);
                 } else {
                     float p[3], e[3], s[3];

@@ -114,6 +114,11 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
             w.upload_friction(friction)
             w.set_ground_plane(True)
         parent = wl.parent.copy()
+        updates_done = 0                               # PhysicsSystem::Update calls so far
+        body_born = np.zeros(1 << 16, np.int64)        # updates_done when the entity's body components were put on a Transform owner:
+        #                                                the body is in the world after the NEXT update (EnsureRigidBody)
+        kept_body = np.zeros(1 << 16, bool)            # the entity lost its Transform while its body was in the world (it lives on)
+        body_edit_pending = np.zeros(1 << 16, bool)    # ... and its body components were edited since
         most_asleep = 0
         gravity_y = -9.81
         for tick in range(n_ticks):
@@ -141,11 +146,13 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                 first, cnt = int(rng.integers(n_bare, n - 30)), int(rng.integers(1, 30))
                 for e in range(first, first + cnt):
                     ref.MarkBodyDirty(e + 1)
+                    body_edit_pending[e] |= not has_transform[e]
                 w.upload_bodies(wl.body_type[first:first + cnt], first=first, **{k: v[first:first + cnt] for k, v in body_kw.items()})
             elif what == "change":
                 # other components on the same entities: type (incl. none: the body is removed), collider, mass, filter
                 first, cnt = int(rng.integers(n_bare, n - 30)), int(rng.integers(1, 30))
                 sl = slice(first, first + cnt)
+                was_none = wl.body_type[sl] == 255
                 wl.body_type[sl] = rng.choice([255, 0, 1, 1, 2], cnt).astype(np.uint8)
                 shape[sl] = rng.choice([0, 1], cnt).astype(np.uint8)
                 size[sl] = rng.uniform(0.1, 1.2, (cnt, 3)).astype(np.float32)
@@ -153,8 +160,12 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                 layer[sl] = rng.choice([1, 2, 4], cnt).astype(np.uint32)
                 mask[sl] = rng.choice([0xFFFFFFFF, 0xFFFFFFFD, 5], cnt).astype(np.uint32)
                 for e in range(first, first + cnt):
+                    body_edit_pending[e] |= not has_transform[e]
+                    if was_none[e - first] and wl.body_type[e] != 255 and has_transform[e]:
+                        body_born[e] = updates_done
                     if wl.body_type[e] == 255:
                         ref.RemoveRigidBody(e + 1)
+                        kept_body[e] = False
                     else:
                         ref.AddCollider(e + 1, int(shape[e]), size[e])
                         ref.AddRigidBody(e + 1, int(wl.body_type[e]), float(mass[e]), int(layer[e]), int(mask[e]))
@@ -189,13 +200,12 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                     if trig is not None and e in trig[0]:
                         continue
                     if has_transform[e]:
-                        # (the RigidBody goes first: the reference keeps stepping the Bullet body of an entity that lost only its
-                        #  Transform — EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393 — where this
-                        #  library drops the body with the Transform; DESIGN.md 7, a documented difference)
-                        ref.RemoveRigidBody(e + 1)
-                        wl.body_type[e] = 255
+                        # (a RigidBody on the entity stays: the reference keeps stepping the Bullet body of an entity that lost only
+                        #  its Transform — EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393 — and
+                        #  so does the world: the body keeps its slot, collides, enters triggers, and is never re-created)
                         ref.RemoveTransform(e + 1)
                         has_transform[e] = 0
+                        kept_body[e] = wl.body_type[e] != 255 and updates_done > body_born[e]
                         w.set_topology(parent, has_transform)
                     else:
                         p3 = rng.uniform(-side, side, (1, 3)).astype(np.float32)
@@ -207,10 +217,15 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                         has_transform[e] = 1
                         w.set_topology(parent, has_transform)
                         w.upload_trs(p3, e3, s3, first=e)
-                        if wl.body_type[e] != 255 and e >= n_bare:
+                        if wl.body_type[e] != 255 and e >= n_bare and (not kept_body[e] or body_edit_pending[e]):
+                            # a body that never existed on the device (the entity had no Transform when it was uploaded), or whose
+                            # components changed while it had none: the reference (re)creates it now, dirty as it still is
                             w.upload_bodies(wl.body_type[e:e + 1], first=e, **{k: v[e:e + 1] for k, v in body_kw.items()})
                             if ground:
                                 w.upload_friction(friction[e:e + 1], first=e)
+                            if not kept_body[e]:
+                                body_born[e] = updates_done
+                        kept_body[e] = body_edit_pending[e] = False
             elif what == "gravity" and not ground:
                 # another gravity (the per-class force table is rebuilt); not with the plane: bodies sleep there, and Bullet's
                 # setGravity skips sleepers where this library takes gravity per tick
@@ -248,6 +263,7 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                 w.upload_bodies(bt, first=n, **grown)
                 if ground:
                     w.upload_friction(np.full(add, 0.5, np.float32), first=n)
+                body_born[n:n + add] = updates_done
                 wl.body_type = np.concatenate([wl.body_type, bt])
                 mass, shape, size, layer, mask = (np.concatenate([body_kw[k], grown[k]]) for k in ("mass", "shape", "size", "layer", "mask"))
                 body_kw = dict(mass=mass, shape=shape, size=size, layer=layer, mask=mask)
@@ -272,19 +288,23 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
             if clock:
                 dt = float(np.float64(rng.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.5, 5.5])) * np.float64(DT))
                 ref.PhysicsSystemUpdate(dt)
+                updates_done += 1
                 got_n = w.step_simulation(dt, 4, DT, gravity=(0.0, gravity_y, 0.0), flags=flags)
                 assert got_n == ref.LastSubSteps(), f"tick {tick}: {got_n} sub-steps, oracle {ref.LastSubSteps()}"
             elif split:
                 ref.PhysicsSystemUpdate(DT)
+                updates_done += 1
                 w.tick(dt=DT, gravity=(0.0, gravity_y, 0.0), flags=flags & ~(B.TICK_TRANSFORMS | B.TICK_NORMAL_MATRICES))
-                assert_bits_equal(w.download_pose()[0], ref.bulk_pose()[0], f"seed {seed} tick {tick}: position after the physics call")
-                assert np.array_equal(w.download_dirty(), ref.bulk_world()[1].astype(bool)), f"seed {seed} tick {tick}: dirty after the physics call"
+                tf_now = has_transform.astype(bool)
+                assert_bits_equal(w.download_pose()[0][tf_now], ref.bulk_pose()[0][tf_now], f"seed {seed} tick {tick}: position after the physics call")
+                assert np.array_equal(w.download_dirty()[tf_now], ref.bulk_world()[1].astype(bool)[tf_now]), f"seed {seed} tick {tick}: dirty after the physics call"
                 w.tick(dt=DT, flags=B.TICK_TRANSFORMS | (B.TICK_NORMAL_MATRICES if normals else 0))
                 got_n = 1
             else:
                 reps = 1 if not style_b or trig or rng.random() < 0.7 else int(rng.integers(2, 5))   # several ticks in one call
                 for _ in range(reps):
                     ref.PhysicsSystemUpdate(DT)
+                    updates_done += 1
                     if _ + 1 < reps:
                         ref.TransformSystemUpdate()
                 w.tick(dt=DT, gravity=(0.0, gravity_y, 0.0), flags=flags, ticks=reps)
@@ -293,15 +313,15 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
 
             # ---- everything observable
             tag = f"seed {seed} tick {tick} (after {what})"
+            tf = has_transform.astype(bool)
             pos, euler = w.download_pose()
             rpos, reuler = ref.bulk_pose()
-            assert_bits_equal(pos, rpos, f"{tag}: position")
-            assert_bits_equal(euler, reuler, f"{tag}: rotationEuler")
+            assert_bits_equal(pos[tf], rpos[tf], f"{tag}: position")
+            assert_bits_equal(euler[tf], reuler[tf], f"{tag}: rotationEuler")
             want_world, want_dirty = ref.bulk_world()
-            assert_bits_equal(w.download_world(), want_world, f"{tag}: world")
-            assert np.array_equal(w.download_dirty(), want_dirty.astype(bool)), f"{tag}: dirty flags"
+            assert_bits_equal(w.download_world()[tf], want_world[tf], f"{tag}: world")
+            assert np.array_equal(w.download_dirty()[tf], want_dirty.astype(bool)[tf]), f"{tag}: dirty flags"
             if normals:
-                tf = has_transform.astype(bool)
                 assert_bits_equal(w.download_normal()[tf], po.normal_matrices(want_world)[tf], f"{tag}: normal matrices")
             assert w.dirty_count() == ref.CountDirtyTransforms(), f"{tag}: CountDirtyTransforms"
             rb, gb = ref.bulk_bodies(), w.download_bodies()
