@@ -25,6 +25,7 @@ namespace bge {
 
 constexpr uint32_t kTile = 256;
 constexpr uint32_t kNone = 0xffffffffu;
+constexpr uint32_t kFrozenGhost = 0xfffffffeu; // TriggerView::slot: the entity lost its Transform, the ghost keeps the box it has
 
 // per-slot flag word (also the device encoding)
 constexpr uint32_t kTypeMask = 0x3u;     // 0 none, 1 Static, 2 Dynamic, 3 Kinematic  (= bge_body_type + 1)

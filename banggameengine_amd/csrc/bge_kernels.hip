@@ -847,6 +847,7 @@ __global__ void k_trigger_aabb(uint32_t n_triggers, TriggerView t, WorldView w)
     if (i >= n_triggers) return;
     const uint32_t slot = t.slot[i];
     float* bb = t.aabb + 6ull * i;
+    if (slot == kFrozenGhost) return; // posed for the last time before its entity lost its Transform
     if (slot == kNone || !t.active[i]) {
         // an inactive ghost is not in the world: an empty box never overlaps
         bb[0] = bb[1] = bb[2] = INFINITY;

@@ -212,11 +212,21 @@ struct bge_world {
         bool one_shot = false;
         bool component_active = true; // TriggerVolume::active
         bool runtime_active = false;  // ghost is in the world
+        bool posed = false;           // ... and a tick has posed it on the device since
+        // The entity lost its Transform: EnsureTrigger returns before it touches the ghost (PhysicsSystem.cpp:530-534) and nothing
+        // removes it, so the ghost stays in the world where it last was and keeps reporting overlaps.
+        bool frozen = false;
+        float frozen_aabb[6] = {0, 0, 0, 0, 0, 0};
         std::vector<uint32_t> overlaps; // sorted entity indices of the previous tick
     };
+    bool owns_transform(uint32_t e) const
+    {
+        return e < flat.slot_of_entity.size() && flat.slot_of_entity[e] != bge::kNone && !(e < orphan_host.size() && orphan_host[e]);
+    }
     std::vector<Trigger> triggers;
     std::vector<bge_trigger_event> trigger_events; // since the last bge_world_trigger_events
     bool triggers_device_stale = true;
+    bool trig_list_on_device = false; // the device arrays are indexed like `triggers` (false between an upload of the list and the next sync)
     DevBuf trig_slot, trig_entity, trig_he, trig_group, trig_mask, trig_active, trig_aabb, trig_pairs, trig_count, trig_lists;
     uint32_t trigger_grid_min = 64;       // more ghosts than this: the broadphase grid answers for the small ones
     uint32_t trig_through_grid = 0, trig_against_all = 0; // how the last tick split them
@@ -411,11 +421,15 @@ int sync_triggers_to_device(bge_world* w)
     for (size_t i = 0; i < n; ++i) {
         const bge_world::Trigger& t = w->triggers[i];
         entity[i] = t.entity;
-        slot[i] = t.entity < w->flat.slot_of_entity.size() ? w->flat.slot_of_entity[t.entity] : bge::kNone;
+        slot[i] = w->owns_transform(t.entity) ? w->flat.slot_of_entity[t.entity] : bge::kNone;
         collider_half_extents(t.shape, t.size, &he[3 * i]);
         group[i] = t.layer;
         mask[i] = t.mask;
         active[i] = t.runtime_active && slot[i] != bge::kNone ? 1 : 0;
+        if (t.runtime_active && t.frozen) {
+            slot[i] = bge::kFrozenGhost; // k_trigger_aabb leaves its box alone
+            active[i] = 1;
+        }
     }
     HIP_TRY(w->trig_slot.ensure(n * 4));
     HIP_TRY(w->trig_entity.ensure(n * 4));
@@ -432,8 +446,15 @@ int sync_triggers_to_device(bge_world* w)
     HIP_TRY(hipMemcpyAsync(w->trig_group.p, group.data(), n * 4, hipMemcpyHostToDevice, w->stream));
     HIP_TRY(hipMemcpyAsync(w->trig_mask.p, mask.data(), n * 4, hipMemcpyHostToDevice, w->stream));
     HIP_TRY(hipMemcpyAsync(w->trig_active.p, active.data(), n, hipMemcpyHostToDevice, w->stream));
+    for (size_t i = 0; i < n; ++i) {
+        const bge_world::Trigger& t = w->triggers[i];
+        if (t.runtime_active && t.frozen) {
+            HIP_TRY(hipMemcpyAsync(static_cast<char*>(w->trig_aabb.p) + 24 * i, t.frozen_aabb, 24, hipMemcpyHostToDevice, w->stream));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(w->stream)); // the host vectors die here
     w->triggers_device_stale = false;
+    w->trig_list_on_device = true;
     return BGE_OK;
 }
 
@@ -441,10 +462,16 @@ int sync_triggers_to_device(bge_world* w)
 void ensure_triggers(bge_world* w)
 {
     for (bge_world::Trigger& t : w->triggers) {
-        const bool has_tf = t.entity < w->flat.slot_of_entity.size() && w->flat.slot_of_entity[t.entity] != bge::kNone;
+        const bool has_tf = w->owns_transform(t.entity);
+        if (!has_tf && t.runtime_active && t.frozen) continue; // EnsureTrigger returns before it touches the ghost
+        if (has_tf && t.frozen) {                              // the Transform is back: posed from it again
+            t.frozen = false;
+            w->triggers_device_stale = true;
+        }
         const bool want = t.component_active && has_tf;
         if (want != t.runtime_active) {
             t.runtime_active = want;
+            t.posed = false;
             t.overlaps.clear();
             w->triggers_device_stale = true;
         }
@@ -584,6 +611,23 @@ try {
                 w->body_type_host[i] != BGE_BODY_NONE && created) {
                 orphan[i] = 1;
                 any_orphan = true;
+            }
+        }
+    }
+    // A trigger ghost whose entity loses its Transform stays in the world where it was last posed (EnsureTrigger returns before
+    // it touches the ghost, PhysicsSystem.cpp:530-534): its box is fetched now, while the device arrays still describe it.
+    if (w->has_topology && has_transform && !w->triggers.empty()) {
+        for (size_t k = 0; k < w->triggers.size(); ++k) {
+            bge_world::Trigger& t = w->triggers[k];
+            const bool keeps_transform = t.entity < n && has_transform[t.entity];
+            if (keeps_transform || t.frozen || !t.runtime_active) continue;
+            if (t.posed && w->trig_list_on_device && w->trig_aabb.p) {
+                HIP_TRY(hipStreamSynchronize(w->stream));
+                HIP_TRY(hipMemcpy(t.frozen_aabb, static_cast<const char*>(w->trig_aabb.p) + 24 * k, 24, hipMemcpyDeviceToHost));
+                t.frozen = true;
+            } else {
+                t.runtime_active = false; // (never posed: there is no ghost to keep)
+                t.overlaps.clear();
             }
         }
     }
@@ -1198,6 +1242,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
             }
             // ghost boxes from the Transforms as they are before the step
             HIP_TRY(bge::launch_trigger_aabb(w->stream, static_cast<uint32_t>(w->triggers.size()), w->trigger_view(), w->view));
+            for (bge_world::Trigger& tg : w->triggers) tg.posed = tg.posed || (tg.runtime_active && !tg.frozen);
         }
         if (flags & BGE_TICK_BROADPHASE) {
             // the broadphase takes its grid from per-wave partials the tick kernel writes beside the AABBs
@@ -1357,6 +1402,7 @@ try {
             if (int rc = sync_triggers_to_device(w)) return rc;
         }
         HIP_TRY(bge::launch_trigger_aabb(w->stream, static_cast<uint32_t>(w->triggers.size()), w->trigger_view(), w->view));
+        for (bge_world::Trigger& tg : w->triggers) tg.posed = tg.posed || (tg.runtime_active && !tg.frozen);
         sub.ghosts_posed = true;
     }
     if (run == 0) {
@@ -1935,10 +1981,21 @@ try {
                 t.runtime_active = o.runtime_active;
                 t.overlaps.swap(o.overlaps);
             }
+            // (a ghost whose entity has no Transform keeps its place whatever is uploaded: EnsureTrigger does not reach it)
+            t.posed = false;
+            if (o.frozen && o.runtime_active) {
+                t.frozen = true;
+                t.runtime_active = true;
+                std::memcpy(t.frozen_aabb, o.frozen_aabb, 24);
+                t.layer = o.layer;
+                t.mask = o.mask;
+                if (t.overlaps.empty()) t.overlaps.swap(o.overlaps);
+            }
         }
     }
     w->triggers.swap(next);
     w->triggers_device_stale = true;
+    w->trig_list_on_device = false;
     return BGE_OK;
 }
 BGE_CATCH_ALL("bge_world_upload_triggers")

@@ -229,19 +229,41 @@ private:
         auto& vols = scene.GetTriggerVolumes();
         t_entity_.clear(); t_shape_.clear(); t_size_.clear(); t_layer_.clear(); t_mask_.clear(); t_oneshot_.clear(); t_active_.clear();
         bool dirty = false;
+        seen_trigger_.assign(ids_.size(), 0);
         for (auto& kv : vols) {
             auto it = index_of_.find(kv.first);
-            if (it == index_of_.end()) continue; // a trigger needs a Transform (PhysicsSystem.cpp:530-534)
+            uint32_t index;
+            bool without_transform = false;
+            if (it != index_of_.end()) {
+                index = it->second;
+            } else {
+                // a trigger needs a Transform to be created or re-posed (PhysicsSystem.cpp:530-534) — but a ghost whose entity lost
+                // its Transform stays in the world where it was: the entity's index was kept for it (RefreshTopology)
+                auto o = orphan_of_.find(kv.first);
+                if (o == orphan_of_.end() || !has_trigger_[o->second]) continue;
+                index = o->second;
+                without_transform = true;
+            }
+            seen_trigger_[index] = 1;
+            has_trigger_[index] = 1;
             auto& tv = kv.second;
-            t_entity_.push_back(it->second);
+            t_entity_.push_back(index);
             t_shape_.push_back(static_cast<uint8_t>(static_cast<int>(tv.shape)));
             t_size_.push_back(tv.size.x); t_size_.push_back(tv.size.y); t_size_.push_back(tv.size.z);
             t_layer_.push_back(tv.layer);
             t_mask_.push_back(tv.mask);
             t_oneshot_.push_back(tv.oneShot ? 1 : 0);
             t_active_.push_back(tv.active ? 1 : 0);
-            dirty = dirty || tv.dirty;
-            tv.dirty = false;
+            if (!without_transform) { // (EnsureTrigger does not reach the other ones: their dirty flag waits)
+                dirty = dirty || tv.dirty;
+                tv.dirty = false;
+            }
+        }
+        for (uint32_t i = 0; i < ids_.size(); ++i) {
+            if (has_trigger_[i] && !seen_trigger_[i]) { // the component is gone
+                has_trigger_[i] = 0;
+                RetireIfNothingLeft(i);
+            }
         }
         any = !t_entity_.empty();
         // signature of the set: everything that reaches the device
@@ -318,16 +340,24 @@ private:
         for (auto it = index_of_.begin(); it != index_of_.end();) {
             if (!scene.HasTransform(it->first)) {
                 has_tf_[it->second] = 0;
-                if (body_[it->second].exists && scene.GetRigidBody(it->first) && scene.GetCollider(it->first)) {
+                const bool body_lives_on = body_[it->second].exists && scene.GetRigidBody(it->first) && scene.GetCollider(it->first);
+                const bool ghost_lives_on = has_trigger_[it->second] && scene.GetTriggerVolume(it->first);
+                if (!body_lives_on && body_[it->second].exists) {
+                    gone_bodies_.push_back(it->second); // (its components went with the Transform)
+                    body_[it->second] = BodyState{};
+                }
+                if (body_lives_on || ghost_lives_on) {
                     // The entity lost its Transform but keeps its body components: the reference keeps stepping the Bullet body
-                    // (EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393).  The index stays the
-                    // entity's — the world keeps the body on it — until the components go (UploadBodies) or the Transform returns.
+                    // (EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393), and a trigger ghost stays where
+                    // it was (EnsureTrigger returns early too).  The index stays the entity's — the world keeps body and ghost on
+                    // it — until the components go (UploadBodies / UploadTriggers) or the Transform returns.
                     orphan_of_[it->first] = it->second;
                 } else {
                     // (the world keeps the body of an index that merely loses its Transform: one whose components went too —
                     //  a destroyed entity — is taken out explicitly, while its slot still exists)
                     if (body_[it->second].exists) gone_bodies_.push_back(it->second);
                     ids_[it->second] = 0;
+                    has_trigger_[it->second] = 0;
                     body_[it->second] = BodyState{};
                     free_.push_back(it->second);
                     is_free_[it->second] = 1;
@@ -385,6 +415,7 @@ private:
                 parent_.push_back(BGE_NO_PARENT);
                 body_.emplace_back();
                 is_free_.push_back(0);
+                has_trigger_.push_back(0);
                 written_.push_back(0);
                 last_pose_.resize(last_pose_.size() + 6, 0.0f);
                 last_scale_.resize(last_scale_.size() + 3, 0.0f);
@@ -407,6 +438,18 @@ private:
         }
         fresh_.clear();
         return true;
+    }
+
+    // An index kept for an entity without a Transform (its body and / or its trigger ghost live on) is given up when neither is left.
+    void RetireIfNothingLeft(uint32_t i)
+    {
+        if (has_tf_[i] || ids_[i] == 0 || body_[i].exists || has_trigger_[i]) return;
+        orphan_of_.erase(ids_[i]);
+        retired_[ids_[i]] = i;
+        ids_[i] = 0;
+        free_.push_back(i);
+        is_free_[i] = 1;
+        topology_stale_ = true;
     }
 
     uint32_t ParentIndex(SceneT& scene, Id id)
@@ -508,14 +551,7 @@ private:
                 b_mask_.push_back(0xffffffffu);
                 b_friction_.push_back(0.5f);
                 body_[i].exists = false;
-                if (!has_tf_[i] && ids_[i] != 0) { // the body of an entity without a Transform is gone: the index goes too
-                    orphan_of_.erase(ids_[i]);
-                    retired_[ids_[i]] = i;
-                    ids_[i] = 0;
-                    free_.push_back(i);
-                    is_free_[i] = 1;
-                    topology_stale_ = true;
-                }
+                RetireIfNothingLeft(i);
             }
         }
         if (index_list_.empty()) return true;
@@ -534,7 +570,7 @@ private:
     std::vector<Id> last_ids_;                  // dense index -> the id it last belonged to
     std::unordered_map<Id, uint32_t> index_of_;
     std::vector<uint32_t> parent_, free_, fresh_, index_list_, gone_bodies_;
-    std::vector<uint8_t> has_tf_, written_, limbo_, seen_, is_free_;
+    std::vector<uint8_t> has_tf_, written_, limbo_, seen_, is_free_, has_trigger_, seen_trigger_;
     std::unordered_map<Id, uint32_t> retired_;  // last index of ids that lost their Transform
     std::unordered_map<Id, uint32_t> orphan_of_; // ids without a Transform whose body lives on, on the index they had
     bool topology_stale_ = false;               // an index was given up outside RefreshTopology

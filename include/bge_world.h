@@ -134,7 +134,9 @@ BGE_API void bge_world_destroy(bge_world* world);
  *     written back, and uploads of Transform or body data to it are ignored — except BGE_BODY_NONE, which removes it
  *     (PhysicsSystem::EnsureRigidBody returns before it looks at the runtime of an entity without a Transform,
  *     PhysicsSystem.cpp:389-393, and only the RigidBody component's removal takes the body out).  A caller that drops an
- *     entity altogether uploads BGE_BODY_NONE for it before the call.
+ *     entity altogether uploads BGE_BODY_NONE for it before the call;
+ *   - a trigger volume whose entity loses its Transform stays in the world with the box it was last posed to (EnsureTrigger
+ *     returns early as well) until the trigger is removed from the uploaded set or the Transform returns.
  */
 BGE_API int bge_world_set_topology(bge_world* world, uint64_t n, const uint32_t* parent, const uint8_t* has_transform);
 

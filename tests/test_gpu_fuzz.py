@@ -197,8 +197,8 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
                 # a fresh index — the entity's body components are uploaded again
                 for _ in range(int(rng.integers(1, 4))):
                     e = int(rng.integers(0, n))
-                    if trig is not None and e in trig[0]:
-                        continue
+                    if trig is not None and rng.random() < 0.3:
+                        e = int(rng.choice(trig[0]))      # a trigger volume's entity: its ghost stays where it was last posed
                     if has_transform[e]:
                         # (a RigidBody on the entity stays: the reference keeps stepping the Bullet body of an entity that lost only
                         #  its Transform — EnsureRigidBody returns before it looks at the runtime, PhysicsSystem.cpp:389-393 — and
@@ -346,7 +346,11 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
             if trig:
                 want_ev = ref.TriggerEvents()
                 want_ev[:, 1:] -= 1
-                assert np.array_equal(w.trigger_events(), want_ev), f"{tag}: trigger events"
+                got_ev = w.trigger_events()
+                if not np.array_equal(got_ev, want_ev):
+                    a, b = set(map(tuple, got_ev.tolist())), set(map(tuple, want_ev.tolist()))
+                    raise AssertionError(f"{tag}: trigger events: only here {sorted(a - b)[:6]}, only in the oracle {sorted(b - a)[:6]}; "
+                                         f"triggers on {trig[0].tolist()}, Transform-less among them {[int(e) for e in trig[0] if not has_transform[e]]}")
         if n_ticks > 40:
             assert most_asleep > 20, f"seed {seed}: only {most_asleep} bodies ever slept in the long run"
 
