@@ -30,7 +30,9 @@ def _forest(rng, n):
 
 
 @pytest.mark.parametrize("seed", range(64))
-def test_random_scene_and_edit_script_match_oracle_every_tick(seed):
+def test_random_scene_and_edit_script_match_oracle_every_tick(seed, monkeypatch):
+    if seed % 5 == 0:
+        monkeypatch.setenv("BGE_TRIGGER_GRID_MIN", "0")    # the ghosts look their bodies up in the broadphase grid
     rng = np.random.default_rng(1000 + seed)
     # seeds 24..39 and 52..63: larger scenes with long parent chains (tiles that overflow into further passes), hundreds of collision
     # filter combinations (the palette's 32-class and 255-class boundaries), physics and transforms as separate calls (the
