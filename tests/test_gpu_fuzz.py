@@ -176,6 +176,23 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed, monkeypatch)
                 w.upload_bodies(wl.body_type[sl], first=first, **{k: v[sl] for k, v in body_kw.items()})
                 if ground:
                     w.upload_friction(friction[sl], first=first)
+            elif what == "triggers" and trig and rng.random() < 0.5 and has_transform[int(trig[0][0])]:
+                # a trigger volume is retuned: other shape / size (the ghost's shape is rebuilt), maybe another layer or mask (the
+                # ghost is re-added: its remembered overlaps are dropped), one-shot on or off
+                k = 0
+                e = int(trig[0][k])
+                act = ref.TriggerIsActive(e + 1)
+                t1, t2, t3, t4, t5 = (a.copy() for a in trig[1:6])
+                t1[k] = rng.choice([0, 1])
+                t2[k] = rng.uniform(0.5, side / 2, 3).astype(np.float32)
+                if rng.random() < 0.5:
+                    t3[k] = rng.choice([0, 4, 2])
+                    t4[k] = rng.choice([0xFFFFFFFF, 1, 6])
+                t5[k] = rng.random() < 0.3
+                ref.AddTriggerVolume(e + 1, int(t1[k]), t2[k], int(t3[k]), int(t4[k]), bool(t5[k]), bool(act))
+                still_active = np.array([ref.TriggerIsActive(int(x) + 1) for x in trig[0]], np.uint8)
+                trig = (trig[0], t1, t2, t3, t4, t5, still_active)
+                w.upload_triggers(*trig)
             elif what == "triggers" and trig:
                 # one trigger volume goes, another entity gets one
                 te = trig[0]
