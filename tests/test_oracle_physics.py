@@ -253,3 +253,38 @@ def test_ground_plane_off_is_the_free_body_path_bit_for_bit():
     run_oracle(b, wl, 30)
     assert np.array_equal(a.bulk_world()[0].view(np.uint32), b.bulk_world()[0].view(np.uint32))
     assert np.array_equal(a.bulk_bodies()["linvel"].view(np.uint32), b.bulk_bodies()["linvel"].view(np.uint32))
+
+
+def test_body_and_trigger_ghost_live_on_when_the_entity_loses_its_transform():
+    """What the restatement does when an entity loses only its Transform — as the reference's code does, read line by line:
+    EnsureRigidBody and EnsureTrigger both return before they touch the runtime when GetTransform is null
+    (src/physics/PhysicsSystem.cpp:389-393, 530-534), and only a missing COMPONENT makes the prune loops remove one.  So the
+    Bullet body keeps falling (nothing is written back: there is no Transform) and the ghost keeps reporting overlaps from
+    where it was last posed; when the Transform returns — dirty, as AddTransform leaves it — the body is teleported to it and
+    the ghost is posed from it again."""
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, True)
+    faller = ref.CreateEntity()
+    ref.AddTransform(faller, pos=(0.0, 10.0, 0.0))
+    ref.AddCollider(faller, 0, (0.5, 0.5, 0.5))
+    ref.AddRigidBody(faller, po.BODY_DYNAMIC, 1.0)
+    zone = ref.CreateEntity()
+    ref.AddTransform(zone, pos=(0.0, 5.0, 0.0))
+    ref.AddTriggerVolume(zone, 0, (3.0, 1.0, 3.0))
+    dt = 1.0 / 120.0
+    for _ in range(3):
+        ref.PhysicsSystemUpdate(dt)
+    y0 = ref.GetBody(faller)["origin"][1]
+    ref.RemoveTransform(faller)
+    ref.RemoveTransform(zone)
+    seen = set()
+    for _ in range(200):
+        ref.PhysicsSystemUpdate(dt)
+        seen |= {tuple(e) for e in ref.TriggerEvents().tolist()}
+    body = ref.GetBody(faller)
+    assert body is not None and body["origin"][1] < y0 - 10.0          # it fell on, through where the ghost still is
+    assert (0, zone, faller) in seen and (2, zone, faller) in seen     # Enter and Exit from a ghost without a Transform
+    ref.AddTransform(faller, pos=(1.0, 20.0, 1.0))
+    ref.PhysicsSystemUpdate(dt)
+    body = ref.GetBody(faller)
+    assert abs(body["origin"][1] - 20.0) < 0.01 and np.allclose(body["linvel"], [0.0, -9.81 * dt, 0.0], atol=1e-6)
