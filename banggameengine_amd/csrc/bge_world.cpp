@@ -1414,10 +1414,17 @@ try {
                                       (flags & BGE_TICK_BULLET_BASIS) != 0));
         w->maybe_dirty = true;
         if (triggers) {
-            // the ghosts' pair caches did not change: ProcessTriggerEvents sees last call's overlaps again -> Stay
+            // the ghosts' pair caches did not change: ProcessTriggerEvents sees last call's overlaps again -> Stay, and a
+            // volume that was made one-shot since fires on them (PhysicsSystem.cpp:1062-1072)
             for (bge_world::Trigger& t : w->triggers) {
                 if (!t.runtime_active) continue;
                 for (uint32_t other : t.overlaps) w->trigger_events.push_back(bge_trigger_event{1u, t.entity, other});
+                if (t.one_shot && !t.overlaps.empty()) {
+                    t.component_active = false;
+                    t.runtime_active = false;
+                    t.overlaps.clear();
+                    w->triggers_device_stale = true;
+                }
             }
         }
         const uint32_t rest = flags & (BGE_TICK_TRANSFORMS | BGE_TICK_NORMAL_MATRICES | BGE_TICK_GATHER_ROOTS);

@@ -698,22 +698,29 @@ def test_step_simulation_clock_matches_oracle(basis):
     script = [1.0, 0.5, 0.5, 0.5, 2.5, 2.5, 6.0, 0.25, 0.25, 0.25, 0.25, 1.0, 0.3, 3.7, 0.1, 0.95, 1.0]
     for fused in (True, False):
         ref = build_oracle(wl, orient_mode=mode, aabbs=True)
+        oneshot = t_oneshot.copy()
         for k in range(12):
-            ref.AddTriggerVolume(int(trig_entities[k]) + 1, 0, t_size[k], 0, 0xFFFFFFFF, bool(t_oneshot[k]), True)
+            ref.AddTriggerVolume(int(trig_entities[k]) + 1, 0, t_size[k], 0, 0xFFFFFFFF, bool(oneshot[k]), True)
         ref.SetAccumulator(True, fixed, 4)
         counts = []
         with B.World(pair_capacity=64 * n) as w:
             w.load(wl)
-            w.upload_triggers(trig_entities, None, t_size, None, None, t_oneshot, None)
+            w.upload_triggers(trig_entities, None, t_size, None, None, oneshot, None)
             for call, factor in enumerate(script):
                 dt = float(np.float64(factor) * np.float64(fixed))
-                if call in (2, 8):   # inside calls that simulate nothing: a teleport and a re-created body
+                if call in (3, 9):   # inside calls that simulate nothing: a teleport and a re-created body
                     e = int(roots[5 + call])
                     new_pos = np.array([[1.0, 9.0 + call, -2.0]], np.float32)
                     ref.SetTRS(e + 1, pos=new_pos[0])
                     w.upload_trs(pos=new_pos, first=e)
                     ref.MarkBodyDirty(int(roots[40]) + 1)
                     w.upload_bodies(wl.body_type[roots[40]:roots[40] + 1], first=int(roots[40]))
+                if call == 9:        # ... and half the volumes are made one-shot: those with remembered overlaps fire in this call
+                    act = np.array([ref.TriggerIsActive(int(e) + 1) for e in trig_entities], np.uint8)
+                    oneshot[::2] = 1
+                    for k in range(12):
+                        ref.AddTriggerVolume(int(trig_entities[k]) + 1, 0, t_size[k], 0, 0xFFFFFFFF, bool(oneshot[k]), bool(act[k]))
+                    w.upload_triggers(trig_entities, None, t_size, None, None, oneshot, act)
                 ref.PhysicsSystemUpdate(dt)
                 if fused:
                     got_n = w.step_simulation(dt, 4, fixed, flags=B.TICK_ALL | B.TICK_BROADPHASE | bflag)
@@ -744,6 +751,12 @@ def test_step_simulation_clock_matches_oracle(basis):
                 want_ev = ref.TriggerEvents()
                 want_ev[:, 1:] -= 1
                 assert np.array_equal(w.trigger_events(), want_ev), f"call {call}: trigger events"
+                want_act = np.array([ref.TriggerIsActive(int(e) + 1) for e in trig_entities], np.uint8)
+                assert np.array_equal(w.trigger_active(trig_entities), want_act), f"call {call}: TriggerVolume::active"
+                if call in (3, 9):
+                    assert got_n == 0
+                if call == 9:
+                    assert int(act.sum() - want_act.sum()) >= 1, (act, want_act)
         assert counts.count(0) >= 6 and max(counts) == 6 and 2 in counts and 3 in counts, counts
 
 
