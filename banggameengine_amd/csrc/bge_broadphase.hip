@@ -899,6 +899,28 @@ __global__ void __launch_bounds__(kSortThreads, 1)
         // 1. this thread's records, in registers
         float4 rec[PT][RS];
         uint32_t bkt[PT];
+        // (every load of the pass issued before the first use: left to itself the compiler sinks each slot's AABB loads below its
+        //  flag test and the entity / class loads below the size test — three dependent round trips per slot, slot after slot)
+        uint32_t fl_[PT], ent_[PT], extra_[PT], msk_[COMPACT ? 1 : PT];
+        float2 b0_[PT], b1_[PT], b2_[PT];
+#pragma unroll
+        for (uint32_t k = 0; k < PT; ++k) {
+            const uint64_t s = min(pass + static_cast<uint64_t>(k) * kSortThreads + tid, end - 1u);
+            fl_[k] = flags[s];
+            const float2* bp = reinterpret_cast<const float2*>(aabb + 6 * s);
+            b0_[k] = bp[0];
+            b1_[k] = bp[1];
+            b2_[k] = bp[2];
+            ent_[k] = entity_of_slot[s];
+            extra_[k] = COMPACT ? class_of_slot[s] : group[s];
+            if (!COMPACT) msk_[k] = mask[s];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PT; ++k) {
+            asm volatile("" : "+v"(fl_[k]), "+v"(ent_[k]), "+v"(extra_[k]), "+v"(b0_[k].x), "+v"(b0_[k].y), "+v"(b1_[k].x), "+v"(b1_[k].y),
+                         "+v"(b2_[k].x), "+v"(b2_[k].y));
+            if (!COMPACT) asm volatile("" : "+v"(msk_[k]));
+        }
 #pragma unroll
         for (uint32_t k = 0; k < PT; ++k) {
             const uint64_t s = pass + static_cast<uint64_t>(k) * kSortThreads + tid;
@@ -906,12 +928,11 @@ __global__ void __launch_bounds__(kSortThreads, 1)
 #pragma unroll
             for (uint32_t q = 0; q < RS; ++q) rec[k][q] = make_float4(0, 0, 0, 0);
             if (s < end) {
-                const uint32_t f = flags[s];
-                const float2* bp = reinterpret_cast<const float2*>(aabb + 6 * s);
-                const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
-                const uint32_t ent = entity_of_slot[s];
-                const uint32_t extra = COMPACT ? class_of_slot[s] : group[s];
-                const uint32_t msk = COMPACT ? 0u : mask[s];
+                const uint32_t f = fl_[k];
+                const float2 b0 = b0_[k], b1 = b1_[k], b2 = b2_[k];
+                const uint32_t ent = ent_[k];
+                const uint32_t extra = extra_[k];
+                const uint32_t msk = COMPACT ? 0u : msk_[k];
                 const float b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
                 if (is_body(f) && !body_is_large(g, b)) {
                     const uint32_t c = cell_of(g, b[0], b[1], b[2]);
@@ -1304,6 +1325,43 @@ __device__ __forceinline__ void lane_flush(const PairSink& sink, LaneList& l, ui
     l.cnt = 0;
 }
 
+// The flush at the END of a block in two halves, so that the atomic's round trip runs beside the next block's first loads:
+// lane_flush_begin scans the counts and issues the atomic, lane_flush_end (after the next block's loads have been issued)
+// picks the result up and stores the entries.
+struct LanePending {
+    unsigned long long base; // lane 0: the atomic's result (in flight until lane_flush_end reads it)
+    uint32_t excl;           // entries of the lanes below this one
+    uint32_t entity;         // the entity this lane's entries belong to
+    uint32_t total;          // wave-uniform
+};
+__device__ __forceinline__ LanePending lane_flush_begin(const PairSink& sink, const LaneList& l, uint32_t own_entity)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = l.cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= static_cast<uint32_t>(off)) incl += t;
+    }
+    LanePending p{0ull, incl - l.cnt, own_entity, static_cast<uint32_t>(__shfl(incl, 63, 64))};
+    if (p.total != 0u && lane == 0u) p.base = atomicAdd(&sink.shard_count[(blockIdx.x % kShards) * 8u], static_cast<unsigned long long>(p.total));
+    return p;
+}
+__device__ __forceinline__ void lane_flush_end(const PairSink& sink, LaneList& l, const LanePending& p)
+{
+    if (p.total == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long base = __shfl(p.base, 0, 64) + p.excl;
+    uint2* dst = sink.pairs + static_cast<uint64_t>(blockIdx.x % kShards) * sink.shard_cap;
+    for (uint32_t k = 0; __any(k < l.cnt); ++k) {
+        if (k < l.cnt) {
+            const uint32_t partner = l.buf[lane + 64u * k];
+            if (base + k < sink.shard_cap) dst[base + k] = make_uint2(min(p.entity, partner), max(p.entity, partner));
+        }
+    }
+    l.cnt = 0;
+}
+
 __device__ __forceinline__ bool overlap(const float4& alo, const float4& ahi, const float4& blo, const float4& bhi)
 {
     // All six comparisons, no short circuit: for `&&` the compiler builds a cascade of exec-mask branches (one per axis, the
@@ -1483,11 +1541,18 @@ __global__ void __launch_bounds__(256, SMALL ? kWaveResidentSmall : (COMPACT ? k
 
     const GridParams g = acc->grid;
     if (SMALL) {
-        if (threadIdx.x < 32u) {
-            const uint4 a = filter_table[threadIdx.x];
+        if (threadIdx.x < 64u) {
+            // one load per lane, the other classes' entries by readlane (a loop over filter_table[c] was 96 dependent scalar loads)
+            const uint4 a = filter_table[threadIdx.x & 31u];
             uint32_t m = 0;
-            for (uint32_t c = 0; c < 32u; ++c) m |= filter_tab(a, filter_table[c]) ? 1u << c : 0u; // (unused entries are zero: never pair)
-            s_compat[threadIdx.x] = m;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const uint4 o = make_uint4(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(a.x), c)),
+                                           static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(a.y), c)),
+                                           static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(a.z), c)), 0u);
+                m |= filter_tab(a, o) ? 1u << c : 0u; // (unused entries are zero: never pair)
+            }
+            if (threadIdx.x < 32u) s_compat[threadIdx.x] = m;
         }
         __syncthreads();
     } else if (COMPACT) {
@@ -1505,6 +1570,7 @@ __global__ void __launch_bounds__(256, SMALL ? kWaveResidentSmall : (COMPACT ? k
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     float4* cand = cand_all[wave];
     LaneList found{lists_lds[wave], 0u};
+    LanePending pending{0ull, 0u, 0u, 0u};
 
     for (uint32_t blk = blockIdx.x * 4u + wave; blk < n_blocks; blk += gridDim.x * 4u) {
         const uint32_t i = blk * 64u + lane;
@@ -1514,16 +1580,13 @@ __global__ void __launch_bounds__(256, SMALL ? kWaveResidentSmall : (COMPACT ? k
         if (active) {
             lo = sorted[static_cast<uint64_t>(RS) * i];
             hi = sorted[static_cast<uint64_t>(RS) * i + 1];
-            if (COMPACT) {
-                cell = cell_of(g, lo.x, lo.y, lo.z);
-            } else {
-                fi = sorted[3ull * i + 2];
-                cell = __float_as_uint(hi.w);
-            }
+            if (!COMPACT) fi = sorted[3ull * i + 2];
         }
+        // the previous block's pairs go out while this block's own record is on its way
+        lane_flush_end(sink, found, pending);
+        if (active) cell = COMPACT ? cell_of(g, lo.x, lo.y, lo.z) : __float_as_uint(hi.w);
         const uint32_t entity_i = __float_as_uint(lo.w);
         const uint32_t last_lane = min(63u, n_sorted - 1u - blk * 64u);
-        const uint32_t cell_first = __shfl(cell, 0, 64), cell_last = __shfl(cell, static_cast<int>(last_lane), 64);
         uint4 own = make_uint4(0, 0, 0, 0);
         auto class_entry = [&](uint32_t cls) {
             const uint2 gm = s_tab[cls & 255u];
@@ -1536,29 +1599,32 @@ __global__ void __launch_bounds__(256, SMALL ? kWaveResidentSmall : (COMPACT ? k
             own = class_entry(__float_as_uint(hi.w));
         }
 
-#pragma unroll 1
-        for (int row = 0; row < 5; ++row) {
-            // this lane's candidate range [j, end) and the wave's union [r_lo, r_hi)
-            uint32_t j = 0, end = 0, r_lo, r_hi;
+        // a row's candidate range of this lane, [j, end): row 0 = own cell's later records + the cell to the right; rows 1..4 =
+        // three cells of the row at dy = 1 (dz = 0) and at dy = -1, 0, 1 (dz = 1)
+        auto row_range = [&](int row, uint32_t& j, uint32_t& end) {
+            j = 0;
+            end = 0;
+            if (!active) return;
             if (row == 0) {
-                // own cell's later records + the cell to the right
-                if (active) {
-                    j = i + 1;
-                    end = cell_start[cell + 2];
-                }
-                r_lo = blk * 64u + 1u;
-                r_hi = cell_start[cell_last + 2];
+                j = i + 1;
+                end = cell_start[cell + 2];
             } else {
-                const int dy = (row == 1) ? 1 : (row - 3); // rows 2,3,4 -> dy = -1,0,1 at dz = 1
+                const int dy = (row == 1) ? 1 : (row - 3);
                 const int dz = (row == 1) ? 0 : 1;
                 const uint32_t off = static_cast<uint32_t>(dy * static_cast<int>(g.dim_x)) + static_cast<uint32_t>(dz) * g.dim_xy;
-                if (active) {
-                    j = cell_start[cell + off - 1];
-                    end = cell_start[cell + off + 2];
-                }
-                r_lo = cell_start[cell_first + off - 1];
-                r_hi = cell_start[cell_last + off + 2];
+                j = cell_start[cell + off - 1];
+                end = cell_start[cell + off + 2];
             }
+        };
+        uint32_t next_j, next_end;
+        row_range(0, next_j, next_end);
+#pragma unroll 1
+        for (int row = 0; row < 5; ++row) {
+            // the next row's range is in flight while this row is searched; the wave's union [r_lo, r_hi) is the first lane's
+            // start and the last lane's end (cells ascend along the sorted records) — no loads of its own
+            const uint32_t j = next_j, end = next_end;
+            if (row < 4) row_range(row + 1, next_j, next_end);
+            const uint32_t r_lo = __shfl(j, 0, 64), r_hi = __shfl(end, static_cast<int>(last_lane), 64);
             for (uint32_t base = r_lo; base < r_hi; base += kWaveChunk) {
                 const uint32_t top = min(base + kWaveChunk, r_hi);
                 const uint32_t jj0 = max(j, base);
@@ -1568,7 +1634,23 @@ __global__ void __launch_bounds__(256, SMALL ? kWaveResidentSmall : (COMPACT ? k
                 // (staging the corners as separate arrays — all min corners, then all max corners — so that the lanes of a
                 //  ds_read_b128 pass hit consecutive 16-byte bank groups was measured: SQ_LDS_BANK_CONFLICT 11.3 M -> 10.6 M, step
                 //  0.504 -> 0.520 ms; rejected)
-                for (uint32_t k = lane; k < RS * (top - base); k += 64u) cand[k] = sorted[static_cast<uint64_t>(RS) * base + k];
+                {
+                    // all loads of the chunk issued before the first LDS store (as a loop: one global round trip after the other)
+                    constexpr uint32_t kLoads = (RS * kWaveChunk + 63u) / 64u;
+                    const uint32_t cnt = RS * (top - base);
+                    const float4* src = sorted + static_cast<uint64_t>(RS) * base;
+                    float4 t[kLoads];
+#pragma unroll
+                    for (uint32_t q = 0; q < kLoads; ++q) t[q] = src[min(lane + 64u * q, cnt - 1u)];
+#pragma unroll
+                    for (uint32_t q = 0; q < kLoads; ++q) { // (keeps the compiler from sinking each load into its guarded store)
+                        asm volatile("" : "+v"(t[q].x), "+v"(t[q].y), "+v"(t[q].z), "+v"(t[q].w));
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < kLoads; ++q) {
+                        if (lane + 64u * q < cnt) cand[lane + 64u * q] = t[q];
+                    }
+                }
                 wave_sync();
                 uint32_t jj = jj0;
                 while (__any(jj < e0)) {
@@ -1601,8 +1683,9 @@ __global__ void __launch_bounds__(256, SMALL ? kWaveResidentSmall : (COMPACT ? k
                 }
             }
         }
-        lane_flush(sink, found, entity_i);
+        pending = lane_flush_begin(sink, found, entity_i);
     }
+    lane_flush_end(sink, found, pending);
 }
 
 __global__ void __launch_bounds__(256) k_bp_large(uint64_t n_slots, const Accum* __restrict__ acc,
