@@ -805,7 +805,9 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_hist(uint64_t n_slots, ui
     const uint64_t begin = blockIdx.x * chunk, end = min(begin + chunk, n_slots);
 #pragma unroll 2
     for (uint64_t s = begin + threadIdx.x; s < end; s += kSortThreads) {
-        // flags and AABB in one round trip (see k_bp_bounds)
+        // (as written the compiler sinks the AABB loads below the is_body test — flags, wait, AABB, wait.  Pinning all loads of
+        //  1 / 2 / 4 slots in front of the first use, as k_sort_coarse_t and the pair search now do, was measured here at 4 M
+        //  bodies: 29.3 / 32.1 / 32.8 us against 29.4 — this pass does not wait on its loads)
         const uint32_t fl = flags[s];
         const float2* bp = reinterpret_cast<const float2*>(aabb + 6 * s);
         const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
@@ -1123,6 +1125,9 @@ __global__ void __launch_bounds__(kSortThreads, 1)
     const uint32_t tid = threadIdx.x;
     float4 rec[PT][RS];
     uint32_t cell[PT];
+    // (the compiler waits for each record before it asks for the next: every load sits in its own `r < n_rec` block.  Requesting all
+    //  eight up front, as k_sort_coarse_t does, made THIS pass slower at 4 M bodies — 60.9 -> 67.4 us: sixteen 16-byte loads per
+    //  thread from eight strided streams — so it stays as it is)
 #pragma unroll
     for (uint32_t k = 0; k < PT; ++k) {
         const uint32_t r = k * kSortThreads + tid;

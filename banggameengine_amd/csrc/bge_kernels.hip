@@ -220,12 +220,13 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
     // from lane (class) once the flags are there (classes are < 64; outside any divergent branch: a permute reads active lanes).
     // 1 M flat bodies: 23.4 -> 23.15 us per tick (three alternating runs).  Doing this — and the early velocity load — in every tile
     // with at least one Dynamic body in eight slots made depth-4 chains (bodies on the roots) 3 % SLOWER (22.5 -> 23.2 us): there
-    // the extra loads cost more than the round trip they hide.
+    // the extra loads cost more than the round trip they hide.  Not in the Bullet-basis variant either: 31.9 -> 32.1 us with it (and
+    // with the queue counter's barrier moved behind the first loads), three alternating runs.
 #ifndef BGE_PALETTE_SHUFFLE
 #define BGE_PALETTE_SHUFFLE 1
 #endif
     float4 gf_early = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const bool palette_early = BGE_PALETTE_SHUFFLE && BGE_SPECULATIVE_LOADS && PHYS && (hdr & kHdrAllDynamic);
+    const bool palette_early = BGE_PALETTE_SHUFFLE && BGE_SPECULATIVE_LOADS && PHYS && !BASIS && (hdr & kHdrAllDynamic);
     if (palette_early) {
         const float4 mine = w.grav_palette[tid & 63u];
         const int cls0 = static_cast<int>((f0 >> kMassShift) & 63u);
