@@ -31,8 +31,9 @@ def _forest(rng, n):
     return parent
 
 
-# BGE_FUZZ_SEEDS=n: a longer campaign (seeds 64.. alternate between the two styles)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BGE_FUZZ_SEEDS", "64"))))
+# BGE_FUZZ_SEEDS=n [BGE_FUZZ_FIRST=k]: a longer campaign, seeds k .. k + n - 1 (seeds 64.. alternate between the two styles)
+_FIRST = int(os.environ.get("BGE_FUZZ_FIRST", "0"))
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + int(os.environ.get("BGE_FUZZ_SEEDS", "64"))))
 def test_random_scene_and_edit_script_match_oracle_every_tick(seed, monkeypatch):
     if seed % 5 == 0:
         monkeypatch.setenv("BGE_TRIGGER_GRID_MIN", "0")    # the ghosts look their bodies up in the broadphase grid
