@@ -18,6 +18,8 @@
 // rows) makes this a register-hungry kernel; it touches only bodies at the ground, so it is sized for correctness first.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "bge_device_math.hpp"
 #include "bge_flatten.hpp"
 #include "bge_kernels.hpp"
@@ -404,7 +406,12 @@ __device__ __forceinline__ CtRow ct_zero_row()
 }
 
 // solveGroup for the island {body} (oracle/contact_ref.h SolveBodyAgainstGround)
-__device__ __noinline__ bool ct_solve(F3& origin, F3& linVel, F3& angVel, Q4& orn, M3& basis, CtPoint (&p)[4], int n, float invMassScalar,
+// (inlined into its one caller: as a call its reference arguments — pose, velocities, the four points — lived in scratch memory.
+//  1 M resting bodies: 0.426 -> 0.355 ms per tick; 222 VGPRs + 320 B of scratch instead of 256 + 400)
+#ifndef BGE_CT_SOLVE_INLINE
+#define BGE_CT_SOLVE_INLINE __forceinline__
+#endif
+__device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel, Q4& orn, M3& basis, CtPoint (&p)[4], int n, float invMassScalar,
                                       const F3& invInertiaLocal, const F3& localInertia, float friction, const F3& force, float dt)
 {
     constexpr int kIterations = 10;
@@ -562,12 +569,11 @@ __device__ __noinline__ bool ct_solve(F3& origin, F3& linVel, F3& angVel, Q4& or
     return moved;
 }
 
+// One body against the plane: collide, refresh the cached manifold, solve.  Every test of k_ground_select is repeated here (they
+// are cheap beside what follows), so the function is correct for any slot.
 template <bool BASIS>
-__global__ void __launch_bounds__(128) k_ground(WorldView w, GroundParams g)
+__device__ void ground_body(const WorldView& w, const GroundParams& g, uint32_t slot)
 {
-    const uint64_t slot64 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (slot64 >= g.n_slots) return;
-    const uint32_t slot = static_cast<uint32_t>(slot64);
     const uint32_t f0 = w.flags[slot];
     if ((f0 & kTypeMask) != 2u) return; // Dynamic bodies only (with a Transform, or orphaned): nothing else responds to a contact
     const uint32_t ci0 = w.cinfo[slot];
@@ -675,14 +681,117 @@ __global__ void __launch_bounds__(128) k_ground(WorldView w, GroundParams g)
     if (f != f0) w.flags[slot] = f;
 }
 
+// ---- two launches per sub-step
+// ground_body needs 248 VGPRs (two waves per SIMD) — and most bodies of a scene need none of it: they sleep, or are nowhere
+// near the plane.  As ONE kernel over all slots (the first version) even those paid for the solver's occupancy: two waves per
+// SIMD cannot keep enough loads in flight, and the tests sat behind five dependent round trips (flags -> contact word ->
+// palette -> shape -> position).  1 M bodies, per tick on top of the 24.5 us tick: asleep +38 us, airborne +22 us.
+//   k_ground_select  256 threads, a handful of registers: the teleport rule of PhysicsSystem::Update for dirty bodies (what
+//                    k_pose_only did as a third launch), then the tests in two batches of loads — flags + contact word +
+//                    deactivation record; shape + position for those still in — and the slots that need the solver appended
+//                    to a list (one atomic per wave)
+//   k_ground         a resident-sized grid walks the list: full waves of bodies that are all in contact
+// The list's order depends on the atomics, the results do not: a body touches nothing but its own records.
+template <bool BASIS>
+__global__ void __launch_bounds__(256) k_ground_select(WorldView w, GroundParams g)
+{
+    const uint64_t slot64 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const bool in_range = slot64 < g.n_slots;
+    const uint32_t slot = in_range ? static_cast<uint32_t>(slot64) : 0u;
+    uint32_t f = w.flags[slot];
+    const uint32_t ci0 = w.cinfo[slot];
+    uint32_t dz = w.deact[slot]; // (read whether or not kDrowsy says it is meaningful: one round trip instead of two)
+    asm volatile("" : "+v"(f), "+v"(dz));
+    bool need = in_range;
+    const uint32_t type = f & kTypeMask;
+    if (need && g.repose && (f & kValid) && type != 0 && (f & (kTDirty | kBDirty))) {
+        // EnsureRigidBody / SyncKinematicBodiesToPhysics before stepSimulation (PhysicsSystem.cpp:952-989): pose from the Transform,
+        // zero velocities — k_pose_only's re-pose, for the body types it applies to; the tick kernel that follows (no_repose) marks
+        // Dynamic transforms dirty and clears kBDirty as always
+        const uint32_t f_in = f;
+        const Q4 q = bt_quat_from_transform_euler(ld3(w.euler, slot));
+        st4(w.quat, slot, q);
+        f &= ~kSettled;
+        const F3 zero{0.0f, 0.0f, 0.0f};
+        if (type == 2u) st3(w.vel, slot, zero);
+        if (f & kSpin) {
+            st3(w.angvel, slot, zero);
+            f &= ~kSpin;
+        }
+        if (type == 2u) st3(w.euler, slot, bt_transform_euler_from_mat(bt_mat_from_quat(q)));
+        if (f != f_in) w.flags[slot] = f;
+    }
+    need = need && type == 2u && (ci0 & kCiGroundMask) != 0;
+    need = need && !((f & kDrowsy) && (dz == kDeactWants || dz == kDeactSleeping));
+    if (__any(need)) {
+        const uint32_t n = (ci0 >> kCiCountShift) & 7u;
+        if (need && n == 0u && !(f & kSpin)) {
+            // cheap reject, as in ground_body: no vertex of the shape can be within the breaking threshold of the plane
+            const float4 cs = w.cshape[slot];
+            const F3 pos = ld3(w.pos, slot);
+            CtShape shape;
+            shape.capsule = (ci0 & kCiCapsule) != 0;
+            shape.dims = F3{cs.x, cs.y, cs.z};
+            const float reach = (__builtin_fabsf(cs.x) + __builtin_fabsf(cs.y) + __builtin_fabsf(cs.z)) * 1.01f + 0.01f;
+            if (pos.y - reach > ct_breaking_threshold(shape)) need = false;
+        }
+    }
+    const unsigned long long m = __ballot(need);
+    if (m == 0) return;
+    // one atomic per wave, on the counter of this workgroup's shard: a single counter word takes ~10^8 atomics a second, and
+    // 15,625 waves of a million resting bodies queued on it for 130 us.  Workgroup b appends to shard b % kGroundShards, whose
+    // segment holds every slot those workgroups could ever send: it cannot overflow.
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t shard = blockIdx.x % kGroundShards;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&g.list_count[16u * shard], static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, 0, 64);
+    if (need) g.list[static_cast<uint64_t>(shard) * g.shard_cap + base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)))] = slot;
+}
+
+template <bool BASIS>
+#ifndef BGE_GROUND_MIN_BLOCKS
+#define BGE_GROUND_MIN_BLOCKS 2 /* 2: 256 VGPRs, two waves per SIMD, 400 B of scratch (without a bound: 264 VGPRs, one wave); 4: 128 VGPRs, four waves, 888 B */
+#endif
+__global__ void __launch_bounds__(128, BGE_GROUND_MIN_BLOCKS) k_ground(WorldView w, GroundParams g)
+{
+    // workgroup b works on shard b % kGroundShards, together with the other gridDim.x / kGroundShards workgroups of that shard
+    const uint32_t shard = blockIdx.x % kGroundShards;
+    const uint32_t n_list = g.list_count[16u * shard];
+    const uint32_t* list = g.list + static_cast<uint64_t>(shard) * g.shard_cap;
+    const uint32_t step = (gridDim.x / kGroundShards) * blockDim.x;
+#ifndef BGE_GROUND_EMPTY /* timing experiment: the launch without the solver (and so without scratch) */
+    for (uint32_t i = (blockIdx.x / kGroundShards) * blockDim.x + threadIdx.x; i < n_list; i += step) ground_body<BASIS>(w, g, list[i]);
+#else
+    if (n_list == 0xffffffffu) w.cinfo[list[step]] = 0;
+#endif
+    // the workgroup that draws the shard's last ticket empties its list for the next sub-step's k_ground_select: by then every
+    // workgroup of the shard has read the count (it did so before it drew its own ticket).  (One ticket word for all 1024
+    // workgroups made an EMPTY launch take 13.6 us: a thousand atomics on one address.)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&g.list_count[16u * shard + 1u], 1u) == gridDim.x / kGroundShards - 1u) {
+            g.list_count[16u * shard] = 0;
+            g.list_count[16u * shard + 1u] = 0;
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundParams& g, bool bullet_basis)
 {
     if (g.n_slots == 0) return hipSuccess;
-    const dim3 grid(static_cast<uint32_t>((g.n_slots + 127) / 128)), block(128);
-    if (bullet_basis) hipLaunchKernelGGL(k_ground<true>, grid, block, 0, stream, w, g);
-    else hipLaunchKernelGGL(k_ground<false>, grid, block, 0, stream, w, g);
+    const dim3 sgrid(static_cast<uint32_t>((g.n_slots + 255) / 256)), sblock(256);
+    // what is resident: 2 x BGE_GROUND_MIN_BLOCKS workgroups of 128 threads on each of the 256 CUs (a multiple of the shard count)
+    const dim3 grid(512u * BGE_GROUND_MIN_BLOCKS), block(128);
+    if (bullet_basis) {
+        hipLaunchKernelGGL(k_ground_select<true>, sgrid, sblock, 0, stream, w, g);
+        hipLaunchKernelGGL(k_ground<true>, grid, block, 0, stream, w, g);
+    } else {
+        hipLaunchKernelGGL(k_ground_select<false>, sgrid, sblock, 0, stream, w, g);
+        hipLaunchKernelGGL(k_ground<false>, grid, block, 0, stream, w, g);
+    }
     return hipGetLastError();
 }
 

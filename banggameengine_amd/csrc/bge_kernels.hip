@@ -232,6 +232,15 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
         const int cls0 = static_cast<int>((f0 >> kMassShift) & 63u);
         gf_early = make_float4(__shfl(mine.x, cls0, 64), __shfl(mine.y, cls0, 64), __shfl(mine.z, cls0, 64), __shfl(mine.w, cls0, 64));
     }
+    // Ground plane on (p.cinfo_in): the contact word k_ground left and the deactivation record — most bodies of a scene at rest
+    // are asleep — are two more dependent round trips behind the flag word; in all-dynamic tiles they are requested with the
+    // first loads (8 B per body more, only in ticks that follow a k_ground launch).
+    uint32_t ci_early = 0, dz_early = 0;
+    const bool ground_early = BGE_SPECULATIVE_LOADS && PHYS && p.cinfo_in != nullptr && (hdr & kHdrAllDynamic);
+    if (ground_early) {
+        ci_early = p.cinfo_in[slot];
+        dz_early = w.deact[slot];
+    }
     uint32_t f = f0;
     const bool valid = (f & kValid) != 0;
     // A slot with a body but no Transform: the entity lost its Transform while its RigidBody stayed.  The reference keeps that
@@ -268,7 +277,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             // ground plane on: k_ground collided this body with the plane before this kernel ran and, if it is in contact (or
             // spinning), solved it — its velocities are final (gravity impulse included), its fed AABB is written
             uint32_t ci = 0;
-            if (p.cinfo_in && dynamic) ci = p.cinfo_in[slot];
+            if (p.cinfo_in && dynamic) ci = ground_early ? ci_early : p.cinfo_in[slot];
             const bool solved = (ci & kCiSolved) != 0;
             // whatever writes the quaternion (re-pose, spin, the split impulse) takes kSettled away
             if (repose || spin || (ci & kCiMoved)) f &= ~kSettled;
@@ -351,7 +360,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 }
                 // Deactivation record: untouched (and unread) while the body is fast and its timer is zero.
                 // (kDrowsy <=> record != 0; body (re)creation clears the bit: a new btRigidBody is ACTIVE_TAG, timer 0)
-                const uint32_t dz0 = (kSleepEnabled && (f & kDrowsy)) ? w.deact[slot] : 0u;
+                const uint32_t dz0 = (kSleepEnabled && (f & kDrowsy)) ? (ground_early ? dz_early : w.deact[slot]) : 0u;
                 uint32_t dz = dz0;
                 // buildIslands: a free body is an island of its own; WANTS_DEACTIVATION -> ISLAND_SLEEPING
                 if (dz == kDeactWants) dz = kDeactSleeping;

@@ -59,7 +59,15 @@ struct GroundParams {
     float gx, gy, gz;
     uint64_t n_slots;
     uint32_t want_aabb; // the tick feeds AABBs (broadphase / triggers): solved bodies' boxes are written here, before the solve
+    uint32_t repose;    // first sub-step of a PhysicsSystem::Update: dirty bodies are re-posed from their Transforms first
+    uint32_t* list;            // [kGroundShards][shard_cap] slots k_ground_select hands to the solver
+    uint32_t* list_count;      // [16 * shard] entries of a shard's segment, [16 * shard + 1] the shard's ticket counter in k_ground; all
+                               // zero between sub-steps (the last workgroup of each shard sees to it)
+    uint64_t shard_cap;        // ground_shard_cap(n_slots)
 };
+constexpr uint32_t kGroundShards = 64;
+// slots the select workgroups b = shard, shard + 64, ... (256 slots each) can send at most
+inline uint64_t ground_shard_cap(uint64_t n_slots) { return ((n_slots + 255) / 256 + kGroundShards - 1) / kGroundShards * 256; }
 
 // Trigger volumes (ghost objects), indexed by trigger number
 struct TriggerView {

@@ -153,6 +153,7 @@ struct bge_world {
     DevBuf pos, euler, scale, world, vel, angvel, quat, inv_mass, half_extent, group, mask, aabb;
     DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table, grav_palette;
     DevBuf cshape, cmass, cfriction, cinfo, manifold; // ground contact (bge_contact.hip); manifold allocated when the plane is switched on
+    DevBuf ground_list, ground_count;                 // slots k_ground_select hands to the solver; count + ticket words
     bool ground_plane = false; // the reference's static plane y = 0 (PhysicsSystem.cpp:149-166); off: free bodies (BASELINE's workloads)
     DevBuf bp_partials; // per-wave bounds / count / widest extent written by the tick kernel for the broadphase (32 B per wave)
     float grav_cached[3] = {0.0f, 0.0f, 0.0f};
@@ -300,7 +301,7 @@ struct bge_world {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
                           &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &frozen, &trig_slot, &trig_entity, &trig_he, &trig_group,
-                          &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists}) {
+                          &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists, &ground_list, &ground_count}) {
             b->release();
         }
         broadphase.release();
@@ -1255,11 +1256,24 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
         }
         if (phys && w->ground_plane) {
             // Ground plane on.  Bullet's order inside PhysicsSystem::Update: teleport dirty bodies (before stepSimulation), then per
-            // sub-step collision detection + solver, then integrateTransforms — so the re-pose runs as its own kernel (once per
-            // stepSimulation call), k_ground collides and solves the bodies at the ground, and the tick kernel integrates.
+            // sub-step collision detection + solver, then integrateTransforms — so k_ground_select re-poses them (once per
+            // stepSimulation call) and picks the bodies at the ground, k_ground collides and solves those, and the tick kernel
+            // integrates.
             const uint64_t n_slots = static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile;
-            if (!sub.no_repose) HIP_TRY(bge::launch_pose_only(w->stream, w->view, n_slots, (flags & BGE_TICK_BULLET_BASIS) != 0));
+            // the solver's work list: slots + its count and ticket words (left at zero by every k_ground)
+            const uint64_t shard_cap = bge::ground_shard_cap(n_slots);
+            const size_t list_bytes = shard_cap * bge::kGroundShards * 4, count_bytes = (bge::kGroundShards + 1) * 64;
+            if (w->ground_list.bytes < list_bytes || !w->ground_count.p) {
+                HIP_TRY(w->ground_list.ensure(list_bytes));
+                HIP_TRY(w->ground_count.ensure(count_bytes));
+                HIP_TRY(hipMemsetAsync(w->ground_count.p, 0, count_bytes, w->stream));
+                w->drop_graph();
+            }
             bge::GroundParams gp{};
+            gp.repose = sub.no_repose ? 0u : 1u; // (the teleport rule is part of k_ground_select)
+            gp.list = w->ground_list.as<uint32_t>();
+            gp.list_count = w->ground_count.as<uint32_t>();
+            gp.shard_cap = shard_cap;
             gp.dt = dt;
             gp.gx = gravity[0];
             gp.gy = gravity[1];
