@@ -146,6 +146,20 @@ __device__ __forceinline__ CtPoint ct_empty_point()
     return p;
 }
 
+// d = c ? s : d, field by field.  Written as `if (i == k) p[i] = s;` over the four points, the compiler turns the chain into a
+// switch and sinks the stores behind a phi of POINTERS to the selected point's fields — which keeps all four points in scratch
+// memory for the whole kernel (320 B per lane, every access a memory round trip).
+__device__ __forceinline__ void ct_point_select(CtPoint& d, bool c, const CtPoint& s)
+{
+    d.localA = F3{c ? s.localA.x : d.localA.x, c ? s.localA.y : d.localA.y, c ? s.localA.z : d.localA.z};
+    d.localB = F3{c ? s.localB.x : d.localB.x, c ? s.localB.y : d.localB.y, c ? s.localB.z : d.localB.z};
+    d.worldA = F3{c ? s.worldA.x : d.worldA.x, c ? s.worldA.y : d.worldA.y, c ? s.worldA.z : d.worldA.z};
+    d.worldB = F3{c ? s.worldB.x : d.worldB.x, c ? s.worldB.y : d.worldB.y, c ? s.worldB.z : d.worldB.z};
+    d.appliedImpulse = c ? s.appliedImpulse : d.appliedImpulse;
+    d.appliedLateral = c ? s.appliedLateral : d.appliedLateral;
+    d.distance = c ? s.distance : d.distance;
+}
+
 __device__ __forceinline__ int ct_sort_cached_points(const CtPoint (&p)[4], const CtPoint& pt)
 {
     int maxPenetrationIndex = -1;
@@ -238,9 +252,7 @@ __device__ __forceinline__ void ct_collide(CtPoint (&p)[4], int& n, const CtShap
                 if (insert < 0) insert = 0;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i == insert) p[i] = np;
-            }
+            for (int i = 0; i < 4; ++i) ct_point_select(p[i], i == insert, np);
         }
     }
     // refreshContactPoints
@@ -262,19 +274,17 @@ __device__ __forceinline__ void ct_collide(CtPoint (&p)[4], int& n, const CtShap
                 const float distance2d = dot3(projectedDifference, projectedDifference);
                 remove = distance2d > breaking * breaking;
             }
-            if (remove) {
+            {
+                // removeContactPoint: the last point takes the removed one's place (selects, not branches: see ct_point_select)
                 const int last = n - 1;
                 CtPoint moved = ct_empty_point();
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k == last) moved = p[k];
-                }
-                if (i != last) p[i] = moved;
+                for (int k = 0; k < 4; ++k) ct_point_select(moved, k == last, p[k]);
+                ct_point_select(p[i], remove && i != last, moved);
+                const CtPoint empty = ct_empty_point();
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k == last) p[k] = ct_empty_point();
-                }
-                n--;
+                for (int k = 0; k < 4; ++k) ct_point_select(p[k], remove && k == last, empty);
+                if (remove) n--;
             }
         }
     }
@@ -407,7 +417,7 @@ __device__ __forceinline__ CtRow ct_zero_row()
 
 // solveGroup for the island {body} (oracle/contact_ref.h SolveBodyAgainstGround)
 // (inlined into its one caller: as a call its reference arguments — pose, velocities, the four points — lived in scratch memory.
-//  1 M resting bodies: 0.426 -> 0.355 ms per tick; 222 VGPRs + 320 B of scratch instead of 256 + 400)
+//  1 M resting bodies: 0.426 -> 0.355 ms per tick; with ct_point_select 0.234 and no scratch at all)
 #ifndef BGE_CT_SOLVE_INLINE
 #define BGE_CT_SOLVE_INLINE __forceinline__
 #endif
@@ -434,6 +444,16 @@ __device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel,
     for (int j = 0; j < 4; ++j) {
         normalRow[j] = ct_zero_row();
         frictionRow[j] = ct_zero_row();
+        // what is the same for every row is set whether or not the row exists (rows j >= n are never looked at): set under
+        // `j < n` these fields were select(j < n, constant, 0) — eight live registers more per contact in the solver's loops
+        normalRow[j].normal = nrm;
+        normalRow[j].cfm = 0.0f;
+        normalRow[j].lower = 0.0f;
+        normalRow[j].upper = 1e10f;
+        normalRow[j].friction = combinedFriction;
+        frictionRow[j].friction = combinedFriction;
+        frictionRow[j].rhsPenetration = 0.0f;
+        frictionRow[j].cfm = 0.0f;
         if (j < n) {
             CtRow& c = normalRow[j];
             const F3 rel_pos1 = sub3(p[j].worldA, origin);
@@ -682,7 +702,7 @@ __device__ void ground_body(const WorldView& w, const GroundParams& g, uint32_t 
 }
 
 // ---- two launches per sub-step
-// ground_body needs 248 VGPRs (two waves per SIMD) — and most bodies of a scene need none of it: they sleep, or are nowhere
+// ground_body needs 246 VGPRs (two waves per SIMD) — and most bodies of a scene need none of it: they sleep, or are nowhere
 // near the plane.  As ONE kernel over all slots (the first version) even those paid for the solver's occupancy: two waves per
 // SIMD cannot keep enough loads in flight, and the tests sat behind five dependent round trips (flags -> contact word ->
 // palette -> shape -> position).  1 M bodies, per tick on top of the 24.5 us tick: asleep +38 us, airborne +22 us.
@@ -746,22 +766,26 @@ __global__ void __launch_bounds__(256) k_ground_select(WorldView w, GroundParams
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&g.list_count[16u * shard], static_cast<uint32_t>(__popcll(m)));
     base = __shfl(base, 0, 64);
-    if (need) g.list[static_cast<uint64_t>(shard) * g.shard_cap + base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)))] = slot;
+    const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+    if (need && at < g.shard_cap) g.list[static_cast<uint64_t>(shard) * g.shard_cap + at] = slot; // (the bound cannot bite while the counts are reset: a guard, not a path)
 }
 
 template <bool BASIS>
 #ifndef BGE_GROUND_MIN_BLOCKS
-#define BGE_GROUND_MIN_BLOCKS 2 /* 2: 256 VGPRs, two waves per SIMD, 400 B of scratch (without a bound: 264 VGPRs, one wave); 4: 128 VGPRs, four waves, 888 B */
+#define BGE_GROUND_MIN_BLOCKS 2 /* waves per SIMD the register budget is set for: 2 -> 246 VGPRs, no scratch; 4 -> 128 VGPRs and spills (measured slower) */
 #endif
 __global__ void __launch_bounds__(128, BGE_GROUND_MIN_BLOCKS) k_ground(WorldView w, GroundParams g)
 {
     // workgroup b works on shard b % kGroundShards, together with the other gridDim.x / kGroundShards workgroups of that shard
     const uint32_t shard = blockIdx.x % kGroundShards;
-    const uint32_t n_list = g.list_count[16u * shard];
+    const uint32_t n_list = min(g.list_count[16u * shard], static_cast<uint32_t>(g.shard_cap));
     const uint32_t* list = g.list + static_cast<uint64_t>(shard) * g.shard_cap;
     const uint32_t step = (gridDim.x / kGroundShards) * blockDim.x;
 #ifndef BGE_GROUND_EMPTY /* timing experiment: the launch without the solver (and so without scratch) */
-    for (uint32_t i = (blockIdx.x / kGroundShards) * blockDim.x + threadIdx.x; i < n_list; i += step) ground_body<BASIS>(w, g, list[i]);
+    for (uint32_t i = (blockIdx.x / kGroundShards) * blockDim.x + threadIdx.x; i < n_list; i += step) {
+        const uint32_t slot = list[i];
+        if (slot < g.n_slots) ground_body<BASIS>(w, g, slot);
+    }
 #else
     if (n_list == 0xffffffffu) w.cinfo[list[step]] = 0;
 #endif
