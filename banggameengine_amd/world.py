@@ -72,6 +72,12 @@ class World:
         count = next(len(a) for a in (pos, euler, scale) if a is not None)
         check(lib().bge_world_upload_trs(self._h, first, count, _p(pos), _p(euler), _p(scale)))
 
+    def upload_trs_indexed(self, entity_index, pos=None, euler=None, scale=None):
+        """Sparse form of upload_trs: row i belongs to entity entity_index[i] (bge_world_upload_trs_indexed)."""
+        idx = _arr(entity_index, np.uint32)
+        pos, euler, scale = (_arr(a, np.float32, 3) for a in (pos, euler, scale))
+        check(lib().bge_world_upload_trs_indexed(self._h, len(idx), _p(idx), _p(pos), _p(euler), _p(scale)))
+
     def mark_dirty(self, first=0, count=None):
         check(lib().bge_world_mark_dirty(self._h, first, self.n - first if count is None else count))
 

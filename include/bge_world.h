@@ -125,7 +125,9 @@ BGE_API void bge_world_destroy(bge_world* world);
  * All Transforms start dirty with TRS = (0, 0, 1) as a default-constructed Transform (Transform.h:14-16).
  * On a live world the call also does what the reference's scene edits do to what stays:
  *   - a changed parent ENTITY marks the child's subtree dirty, through Transform-less entities too (Scene::SetParent ->
- *     MarkHierarchyDirty, Scene.cpp:354-393, 535-550);
+ *     MarkHierarchyDirty, Scene.cpp:354-393, 535-550).  "Changed" is read off the two arrays: a child moved away and back
+ *     between two calls (two SetParent calls in the reference, each marking it) shows nothing here — mark it with
+ *     bge_world_mark_dirty, as an adapter that forwards Transform::dirty does anyway;
  *   - a clean Transform whose parent entity stays but lost its Transform becomes a root WITHOUT being marked, and keeps its
  *     world matrix until something marks it (Scene::RemoveTransform marks nobody; TransformSystem::Update recomputes a node
  *     only when it or an ancestor is dirty);

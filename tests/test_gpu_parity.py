@@ -842,6 +842,70 @@ def test_ground_plane_contacts_match_oracle_bitwise(basis, aabbs):
     assert slept > 0.7 * resting.sum(), f"only {slept} of {resting.sum()} bodies fell asleep"
 
 
+@pytest.mark.parametrize("basis", [False, True])
+def test_ground_plane_at_a_size_that_wraps_the_solver_work_list(basis):
+    """The ground path at 40,000 bodies: k_ground_select hands the bodies near the plane to the solver through 64 list shards
+    (workgroup b appends to shard b mod 64, 16 solver workgroups share a shard) — scenes of a few thousand bodies, like the
+    test above and the randomised ones, fill only the first few.  Boxes and capsules dropped from 0.05 .. 1.2 m in waves (so
+    that airborne, landing, resting and sleeping bodies coexist in every part of the slot range), a batch teleported back up
+    after 100 ticks; positions, rotationEuler, velocities, quaternions, contact counts and activation states against the oracle,
+    bit for bit, every tenth tick of 330."""
+    n = 40000
+    rng = np.random.default_rng(4242)
+    wl = synth.Workload("ground-wide", synth.FLAT, n, 99)
+    wl.pos[:, 0] = rng.uniform(-900, 900, n).astype(np.float32)
+    wl.pos[:, 2] = rng.uniform(-900, 900, n).astype(np.float32)
+    wl.pos[:, 1] = rng.choice([0.05, 0.4, 1.2, 6.0, 40.0], n).astype(np.float32) + rng.uniform(0.0, 0.3, n).astype(np.float32)
+    wl.euler[rng.random(n) < 0.3] = 0.0
+    wl.body_type = rng.choice([1, 1, 1, 1, 1, 1, 0, 2], n).astype(np.uint8)
+    shape = rng.choice([0, 0, 1], n).astype(np.uint8)
+    size = rng.uniform(0.15, 0.8, (n, 3)).astype(np.float32)
+    mass = rng.choice([0.5, 1.0, 4.0], n).astype(np.float32)
+    ref = build_oracle(wl, orient_mode=po.ORIENT_BASIS if basis else po.ORIENT_IDEAL, shape=shape, size=size, mass=mass)
+    ref.SetGroundPlane(True)
+    flags = B.TICK_ALL | (B.TICK_BULLET_BASIS if basis else 0)
+    dyn = wl.body_type == 1
+    states = set()
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(wl.body_type, mass=mass, shape=shape, size=size)
+        w.set_ground_plane(True)
+        for tick in range(330):
+            if tick == 100:   # every 40th body goes back up: the teleport rule inside k_ground_select, all over the slot range
+                up = np.arange(0, n, 40)
+                new_pos = wl.pos[up].copy()
+                new_pos[:, 1] = 2.0
+                for e, q in zip(up, new_pos):
+                    ref.SetTRS(int(e) + 1, pos=q)
+                w.upload_trs_indexed(up.astype(np.uint32), pos=new_pos)
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, flags=flags)
+            if tick % 10 and tick not in (100, 101):
+                continue
+            rb, gb = ref.bulk_bodies(), w.download_bodies()
+            ex = rb["exists"]
+            pos, euler = w.download_pose()
+            rpos, reuler = ref.bulk_pose()
+            assert_bits_equal(pos, rpos, f"tick {tick}: position")
+            assert_bits_equal(euler, reuler, f"tick {tick}: rotationEuler")
+            assert_bits_equal(gb["linvel"][dyn], rb["linvel"][dyn], f"tick {tick}: linear velocity")
+            assert_bits_equal(gb["angvel"][dyn], rb["angvel"][dyn], f"tick {tick}: angular velocity")
+            assert_bits_equal(gb["quat"][ex], rb["quat"][ex], f"tick {tick}: quaternion")
+            st, _ = w.download_activation()
+            rst, _ = ref.bulk_activation()
+            assert np.array_equal(st[ex], rst[ex].astype(np.uint8)), f"tick {tick}: activation states"
+            states |= set(st[dyn].tolist())
+            if tick % 50 == 0:
+                cn, _ = w.download_contacts()
+                for e in np.flatnonzero(dyn)[::97]:
+                    rn, _ = ref.GroundContacts(int(e) + 1)
+                    assert cn[e] == rn, f"tick {tick}: body {e} has {cn[e]} contacts, oracle {rn}"
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world matrices at the end")
+    assert {1, 2} <= states, states       # awake and asleep bodies side by side at the end
+
+
 def test_transform_fixtures_incl_multi_pass_layouts():
     """tests/golden/transform_cases.npz on the GPU: flat, chains, subtrees, a forest with Transform-less parents, a
     600-deep chain (three dependent passes) and a 700-wide root (children in a later pass read the parent from memory)."""
