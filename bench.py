@@ -322,6 +322,64 @@ def measure_extra_config(B, synth, torch, label, name, entities, steps, warmup, 
         world.close()
 
 
+def measure_ground_config(B, synth, torch, entities, check):
+    """configs[1] with the reference's ground plane (PhysicsSystem.cpp:149-166): n unit boxes dropped
+    from just above y = 0.  Two timed regions on one world: all bodies RESTING awake on their contacts (collide + 10 solver
+    iterations per body and tick), and ASLEEP after Bullet's 2 s deactivation time (the state a scene at rest is in).  Wall
+    clock around a synchronised batch of ticks (three launches per tick: select, solve, tick).  The checker replays the whole
+    tick sequence on the first 4,096 entities with the oracle's contact restatement."""
+    import numpy as np
+    from banggameengine_amd.world import FIXED_DT, GRAVITY
+    wl = synth.config("flat1m", n=entities)
+    rng = np.random.default_rng(11)
+    wl.pos[:, 1] = (0.9 + rng.uniform(0.0, 0.3, wl.n)).astype(np.float32)   # default collider: a unit box (half extent 0.5 + margin)
+    stream = torch.cuda.current_stream()
+    world = B.World(stream=stream.cuda_stream)
+    script = (("landing", 150, False), ("resting", 60, True), ("falling asleep", 400, False), ("asleep", 100, True))
+    try:
+        world.load(wl)
+        world.set_ground_plane(True)
+        phases = []
+        for phase, ticks, timed in script:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=B.TICK_ALL, ticks=ticks)
+            torch.cuda.synchronize()
+            if timed:
+                phases.append({"phase": phase, "ticks": ticks, "ms_per_step": (time.perf_counter() - t0) / ticks * 1e3})
+        st, _ = world.download_activation()
+        cn, _ = world.download_contacts()
+        out = {"label": "configs[1] on the reference's ground plane (contacts + solver, SURVEY 8(f) rank 4)", "workload": "flat1m + ground plane",
+               "entities": wl.n, "phases": phases, "asleep_at_the_end": int((st == 2).sum()),
+               "contacts_per_body_histogram": np.bincount(cn, minlength=5).tolist(),
+               "note": "wall clock per tick; the solver is bound by dependent arithmetic, not by HBM: no roofline fraction is quoted"}
+        if check:
+            from oracle import pyoracle as po
+            sample = 4096
+            swl = synth.config("flat1m", n=sample)
+            swl.pos[:, 1] = wl.pos[:sample, 1]
+            parent_i32 = np.where(swl.parent == 0xFFFFFFFF, -1, swl.parent.astype(np.int64)).astype(np.int32)
+            ref = po.RefScene().bulk_build(parent_i32, swl.pos, swl.euler, swl.scale, body_type=swl.body_type)
+            ref.SetPhysicsOptions(gravity_y=-9.81, orient_mode=po.ORIENT_IDEAL)
+            ref.SetGroundPlane(True)
+            n_ticks = sum(t for _, t, _ in script)
+            for _ in range(n_ticks):
+                ref.PhysicsSystemUpdate(FIXED_DT)
+                ref.TransformSystemUpdate()
+            want_w, _ = ref.bulk_world()
+            want_p, _ = ref.bulk_pose()
+            ref.close()
+            got_w = world.download_world(0, sample)
+            got_p, _ = world.download_pose(0, sample)
+            same = bool(np.array_equal(got_w.view(np.uint32), want_w.view(np.uint32)) and np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)))
+            err = float(np.max(np.abs(got_p.astype(np.float64) - want_p.astype(np.float64))))
+            out["parity"] = {"checker": "oracle port (CPU) with its contact restatement, same tick sequence", "sample_entities": sample,
+                             "ticks": n_ticks, "max_abs_err_position": err, "bit_identical": same, "ok": bool(err <= 1e-5)}
+        return out
+    finally:
+        world.close()
+
+
 # ----------------------------------------------------------------------------------------------------------- a rank
 def run_rank(args):
     # stdout carries exactly ONE line, the result.  Libraries print there too (RCCL writes its version banner to fd 1
@@ -655,6 +713,10 @@ def run_rank(args):
             except Exception as e:  # the headline stands on its own
                 extras.append({"label": label, "workload": cname, "error": repr(e)})
                 rc = rc or 5
+        try:   # (one more row of SURVEY 8(f); whatever happens here leaves the exit code alone)
+            extras.append(measure_ground_config(B, synth, torch, None, check))
+        except Exception as e:
+            extras.append({"label": "configs[1] on the reference's ground plane", "workload": "flat1m + ground plane", "error": repr(e)})
         out["configs"] = extras
 
     if rank == 0:
