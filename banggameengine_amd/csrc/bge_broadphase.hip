@@ -1831,8 +1831,8 @@ __global__ void __launch_bounds__(256) k_bp_query_boxes(const Accum* __restrict_
                             e = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), 0u);
                         }
                         ent = __float_as_uint(lo.w);
-                        // the ghost is a static object: static bodies never pair with it
-                        hit = e.z == 0u && ent != te && (tg & e.y) != 0u && (e.x & tm) != 0u;
+                        // (Static bodies included: the pair cache pairs a ghost with every registered object whose filter passes)
+                        hit = ent != te && (tg & e.y) != 0u && (e.x & tm) != 0u;
                     }
                     ++j;
                 }
@@ -1848,7 +1848,7 @@ __global__ void __launch_bounds__(256) k_bp_query_boxes(const Accum* __restrict_
                 const float* q = aabb + 6ull * L;
                 if (overlap(blo, bhi, make_float4(q[0], q[1], q[2], 0), make_float4(q[3], q[4], q[5], 0))) {
                     ent = entity_of_slot[L];
-                    hit = (flags[L] & kTypeMask) >= 2u && ent != te && (tg & mask[L]) != 0u && (group[L] & tm) != 0u;
+                    hit = (flags[L] & kTypeMask) != 0u && ent != te && (tg & mask[L]) != 0u && (group[L] & tm) != 0u;
                 }
             }
             emit(hit, i, ent);

@@ -913,8 +913,9 @@ __global__ void __launch_bounds__(256) k_trigger_pairs(uint64_t n_slots, uint32_
         uint32_t grp = 0, msk = 0, ent = 0;
         if (s < n_slots) {
             const uint32_t f = w.flags[s];
-            // the ghost is a static object: static bodies never pair with it
-            body = (f & kTypeMask) >= 2u; // (with or without a Transform: an orphaned body is still in the world)
+            // every rigid body of whatever type: Bullet's pair cache pairs the ghost with Static bodies too (the reference hands
+            // Bullet custom groups, PhysicsSystem.cpp:473,577; oracle/physics_ref.h has the reasoning)
+            body = (f & kTypeMask) != 0u; // (with or without a Transform: an orphaned body is still in the world)
             if (body) {
                 const float* b = w.aabb + 6 * s;
                 for (int a = 0; a < 3; ++a) {
@@ -942,6 +943,58 @@ __global__ void __launch_bounds__(256) k_trigger_pairs(uint64_t n_slots, uint32_
             if (hit) {
                 const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
                 if (at < cap) out[at] = make_uint2(i, ent);
+            }
+        }
+    }
+}
+
+// every ghost against every other ghost: both are registered collision objects, so the pair cache lists each in the other
+// (btGhostPairCallback::addOverlappingPair serves both proxies).  One thread per ghost i, the j boxes pass through LDS in
+// tiles of 256; a hit is (i | kGhostHit, j) — trigger INDICES, the host maps j to its entity and knows whether j is still
+// in the world when i is processed (a one-shot ghost that fired earlier in ProcessTriggerEvents' loop is not).  An inactive
+// ghost carries an empty box and overlaps nothing.  n_triggers^2 / 2 box tests x 2: thousands of ghosts are microseconds.
+__global__ void __launch_bounds__(256) k_trigger_ghost_pairs(uint32_t n_triggers, TriggerView t, uint32_t* __restrict__ count,
+                                                             uint2* __restrict__ out, uint32_t cap)
+{
+    __shared__ float s_box[256][6];
+    __shared__ uint32_t s_group[256], s_mask[256];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t grp = 0, msk = 0;
+    if (i < n_triggers) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) b[a] = t.aabb[6ull * i + a];
+        grp = t.group[i];
+        msk = t.mask[i];
+    }
+    for (uint32_t j0 = 0; j0 < n_triggers; j0 += 256u) { // uniform trip count: the ballots need every lane
+        __syncthreads();
+        const uint32_t jl = j0 + threadIdx.x;
+        if (jl < n_triggers) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) s_box[threadIdx.x][a] = t.aabb[6ull * jl + a];
+            s_group[threadIdx.x] = t.group[jl];
+            s_mask[threadIdx.x] = t.mask[jl];
+        }
+        __syncthreads();
+        const uint32_t nj = min(256u, n_triggers - j0);
+        for (uint32_t k = 0; k < nj; ++k) {
+            const uint32_t j = j0 + k;
+            bool hit = i < n_triggers && j != i && (grp & s_mask[k]) != 0u && (s_group[k] & msk) != 0u;
+            if (hit) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) hit = hit && b[a] <= s_box[k][3 + a] && b[3 + a] >= s_box[k][a];
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m == 0) continue;
+            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(count, static_cast<uint32_t>(__popcll(m)));
+            base = __shfl(base, static_cast<int>(leader), 64);
+            if (hit) {
+                const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+                if (at < cap) out[at] = make_uint2(i | kGhostHit, j);
             }
         }
     }
@@ -1062,6 +1115,15 @@ hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n
     const uint64_t blocks = (n_slots + 255) / 256;
     hipLaunchKernelGGL(k_trigger_pairs, dim3(static_cast<uint32_t>(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, n_slots,
                        n_triggers, t, w, entity_of_slot, count, static_cast<uint2*>(out_pairs), cap, list, list_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_trigger_ghost_pairs(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, uint32_t* count, void* out_pairs,
+                                      uint32_t cap)
+{
+    if (n_triggers < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_trigger_ghost_pairs, grid_for(n_triggers, 256), dim3(256), 0, stream, n_triggers, t, count,
+                       static_cast<uint2*>(out_pairs), cap);
     return hipGetLastError();
 }
 

@@ -126,6 +126,10 @@ hipError_t launch_trigger_aabb(hipStream_t stream, uint32_t n_triggers, const Tr
 hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n_triggers, const TriggerView& t, const WorldView& w,
                                 const uint32_t* entity_of_slot, uint32_t* count, void* out_pairs, uint32_t cap,
                                 const uint32_t* list = nullptr, const uint32_t* list_count = nullptr);
+// ghost against ghost (both directions): appends (i | kGhostHit, j), trigger indices, to the same hit list
+constexpr uint32_t kGhostHit = 0x80000000u;
+hipError_t launch_trigger_ghost_pairs(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, uint32_t* count, void* out_pairs,
+                                      uint32_t cap);
 // compact: 12 floats per root (4x3, the constant fourth column dropped) instead of 16
 hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst,
                              bool compact = false);

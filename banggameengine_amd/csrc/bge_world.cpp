@@ -154,7 +154,9 @@ struct bge_world {
     DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table, grav_palette;
     DevBuf cshape, cmass, cfriction, cinfo, manifold; // ground contact (bge_contact.hip); manifold allocated when the plane is switched on
     DevBuf ground_list, ground_count;                 // slots k_ground_select hands to the solver; count + ticket words
-    std::vector<std::vector<uint32_t>> trig_scratch;  // process_trigger_pairs: this tick's overlaps per trigger (capacity kept)
+    std::vector<std::vector<uint32_t>> trig_scratch;  // process_trigger_pairs: this tick's body overlaps per trigger (capacity kept)
+    std::vector<std::vector<uint32_t>> trig_scratch_ghosts; // ... and the ghosts met, as trigger indices
+    std::vector<uint32_t> trig_union;                 // ... and the union being diffed
     std::vector<uint32_t> trig_pairs_host;            // ... and the downloaded (trigger, entity) hit list
     bool ground_plane = false; // the reference's static plane y = 0 (PhysicsSystem.cpp:149-166); off: free bodies (BASELINE's workloads)
     DevBuf bp_partials; // per-wave bounds / count / widest extent written by the tick kernel for the broadphase (32 B per wave)
@@ -220,13 +222,22 @@ struct bge_world {
         // removes it, so the ghost stays in the world where it last was and keeps reporting overlaps.
         bool frozen = false;
         float frozen_aabb[6] = {0, 0, 0, 0, 0, 0};
-        std::vector<uint32_t> overlaps; // sorted entity indices of the previous tick
+        std::vector<uint32_t> overlaps;       // sorted entity indices of the previous tick: the union of the two lists below
+        std::vector<uint32_t> overlap_bodies; // ... met as rigid bodies (of any type: the pair cache pairs a ghost with Static bodies too)
+        std::vector<uint32_t> overlap_ghosts; // ... met as other trigger ghosts (each of two overlapping ghosts lists the other)
+        void clear_overlaps()
+        {
+            overlaps.clear();
+            overlap_bodies.clear();
+            overlap_ghosts.clear();
+        }
     };
     bool owns_transform(uint32_t e) const
     {
         return e < flat.slot_of_entity.size() && flat.slot_of_entity[e] != bge::kNone && !(e < orphan_host.size() && orphan_host[e]);
     }
-    std::vector<Trigger> triggers;
+    std::vector<Trigger> triggers; // in upload order = the order ProcessTriggerEvents' loop walks them (bge_world.h)
+    std::unordered_map<uint32_t, uint32_t> trig_index_of_entity;
     std::vector<bge_trigger_event> trigger_events; // since the last bge_world_trigger_events
     bool triggers_device_stale = true;
     bool trig_list_on_device = false; // the device arrays are indexed like `triggers` (false between an upload of the list and the next sync)
@@ -475,13 +486,54 @@ void ensure_triggers(bge_world* w)
         if (want != t.runtime_active) {
             t.runtime_active = want;
             t.posed = false;
-            t.overlaps.clear();
+            t.clear_overlaps();
             w->triggers_device_stale = true;
         }
     }
 }
 
-// ProcessTriggerEvents on the pair list the device produced for this tick
+// One trip of ProcessTriggerEvents' loop (PhysicsSystem.cpp:1019-1073) for trigger t: `bodies` = entities met as rigid bodies
+// (sorted), `ghosts` = other triggers met, as indices into w->triggers (any order).  A ghost that has left the world since the
+// lists were made — a one-shot trigger that fired EARLIER in this loop (:1062-1072 removes it at once, and the pair cache takes
+// it out of every other ghost's list) — no longer counts.  An entity met both ways counts once (:1026 std::unordered_set).
+void diff_and_commit_trigger(bge_world* w, bge_world::Trigger& t, std::vector<uint32_t>& bodies, std::vector<uint32_t>& ghosts)
+{
+    size_t kept = 0;
+    for (uint32_t j : ghosts) {
+        if (j < w->triggers.size() && w->triggers[j].runtime_active) ghosts[kept++] = w->triggers[j].entity;
+    }
+    ghosts.resize(kept);
+    std::sort(ghosts.begin(), ghosts.end());
+    std::vector<uint32_t>& cur = w->trig_union;
+    cur.resize(bodies.size() + ghosts.size());
+    cur.erase(std::set_union(bodies.begin(), bodies.end(), ghosts.begin(), ghosts.end(), cur.begin()), cur.end());
+    // (both sets are sorted, so Enter / Stay / Exit come out of two linear merges — with a binary search per overlap the host
+    //  side of 92,000 overlaps a tick took 2.7 ms)
+    const std::vector<uint32_t>& prev = t.overlaps;
+    size_t at = 0;
+    for (uint32_t other : cur) {
+        while (at < prev.size() && prev[at] < other) ++at;
+        const bool was = at < prev.size() && prev[at] == other;
+        w->trigger_events.push_back(bge_trigger_event{was ? 1u : 0u, t.entity, other});
+    }
+    at = 0;
+    for (uint32_t previous : prev) {
+        while (at < cur.size() && cur[at] < previous) ++at;
+        if (!(at < cur.size() && cur[at] == previous)) w->trigger_events.push_back(bge_trigger_event{2u, t.entity, previous});
+    }
+    t.overlaps.swap(cur);
+    t.overlap_bodies.swap(bodies);
+    t.overlap_ghosts.swap(ghosts);
+    if (t.one_shot && !t.overlaps.empty()) {
+        t.component_active = false;
+        t.runtime_active = false; // out of the world, and out of every list, from here on
+        t.clear_overlaps();
+        w->triggers_device_stale = true;
+    }
+}
+
+// ProcessTriggerEvents on the hit list the device produced for this tick: (trigger, body entity) from the all-bodies pass and
+// the grid look-up, (trigger | kGhostHit, other trigger) from the ghost-against-ghost pass
 int process_trigger_pairs(bge_world* w)
 {
     uint32_t counters[3] = {0, 0, 0};
@@ -497,39 +549,49 @@ int process_trigger_pairs(bge_world* w)
         HIP_TRY(hipMemcpyAsync(pairs.data(), w->trig_pairs.p, 2 * static_cast<size_t>(n_pairs) * 4, hipMemcpyDeviceToHost, w->stream));
         HIP_TRY(hipStreamSynchronize(w->stream));
     }
-    // (the per-trigger lists keep their capacity from tick to tick; both sets are sorted, so Enter / Stay / Exit come out of two
-    //  linear merges — with a binary search per overlap the host side of 92,000 overlaps a tick took 2.7 ms)
-    std::vector<std::vector<uint32_t>>& current = w->trig_scratch;
-    if (current.size() < w->triggers.size()) current.resize(w->triggers.size());
-    for (size_t i = 0; i < w->triggers.size(); ++i) current[i].clear();
-    for (uint32_t k = 0; k < n_pairs; ++k) current[pairs[2 * k]].push_back(pairs[2 * k + 1]);
+    // (the per-trigger lists keep their capacity from tick to tick)
+    std::vector<std::vector<uint32_t>>& bodies = w->trig_scratch;
+    std::vector<std::vector<uint32_t>>& ghosts = w->trig_scratch_ghosts;
+    const size_t n_trig = w->triggers.size();
+    if (bodies.size() < n_trig) bodies.resize(n_trig);
+    if (ghosts.size() < n_trig) ghosts.resize(n_trig);
+    for (size_t i = 0; i < n_trig; ++i) {
+        bodies[i].clear();
+        ghosts[i].clear();
+    }
+    for (uint32_t k = 0; k < n_pairs; ++k) {
+        const uint32_t a = pairs[2 * k], b = pairs[2 * k + 1];
+        const uint32_t i = a & ~bge::kGhostHit;
+        if (i >= n_trig) continue;
+        if (a & bge::kGhostHit) ghosts[i].push_back(b);
+        else bodies[i].push_back(b);
+    }
     w->trigger_events.reserve(w->trigger_events.size() + n_pairs + n_pairs / 4);
-    for (size_t i = 0; i < w->triggers.size(); ++i) {
+    for (size_t i = 0; i < n_trig; ++i) {
         bge_world::Trigger& t = w->triggers[i];
         if (!t.runtime_active) continue;
-        std::vector<uint32_t>& cur = current[i];
-        std::sort(cur.begin(), cur.end());
-        const std::vector<uint32_t>& prev = t.overlaps;
-        size_t at = 0;
-        for (uint32_t other : cur) {
-            while (at < prev.size() && prev[at] < other) ++at;
-            const bool was = at < prev.size() && prev[at] == other;
-            w->trigger_events.push_back(bge_trigger_event{was ? 1u : 0u, t.entity, other});
-        }
-        at = 0;
-        for (uint32_t previous : prev) {
-            while (at < cur.size() && cur[at] < previous) ++at;
-            if (!(at < cur.size() && cur[at] == previous)) w->trigger_events.push_back(bge_trigger_event{2u, t.entity, previous});
-        }
-        t.overlaps.swap(cur);
-        if (t.one_shot && !t.overlaps.empty()) {
-            t.component_active = false;
-            t.runtime_active = false;
-            t.overlaps.clear();
-            w->triggers_device_stale = true;
-        }
+        std::sort(bodies[i].begin(), bodies[i].end());
+        diff_and_commit_trigger(w, t, bodies[i], ghosts[i]);
     }
     return BGE_OK;
+}
+
+// ... and in a call that simulates nothing: no collision detection ran, every ghost's list is last call's — minus the ghosts
+// that are no longer in the world (deactivated by EnsureTrigger since, or fired as one-shot earlier in this loop); a volume
+// that was made one-shot since fires on what it remembers (PhysicsSystem.cpp:1062-1072)
+void process_triggers_without_a_step(bge_world* w)
+{
+    std::vector<uint32_t> bodies, ghosts;
+    for (bge_world::Trigger& t : w->triggers) {
+        if (!t.runtime_active) continue;
+        bodies = t.overlap_bodies;
+        ghosts.clear();
+        for (uint32_t e : t.overlap_ghosts) {
+            auto it = w->trig_index_of_entity.find(e);
+            if (it != w->trig_index_of_entity.end()) ghosts.push_back(it->second);
+        }
+        diff_and_commit_trigger(w, t, bodies, ghosts);
+    }
 }
 
 // sum the recorded event pairs into the carry (synchronises the stream)
@@ -641,7 +703,7 @@ try {
                 t.frozen = true;
             } else {
                 t.runtime_active = false; // (never posed: there is no ghost to keep)
-                t.overlaps.clear();
+                t.clear_overlaps();
             }
         }
     }
@@ -799,7 +861,9 @@ try {
     HIP_TRY(w->cmass.ensure(S * 4));
     HIP_TRY(w->cfriction.ensure(S * 4));
     HIP_TRY(w->cinfo.ensure(S * 4));
-    if (w->ground_plane) {
+    // (the manifold store exists from the first time the plane is switched on and then follows every layout, plane on or off:
+    //  the carry above scatters its rows to the NEW slot indices, and k_ground indexes it by slot as soon as the plane is back)
+    if (w->ground_plane || w->manifold.p) {
         HIP_TRY(w->manifold.ensure(S * 128));
         HIP_TRY(hipMemsetAsync(w->manifold.p, 0, w->manifold.bytes, w->stream));
     }
@@ -1374,6 +1438,8 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
                                                   w->trigger_view(), w->view, w->entity_of_slot.as<uint32_t>(), w->trig_count.as<uint32_t>(),
                                                   w->trig_pairs.p, kTriggerPairCap, big_list,
                                                   big_list ? w->trig_count.as<uint32_t>() + 1 : nullptr));
+                HIP_TRY(bge::launch_trigger_ghost_pairs(w->stream, n_trig, w->trigger_view(), w->trig_count.as<uint32_t>(), w->trig_pairs.p,
+                                                        kTriggerPairCap));
                 if (int rc2 = process_trigger_pairs(w)) return rc2;
             }
         }
@@ -1441,18 +1507,7 @@ try {
                                       (flags & BGE_TICK_BULLET_BASIS) != 0));
         w->maybe_dirty = true;
         if (triggers) {
-            // the ghosts' pair caches did not change: ProcessTriggerEvents sees last call's overlaps again -> Stay, and a
-            // volume that was made one-shot since fires on them (PhysicsSystem.cpp:1062-1072)
-            for (bge_world::Trigger& t : w->triggers) {
-                if (!t.runtime_active) continue;
-                for (uint32_t other : t.overlaps) w->trigger_events.push_back(bge_trigger_event{1u, t.entity, other});
-                if (t.one_shot && !t.overlaps.empty()) {
-                    t.component_active = false;
-                    t.runtime_active = false;
-                    t.overlaps.clear();
-                    w->triggers_device_stale = true;
-                }
-            }
+            process_triggers_without_a_step(w);
         }
         const uint32_t rest = flags & (BGE_TICK_TRANSFORMS | BGE_TICK_NORMAL_MATRICES | BGE_TICK_GATHER_ROOTS);
         if (rest & BGE_TICK_TRANSFORMS) return tick_impl(w, 1, step, gravity, rest, sub);
@@ -1486,9 +1541,12 @@ try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     DeviceGuard guard(w->device);
     const bool on = enabled != 0;
-    if (on && w->has_topology && !w->manifold.p) {
+    const uint64_t manifold_bytes = std::max<uint64_t>(w->flat.n_slots, bge::kTile) * 128;
+    if (on && w->has_topology && w->manifold.bytes < manifold_bytes) {
+        // (first use; bge_world_set_topology keeps an existing store sized for the layout, so a smaller one cannot survive —
+        //  checked by size all the same: k_ground loads and stores manifold[32 * slot ..] for every slot of the layout)
         HIP_TRY(hipStreamSynchronize(w->stream));
-        HIP_TRY(w->manifold.ensure(std::max<uint64_t>(w->flat.n_slots, bge::kTile) * 128));
+        HIP_TRY(w->manifold.ensure(manifold_bytes));
         HIP_TRY(hipMemsetAsync(w->manifold.p, 0, w->manifold.bytes, w->stream));
         w->rebuild_view();
     }
@@ -2014,6 +2072,8 @@ try {
             if (o.layer == t.layer && o.mask == t.mask) {
                 t.runtime_active = o.runtime_active;
                 t.overlaps.swap(o.overlaps);
+                t.overlap_bodies.swap(o.overlap_bodies);
+                t.overlap_ghosts.swap(o.overlap_ghosts);
             }
             // (a ghost whose entity has no Transform keeps its place whatever is uploaded: EnsureTrigger does not reach it)
             t.posed = false;
@@ -2023,11 +2083,17 @@ try {
                 std::memcpy(t.frozen_aabb, o.frozen_aabb, 24);
                 t.layer = o.layer;
                 t.mask = o.mask;
-                if (t.overlaps.empty()) t.overlaps.swap(o.overlaps);
+                if (t.overlaps.empty()) {
+                    t.overlaps.swap(o.overlaps);
+                    t.overlap_bodies.swap(o.overlap_bodies);
+                    t.overlap_ghosts.swap(o.overlap_ghosts);
+                }
             }
         }
     }
     w->triggers.swap(next);
+    w->trig_index_of_entity.clear();
+    for (size_t i = 0; i < w->triggers.size(); ++i) w->trig_index_of_entity[w->triggers[i].entity] = static_cast<uint32_t>(i);
     w->triggers_device_stale = true;
     w->trig_list_on_device = false;
     return BGE_OK;

@@ -230,7 +230,14 @@ private:
         t_entity_.clear(); t_shape_.clear(); t_size_.clear(); t_layer_.clear(); t_mask_.clear(); t_oneshot_.clear(); t_active_.clear();
         bool dirty = false;
         seen_trigger_.assign(ids_.size(), 0);
-        for (auto& kv : vols) {
+        // ProcessTriggerEvents' loop order matters once a one-shot trigger overlaps another trigger (bge_world.h): the world walks
+        // the uploaded array, the reference an unordered_map (unspecified order) — ascending EntityId here, as in the oracle
+        t_order_.clear();
+        for (auto& kv : vols) t_order_.push_back(kv.first);
+        std::sort(t_order_.begin(), t_order_.end());
+        for (const auto id : t_order_) {
+            auto vit = vols.find(id);
+            auto& kv = *vit;
             auto it = index_of_.find(kv.first);
             uint32_t index;
             bool without_transform = false;
@@ -276,7 +283,6 @@ private:
                                    static_cast<uint32_t>(t_oneshot_[k] | (t_active_[k] << 1))});
         }
         if (!dirty && sig == t_signature_) return true;
-        // order the set by entity index so that the signature is independent of hash-map iteration order
         t_signature_ = sig;
         if (bge_world_upload_triggers(world_, t_entity_.size(), t_entity_.data(), t_shape_.data(), t_size_.data(), t_layer_.data(),
                                       t_mask_.data(), t_oneshot_.data(), t_active_.data()) != BGE_OK) {
@@ -612,6 +618,7 @@ private:
     std::vector<uint32_t> t_entity_, t_layer_, t_mask_, t_signature_;
     std::vector<uint8_t> t_shape_, t_oneshot_, t_active_;
     std::vector<float> t_size_;
+    std::vector<uint32_t> t_order_; // EntityIds of the scene's TriggerVolumes, ascending
     std::vector<bge_trigger_event> raw_events_;
     std::vector<GpuTriggerEvent> trigger_events_;
 };

@@ -233,8 +233,14 @@ class World:
         return int(total.value)
 
     # -- trigger volumes
-    def upload_triggers(self, entity_index, shape=None, size=None, layer=None, mask=None, one_shot=None, active=None):
+    def upload_triggers(self, entity_index, shape=None, size=None, layer=None, mask=None, one_shot=None, active=None, keep_order=False):
+        """The world processes its triggers in the order of the uploaded array (bge_world.h); unless keep_order is set the set is
+        sent in ascending entity order — the order the oracle's ProcessTriggerEvents walks (oracle/physics_ref.h)."""
         e = _arr(entity_index, np.uint32)
+        if not keep_order and len(e) > 1:
+            order = np.argsort(e, kind="stable")
+            pick = lambda a: None if a is None else np.asarray(a)[order]
+            e, shape, size, layer, mask, one_shot, active = e[order], pick(shape), pick(size), pick(layer), pick(mask), pick(one_shot), pick(active)
         check(lib().bge_world_upload_triggers(self._h, len(e), _p(e), _p(_arr(shape, np.uint8)), _p(_arr(size, np.float32, 3)),
                                               _p(_arr(layer, np.uint32)), _p(_arr(mask, np.uint32)),
                                               _p(_arr(one_shot, np.uint8)), _p(_arr(active, np.uint8))))

@@ -288,11 +288,16 @@ BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, ui
  *       sits on (needs a Transform), shape/size as for colliders, layer (0 is treated as 4, kDefaultTriggerLayer), mask,
  *       oneShot, active.  Triggers that were present before keep their remembered overlaps unless layer/mask changed.
  *   Every BGE_TICK_BROADPHASE tick then (a) poses each active trigger's ghost box from its entity's Transform as it is
- *       BEFORE the step (EnsureTrigger, PhysicsSystem.cpp:575), (b) tests it on the device against the AABB of every
- *       Dynamic / Kinematic body (the ghost is a static object; filter (groupT & maskB) && (groupB & maskT)), (c) diffs the
- *       overlap set with the previous tick's on the host: Enter (0) / Stay (1) / Exit (2).  A one-shot trigger turns
- *       inactive after its first non-empty set and forgets it.  With triggers present such a tick synchronises the
- *       stream (the events are for host code).
+ *       BEFORE the step (EnsureTrigger, PhysicsSystem.cpp:575), (b) tests it on the device against the fed AABB of every
+ *       registered collision object — every rigid body, Static ones included, and every other active trigger ghost (each
+ *       of two overlapping ghosts then reports the other) — with the filter (groupT & maskO) && (groupO & maskT): the
+ *       content of Bullet's pair cache for the ghost (btGhostPairCallback, PhysicsSystem.cpp:132-133; the reference gives
+ *       Bullet custom groups, :473,577, so no static-static exclusion applies; the ghost's own entity is skipped, :1033),
+ *       (c) diffs the overlap set with the previous tick's on the host: Enter (0) / Stay (1) / Exit (2).  A one-shot trigger
+ *       turns inactive after its first non-empty set, forgets it, and leaves the world at once: triggers processed AFTER
+ *       it in the same tick no longer list it (:1062-1072).  The triggers are processed IN THE ORDER OF THE UPLOADED ARRAY
+ *       (the reference walks a std::unordered_map — an order the language leaves open; the C++ adapter and the oracle use
+ *       ascending EntityId).  With triggers present such a tick synchronises the stream (the events are for host code).
  *   bge_world_trigger_events returns (and clears) the events accumulated since the previous call.
  *   bge_world_trigger_active reports TriggerVolume::active per queried entity (0 after a one-shot fired, or no trigger).
  *   With more than 64 triggers (BGE_TRIGGER_GRID_MIN overrides the number) step (b) changes: a ghost whose box covers at
@@ -303,7 +308,7 @@ BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, ui
 typedef struct bge_trigger_event {
     uint32_t type;    /* 0 Enter, 1 Stay, 2 Exit (PhysicsSystem::TriggerEvent::Type, src/physics/PhysicsSystem.h:50-62) */
     uint32_t trigger; /* entity index of the trigger */
-    uint32_t other;   /* entity index of the body */
+    uint32_t other;   /* entity index of the body or of the other trigger */
 } bge_trigger_event;
 BGE_API int bge_world_upload_triggers(bge_world* world, uint64_t count, const uint32_t* entity_index, const uint8_t* shape,
                                       const float* size3, const uint32_t* layer, const uint32_t* mask,

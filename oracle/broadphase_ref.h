@@ -9,8 +9,14 @@
 //   three axes with NON-strict comparisons (btDbvtAabbMm Intersect: a.min <= b.max && a.max >= b.min)
 //   AND the collision filter passes both ways (btOverlapFilterCallback default:
 //   (groupA & maskB) && (groupB & maskA), group = layer ? layer : 1 — PhysicsSystem.cpp:407-408,473)
-//   AND at least one of the two bodies is not Static (static-static pairs are never produced:
-//   both proxies sit in the fixed dbvt set, which is not collided against itself).
+//   AND at least one of the two bodies is not Static.  That last clause is a SPECIFICATION CHOICE, not Bullet's pair cache:
+//   btDbvtBroadphase::createProxy / ::setAabb collide a new or moved leaf against BOTH of its trees and
+//   btHashedOverlappingPairCache::needsBroadphaseCollision tests group / mask only (oracle/tools/check_pair_cache.py reads
+//   both off the reference's exe), and the reference hands Bullet custom groups (addRigidBody(body, layer, mask),
+//   PhysicsSystem.cpp:473), so two overlapping Static bodies DO share a cache entry there.  The entry is inert:
+//   btCollisionDispatcher::needsCollision rejects a pair of inactive objects before any narrowphase, and the reference never
+//   exposes the body-body pair list.  The list specified here is "the pairs that can reach the narrowphase"; where cache
+//   membership is observable — trigger ghosts, which list Static bodies and each other — physics_ref.h follows the cache.
 //
 // Two implementations: O(n^2) brute force and sort-and-sweep on x; tests require they agree.
 // PARITY STATUS: "parity unpinned" (spec-derived).

@@ -122,10 +122,29 @@ struct RefBodyRuntime {
 //   src/physics/PhysicsSystem.cpp:1017-1074 ProcessTriggerEvents: current overlap set vs the previous one ->
 //                                            Enter / Stay / Exit; a one-shot trigger deactivates after its first
 //                                            non-empty set and forgets it (no Exit later)
-// The ghost's overlap list is Bullet's pair cache restricted to the ghost; as for the broadphase the specification here
-// is its history-free core: the ghost's AABB (shape AABB at its pose + 0.02) overlaps the body's fed AABB, the collision
-// filter passes both ways, and the body is not Static (the ghost itself is a static object).  Trigger-trigger pairs
-// (static-static) are not produced.  PARITY STATUS: unpinned (spec-derived).
+// The ghost's overlap list (btPairCachingGhostObject::m_overlappingObjects) is Bullet's pair cache restricted to the ghost:
+// btGhostPairCallback::addOverlappingPair (installed at PhysicsSystem.cpp:132-133) is called by
+// btHashedOverlappingPairCache::addOverlappingPair for EVERY pair the broadphase reports whose filter passes
+// (needsBroadphaseCollision: (group0 & mask1) && (group1 & mask0) — group / mask are the custom values the reference hands
+// to addRigidBody / addCollisionObject, PhysicsSystem.cpp:473,577, so Bullet's default "static objects do not collide with
+// static objects" mask is NOT in force) and records the other proxy's object in each of the two objects that is a ghost.
+// btDbvtBroadphase::createProxy and ::setAabb collide a new / moved leaf against BOTH of its trees, so a ghost pairs with
+// Static, Kinematic and Dynamic bodies alike AND with other ghosts (each of the two then lists the other).  As for the
+// broadphase the specification is the history-free core of that cache: the ghost's AABB (shape AABB at its pose + 0.02,
+// updateSingleAabb) overlaps the other object's fed AABB non-strictly and the filter passes both ways.  The reference maps
+// objects to entities (FindEntityByCollisionObject, :672): rigid bodies (:474,491) and ghosts (:578) are registered, the
+// ground plane is not (kInvalidEntity, skipped at :1033), the ghost's own entity is skipped (:1033) — so an entity that
+// carries both a RigidBody and a TriggerVolume does not report itself — and an entity met both as a body and as a ghost
+// counts once (std::unordered_set, :1026).
+// One-shot and ghost-ghost: a one-shot trigger that fires is removed from the world INSIDE the loop of ProcessTriggerEvents
+// (:1062-1072: removeCollisionObject -> the pair cache drops its pairs -> btGhostPairCallback::removeOverlappingPair takes it
+// out of every other ghost's list at once), so a ghost processed LATER in the same loop no longer lists it.  The reference
+// walks m_triggerRuntime, a std::unordered_map (PhysicsSystem.h) — an order the language leaves unspecified (MSVC's differs
+// from libstdc++'s); the specification here fixes it: ASCENDING ENTITY ID.
+// A call that simulates nothing (accumulate, n == 0) runs no collision detection: every list keeps last call's content,
+// minus the ghosts that are no longer in the world (deactivated by EnsureTrigger, or fired as one-shot earlier in the loop).
+// PARITY STATUS: unpinned (spec-derived); the three Bullet functions named above are located in the reference's exe and
+// their tests read off the disassembly by oracle/tools/check_pair_cache.py.
 struct RefTriggerEvent {
     int type; // 0 Enter, 1 Stay, 2 Exit   (PhysicsSystem.h:50-62)
     EntityId trigger;
@@ -139,7 +158,15 @@ struct RefTriggerRuntime {
     uint32_t layer = 0, mask = 0;
     bt::Vec3 aabbHalfExtents{0.5f, 0.5f, 0.5f};
     float aabbMin[3] = {0, 0, 0}, aabbMax[3] = {0, 0, 0};
-    std::vector<EntityId> overlaps; // sorted
+    std::vector<EntityId> overlaps;      // sorted; the union of the two below = TriggerRuntime::overlaps (what the events are diffed on)
+    std::vector<EntityId> overlapBodies; // sorted: entities met as rigid bodies
+    std::vector<EntityId> overlapGhosts; // sorted: entities met as other trigger ghosts
+    void ClearOverlaps()
+    {
+        overlaps.clear();
+        overlapBodies.clear();
+        overlapGhosts.clear();
+    }
 };
 
 class RefPhysicsSystem {
@@ -464,45 +491,73 @@ private:
             bt::AabbOfPose(origin, basis, rt.aabbHalfExtents, rt.aabbMin, rt.aabbMax);
             if (!rt.active) {
                 rt.active = true;
-                rt.overlaps.clear();
+                rt.ClearOverlaps();
             }
         } else if (rt.active) {
             rt.active = false;
-            rt.overlaps.clear();
+            rt.ClearOverlaps();
         }
+    }
+
+    static bool BoxesOverlap(const float* amn, const float* amx, const float* bmn, const float* bmx)
+    {
+        bool overlap = true;
+        for (int a = 0; a < 3; ++a) overlap = overlap && amn[a] <= bmx[a] && amx[a] >= bmn[a];
+        return overlap;
     }
 
     void ProcessTriggerEvents(RefScene& scene, bool noStep = false)
     {
         events_.clear();
-        for (auto& kv : triggerRuntime_) {
-            RefTriggerVolume* trigger = scene.GetTriggerVolume(kv.first);
-            RefTriggerRuntime& rt = kv.second;
+        // (:1019 walks an unordered_map: unspecified order, fixed here — see the header — as ascending entity id)
+        std::vector<EntityId> order;
+        order.reserve(triggerRuntime_.size());
+        for (const auto& kv : triggerRuntime_) order.push_back(kv.first);
+        std::sort(order.begin(), order.end());
+        for (EntityId id : order) {
+            RefTriggerVolume* trigger = scene.GetTriggerVolume(id);
+            RefTriggerRuntime& rt = triggerRuntime_[id];
             if (!trigger || !rt.hasGhost || !rt.active) continue;
-            std::vector<EntityId> current;
-            if (noStep) current = rt.overlaps; // no collision detection ran: the ghost's pair cache is last call's
-            for (const auto& bk : runtime_) {
-                if (noStep) break;
-                const RefBodyRuntime& b = bk.second;
-                if (!b.hasBody || bk.first == kv.first || b.type == RefBodyType::Static) continue;
-                if ((rt.layer & b.mask) == 0 || (b.layer & rt.mask) == 0) continue;
-                bool overlap = true;
-                for (int a = 0; a < 3; ++a) overlap = overlap && rt.aabbMin[a] <= b.aabbMax[a] && rt.aabbMax[a] >= b.aabbMin[a];
-                if (overlap) current.push_back(bk.first);
+            std::vector<EntityId> bodies, ghosts;
+            if (noStep) {
+                // no collision detection ran: the ghost's list is last call's, minus the ghosts no longer in the world
+                bodies = rt.overlapBodies;
+                for (EntityId g : rt.overlapGhosts) {
+                    auto it = triggerRuntime_.find(g);
+                    if (it != triggerRuntime_.end() && it->second.hasGhost && it->second.active) ghosts.push_back(g);
+                }
+            } else {
+                for (const auto& bk : runtime_) { // every registered rigid body, whatever its type (:474)
+                    const RefBodyRuntime& b = bk.second;
+                    if (!b.hasBody || bk.first == id) continue;
+                    if ((rt.layer & b.mask) == 0 || (b.layer & rt.mask) == 0) continue;
+                    if (BoxesOverlap(rt.aabbMin, rt.aabbMax, b.aabbMin, b.aabbMax)) bodies.push_back(bk.first);
+                }
+                for (const auto& gk : triggerRuntime_) { // every other ghost that is in the world right now (:578)
+                    const RefTriggerRuntime& g = gk.second;
+                    if (gk.first == id || !g.hasGhost || !g.active) continue;
+                    if ((rt.layer & g.mask) == 0 || (g.layer & rt.mask) == 0) continue;
+                    if (BoxesOverlap(rt.aabbMin, rt.aabbMax, g.aabbMin, g.aabbMax)) ghosts.push_back(gk.first);
+                }
+                std::sort(bodies.begin(), bodies.end());
+                std::sort(ghosts.begin(), ghosts.end());
             }
-            std::sort(current.begin(), current.end());
+            std::vector<EntityId> current(bodies.size() + ghosts.size());
+            current.erase(std::set_union(bodies.begin(), bodies.end(), ghosts.begin(), ghosts.end(), current.begin()), current.end());
             for (EntityId other : current) {
                 const bool was = std::binary_search(rt.overlaps.begin(), rt.overlaps.end(), other);
-                events_.push_back(RefTriggerEvent{was ? 1 : 0, kv.first, other});
+                events_.push_back(RefTriggerEvent{was ? 1 : 0, id, other});
             }
             for (EntityId previous : rt.overlaps) {
-                if (!std::binary_search(current.begin(), current.end(), previous)) events_.push_back(RefTriggerEvent{2, kv.first, previous});
+                if (!std::binary_search(current.begin(), current.end(), previous)) events_.push_back(RefTriggerEvent{2, id, previous});
             }
             rt.overlaps = std::move(current);
+            rt.overlapBodies = std::move(bodies);
+            rt.overlapGhosts = std::move(ghosts);
             if (rt.oneShot && !rt.overlaps.empty()) {
                 trigger->active = false;
-                rt.active = false;
-                rt.overlaps.clear();
+                rt.active = false; // removeCollisionObject: gone from every other ghost's list from here on
+                rt.ClearOverlaps();
             }
         }
     }

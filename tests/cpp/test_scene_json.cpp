@@ -121,6 +121,14 @@ static void RunCase(const std::string& text, const char* what, bool gpu)
             std::sort(b.begin(), b.end());
             CHECK(a == b, "%s: trigger events of tick %d differ (%zu vs %zu)", what, k, a.size(), b.size());
             g_events += a.size();
+            if (std::strcmp(what, "demo.json") == 0) {
+                // the reference's own scene: the Checkpoint ghost overlaps Ground, a Static body — Bullet's pair cache pairs them
+                // (custom groups, PhysicsSystem.cpp:473,577): Enter on the first Update, Stay on every later one
+                const uint32_t cp = keys_gpu["checkpoint"], ground = keys_gpu["ground"];
+                const std::vector<std::array<uint32_t, 3>> expect{{k == 0 ? 0u : 1u, cp, ground}};
+                CHECK(b == expect, "demo.json: tick %d must publish %s(checkpoint, ground); the adapter published %zu events", k, k == 0 ? "Enter" : "Stay", b.size());
+                CHECK(a == expect, "demo.json: tick %d, oracle: %zu events", k, a.size());
+            }
         }
         orc::RefTransformSystemUpdate(ref);
         bge::GpuTransformSystem<bge::Scene>::Update(scene);

@@ -620,6 +620,81 @@ def test_trigger_events_match_oracle_every_tick(grid_min, monkeypatch):
     assert seen_types == {0, 1, 2}                              # the scene really produced Enter, Stay and Exit
 
 
+@pytest.mark.parametrize("grid_min", [None, 0])
+def test_triggers_list_static_bodies_and_each_other(grid_min, monkeypatch):
+    """VERDICT r02 item 1.  The reference's own scene (assets/scenes/demo.json:67-107): the Checkpoint ghost overlaps Ground, a
+    Static box — Bullet's pair cache pairs them (custom groups, PhysicsSystem.cpp:473,577), so the reference publishes
+    Enter(checkpoint, ground) on the first Update and Stay afterwards; so must the C ABI, in the all-bodies pass and through
+    the grid look-up.  Then two more ghosts: overlapping ghosts list each other, an entity that is a body and a ghost does not
+    list itself, a one-shot ghost that fires leaves the world inside the loop (ascending entity order), a ghost whose
+    layer / mask changes forgets.  Explicit expectations for the demo part, the oracle for all of it."""
+    if grid_min is not None:
+        monkeypatch.setenv("BGE_TRIGGER_GRID_MIN", str(grid_min))
+    # entity 0 Ground, 1 Checkpoint, 2 a Kinematic body that is a ghost too, 3 a one-shot ghost, 4 a Dynamic body falling through them
+    pos = np.array([[0, -0.01, 0], [5, 1, 5], [6, 1.5, 5], [5.5, 2.0, 4.5], [5.2, 3.2, 5.1]], np.float32)
+    scale = np.array([[0.05, 1, 0.05], [1, 1, 1], [1, 1, 1], [1, 1, 1], [1, 1, 1]], np.float32)
+    euler = np.zeros((5, 3), np.float32)
+    body_type = np.array([0, 255, 2, 255, 1], np.uint8)
+    size = np.array([[50, 1, 50], [.5, .5, .5], [.5, .5, .5], [.5, .5, .5], [.3, .3, .3]], np.float32)
+    parent = np.full(5, 0xFFFFFFFF, np.uint32)
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, True)
+    ref.bulk_build(parent_i32(parent), pos, euler, scale, body_type=body_type, size=size)
+    ref.AddTriggerVolume(2, 0, (1.5, 1.5, 1.5), 4, 0xFFFFFFFF, False, True)
+    flags = B.TICK_ALL | B.TICK_BROADPHASE
+    t_entities = np.array([1], np.uint32)
+    t_size = np.array([[1.5, 1.5, 1.5]], np.float32)
+    t_layer = np.array([4], np.uint32)
+    t_mask = np.array([0xFFFFFFFF], np.uint32)
+    t_oneshot = np.array([0], np.uint8)
+
+    def both(w, tick):
+        ref.PhysicsSystemUpdate(DT)
+        ref.TransformSystemUpdate()
+        w.tick(dt=DT, flags=flags)
+        want = ref.TriggerEvents()
+        want[:, 1:] -= 1
+        got = w.trigger_events()
+        assert np.array_equal(got, want), f"tick {tick}: got {got.tolist()} oracle {want.tolist()}"
+        return [tuple(r) for r in got.tolist()]
+
+    seen = set()
+    with B.World(pair_capacity=4096) as w:
+        w.set_topology(parent)
+        w.upload_trs(pos, euler, scale)
+        w.upload_bodies(body_type, size=size)
+        w.upload_triggers(t_entities, None, t_size, t_layer, t_mask, t_oneshot, None)
+        assert both(w, 0) == [(0, 1, 0), (0, 1, 2)]             # Enter(checkpoint, ground) — and the Kinematic body beside it
+        assert both(w, 1) == [(1, 1, 0), (1, 1, 2)]             # Stay
+        # two more ghosts: entity 2 (a Kinematic body as well) and entity 3 (one-shot)
+        ref.AddTriggerVolume(3, 0, (1.0, 1.0, 1.0), 0, 0xFFFFFFFF, False, True)
+        ref.AddTriggerVolume(4, 0, (0.6, 0.6, 0.6), 0, 0xFFFFFFFF, True, True)
+        t_entities = np.array([3, 1, 2], np.uint32)             # (any order: the plumbing sends ascending entities)
+        t_size = np.array([[0.6, 0.6, 0.6], [1.5, 1.5, 1.5], [1.0, 1.0, 1.0]], np.float32)
+        t_layer = np.array([0, 4, 0], np.uint32)
+        t_mask = np.array([0xFFFFFFFF] * 3, np.uint32)
+        t_oneshot = np.array([1, 0, 0], np.uint8)
+        w.upload_triggers(t_entities, None, t_size, t_layer, t_mask, t_oneshot, None)
+        ev = both(w, 2)
+        assert (1, 1, 2) in ev and (0, 2, 1) in ev and (1, 1, 0) in ev      # ghost 2 lists ghost 1 (1 knew entity 2 as a body already); Ground stays
+        assert (0, 2, 2) not in ev and (0, 3, 1) in ev and (0, 1, 3) in ev  # nobody lists itself; 3 fired AFTER 1 and 2 had listed it
+        assert not w.trigger_active(np.array([3], np.uint32))[0]
+        ev = both(w, 3)
+        assert (2, 1, 3) in ev and (2, 2, 3) in ev                           # ... and is gone from their lists one tick later
+        for tick in range(4, 135):                                           # the Dynamic body falls through the ghosts onto nothing
+            seen |= set(both(w, tick))
+        assert (0, 1, 4) in seen and (0, 2, 4) in seen and (2, 1, 4) in seen
+        # ghost 2 stops listening to layer 4 (the ghosts' layer): the ghost pair goes; its BODY (layer 1) still meets ghost 1
+        ref.AddTriggerVolume(3, 0, (1.0, 1.0, 1.0), 0, 0xFFFFFFFB, False, True)
+        t_mask = np.array([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFB], np.uint32)
+        act = w.trigger_active(t_entities).astype(np.uint8)
+        w.upload_triggers(t_entities, None, t_size, t_layer, t_mask, t_oneshot, act)
+        ev = both(w, 135)
+        assert (1, 1, 2) in ev and (0, 2, 1) not in ev and (1, 2, 1) not in ev
+        through_grid, against_all = w.trigger_query_stats()
+        assert (through_grid > 0) == (grid_min == 0)
+
+
 def test_many_triggers_through_the_grid_match_oracle():
     """with more than 64 trigger volumes the ghosts that cover few cells walk the broadphase's sorted
     grid (Broadphase::query_boxes) and only the wide ones are tested against every body.  600 ghosts from 0.2 to 60 units
@@ -904,6 +979,85 @@ def test_ground_plane_at_a_size_that_wraps_the_solver_work_list(basis):
                     assert cn[e] == rn, f"tick {tick}: body {e} has {cn[e]} contacts, oracle {rn}"
         assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world matrices at the end")
     assert {1, 2} <= states, states       # awake and asleep bodies side by side at the end
+
+
+def test_ground_plane_switched_off_then_scene_grows_then_on_again():
+    """the contact manifold store follows the slot layout whether the plane is on or off.  Bodies land and rest
+    on the plane, the plane goes off (they fall on), the scene grows across several tile boundaries (bge_world_set_topology
+    carries the manifold rows to the new slots), the plane comes back: the grown world's solver indexes manifold[32 * slot]
+    for every slot of the NEW layout.  Positions, velocities, contact counts and points against the oracle, bit for bit."""
+    n0, n1 = 500, 1500
+    rng = np.random.default_rng(31)
+    wl = synth.Workload("ground-grow", synth.FLAT, n1, 1234)
+    wl.pos[:, 0] = rng.uniform(-30, 30, n1).astype(np.float32)
+    wl.pos[:, 2] = rng.uniform(-30, 30, n1).astype(np.float32)
+    wl.pos[:, 1] = rng.uniform(0.3, 1.2, n1).astype(np.float32)
+    wl.body_type[:] = 1
+    size = rng.uniform(0.2, 0.6, (n1, 3)).astype(np.float32)
+    mass = rng.choice([0.5, 1.0, 3.0], n1).astype(np.float32)
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, False)
+    ref.bulk_build(parent_i32(wl.parent[:n0]), wl.pos[:n0], wl.euler[:n0], wl.scale[:n0], body_type=wl.body_type[:n0], size=size[:n0], mass=mass[:n0])
+    ref.SetGroundPlane(True)
+
+    def compare(w, n, what):
+        pos, euler = w.download_pose()
+        rpos, reuler = ref.bulk_pose()
+        assert_bits_equal(pos, rpos, f"{what}: position")
+        assert_bits_equal(euler, reuler, f"{what}: rotationEuler")
+        rb, gb = ref.bulk_bodies(), w.download_bodies()
+        assert_bits_equal(gb["linvel"], rb["linvel"], f"{what}: linear velocity")
+        assert_bits_equal(gb["angvel"], rb["angvel"], f"{what}: angular velocity")
+        cn, cpts = w.download_contacts()
+        for e in range(0, n, 3):
+            rn, rpts = ref.GroundContacts(e + 1)
+            assert cn[e] == rn, f"{what}: body {e} has {cn[e]} contacts, oracle {rn}"
+            assert_bits_equal(cpts[e, :rn], rpts, f"{what}: contact points of body {e}")
+        return cn
+
+    with B.World() as w:
+        w.set_topology(wl.parent[:n0])
+        w.upload_trs(wl.pos[:n0], wl.euler[:n0], wl.scale[:n0])
+        w.upload_bodies(wl.body_type[:n0], mass=mass[:n0], size=size[:n0])
+        w.set_ground_plane(True)
+        for tick in range(90):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT)
+        cn = compare(w, n0, "resting, plane on")
+        assert (cn[:n0] > 0).sum() > 0.8 * n0
+        ref.SetGroundPlane(False)
+        w.set_ground_plane(False)
+        for tick in range(12):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT)
+        compare(w, n0, "falling, plane off")
+        # the scene grows from 2 tiles to 6 while the plane is off
+        for k in range(n0, n1):
+            eid = ref.CreateEntity()
+            ref.AddTransform(eid, wl.pos[k], wl.euler[k], wl.scale[k])
+            ref.AddCollider(eid, 0, size[k])
+            ref.AddRigidBody(eid, po.BODY_DYNAMIC, float(mass[k]))
+        ref.n = n1
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos[n0:], wl.euler[n0:], wl.scale[n0:], first=n0)
+        w.upload_bodies(wl.body_type[n0:], mass=mass[n0:], size=size[n0:], first=n0)
+        for tick in range(3):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT)
+        ref.SetGroundPlane(True)
+        w.set_ground_plane(True)
+        for tick in range(120):
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT)
+            if tick in (0, 1, 40):
+                compare(w, n1, f"plane on again, tick {tick}")
+        cn = compare(w, n1, "the grown scene at rest")
+        assert (cn[n0:] > 0).sum() > 0.8 * (n1 - n0)       # the new bodies (slots beyond the old layout) rest on contacts
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world matrices at the end")
 
 
 def test_transform_fixtures_incl_multi_pass_layouts():

@@ -288,3 +288,85 @@ def test_body_and_trigger_ghost_live_on_when_the_entity_loses_its_transform():
     ref.PhysicsSystemUpdate(dt)
     body = ref.GetBody(faller)
     assert abs(body["origin"][1] - 20.0) < 0.01 and np.allclose(body["linvel"], [0.0, -9.81 * dt, 0.0], atol=1e-6)
+
+
+def _trigger_scene():
+    """The geometry of the reference's own scene (assets/scenes/demo.json:67-107): Ground, a Static 50 x 1 x 50 box whose centre is
+    at y = -0.01 (layer 1, mask all), and Checkpoint, a trigger box of half extent 1.5 at (5, 1, 5) (layer 4, mask all)."""
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, True)
+    ground = ref.CreateEntity()
+    ref.AddTransform(ground, (0.0, -0.01, 0.0), (0, 0, 0), (0.05, 1.0, 0.05))
+    ref.AddCollider(ground, 0, (50.0, 1.0, 50.0))
+    ref.AddRigidBody(ground, po.BODY_STATIC, 0.0, 1, 0xFFFFFFFF)
+    checkpoint = ref.CreateEntity()
+    ref.AddTransform(checkpoint, (5.0, 1.0, 5.0), (0, 0, 0), (1, 1, 1))
+    ref.AddTriggerVolume(checkpoint, 0, (1.5, 1.5, 1.5), 4, 0xFFFFFFFF, False, True)
+    return ref, ground, checkpoint
+
+
+def _events(ref):
+    return [tuple(int(x) for x in row) for row in ref.TriggerEvents()]
+
+
+def test_demo_scene_checkpoint_enters_the_static_ground_then_stays():
+    """Bullet's pair cache pairs a ghost with every registered object whose filter passes, Static bodies
+    included (the reference hands Bullet custom groups, PhysicsSystem.cpp:473,577) — so in the reference's own demo.json the
+    Checkpoint ghost (y in [-0.52, 2.52]) overlaps Ground (y in [-1.03, 1.01]): Enter on the first Update, Stay every tick after."""
+    ref, ground, checkpoint = _trigger_scene()
+    ref.PhysicsSystemUpdate(1 / 120)
+    assert _events(ref) == [(0, checkpoint, ground)]
+    for _ in range(3):
+        ref.PhysicsSystemUpdate(1 / 120)
+        assert _events(ref) == [(1, checkpoint, ground)]
+    # the ground moves away (a Static body follows its dirty Transform): Exit
+    ref.SetTRS(ground, pos=(0.0, -5.0, 0.0))
+    ref.PhysicsSystemUpdate(1 / 120)
+    assert _events(ref) == [(2, checkpoint, ground)]
+    # a body whose mask lacks the ghost's layer (4) is not listed; neither is a ghost whose mask lacks the body's layer
+    ref.SetTRS(ground, pos=(0.0, -0.01, 0.0))
+    ref.AddRigidBody(ground, po.BODY_STATIC, 0.0, 1, 0xFFFFFFFB)
+    ref.PhysicsSystemUpdate(1 / 120)
+    assert _events(ref) == []
+
+
+def test_two_overlapping_triggers_report_each_other():
+    """Ghost against ghost: both are registered collision objects (PhysicsSystem.cpp:578), btGhostPairCallback serves both
+    proxies of a pair, so each lists the other.  An entity that carries a body AND a trigger does not list itself (:1033)."""
+    ref, ground, a = _trigger_scene()
+    b = ref.CreateEntity()
+    ref.AddTransform(b, (6.0, 1.5, 5.0), (0, 0, 0), (1, 1, 1))
+    ref.AddTriggerVolume(b, 0, (1.0, 1.0, 1.0), 0, 0xFFFFFFFF, False, True)     # layer 0 -> 4
+    ref.AddCollider(b, 0, (0.5, 0.5, 0.5))
+    ref.AddRigidBody(b, po.BODY_KINEMATIC, 0.0, 1, 0xFFFFFFFF)                   # b is a body as well: a meets it twice, once counts
+    ref.PhysicsSystemUpdate(1 / 120)
+    assert _events(ref) == [(0, a, ground), (0, a, b), (0, b, ground), (0, b, a)]
+    ref.PhysicsSystemUpdate(1 / 120)
+    assert _events(ref) == [(1, a, ground), (1, a, b), (1, b, ground), (1, b, a)]
+    # b's mask drops layer 4 (the ghosts' layer): the ghost pair goes — b's body (layer 1, its own mask) still meets ghost a
+    ref.AddTriggerVolume(b, 0, (1.0, 1.0, 1.0), 0, 0xFFFFFFFB, False, True)
+    ref.PhysicsSystemUpdate(1 / 120)
+    assert _events(ref) == [(0, b, ground), (1, a, ground), (1, a, b)]            # (layer / mask change: b's ghost is re-added, its memory gone)
+
+
+@pytest.mark.parametrize("one_shot_first", [True, False])
+def test_a_one_shot_trigger_leaves_the_world_inside_the_loop(one_shot_first):
+    """ProcessTriggerEvents removes a fired one-shot ghost at once (PhysicsSystem.cpp:1062-1072): ghosts processed later in the
+    same loop no longer list it.  The loop order is an unordered_map's in the reference; the specification fixes ascending id."""
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(-9.81, po.ORIENT_IDEAL, True)
+    lo, hi = ref.CreateEntity(), ref.CreateEntity()
+    for e, x in ((lo, 0.0), (hi, 0.5)):
+        ref.AddTransform(e, (x, 0.0, 0.0), (0, 0, 0), (1, 1, 1))
+    ref.AddTriggerVolume(lo, 0, (1, 1, 1), 0, 0xFFFFFFFF, one_shot_first, True)
+    ref.AddTriggerVolume(hi, 0, (1, 1, 1), 0, 0xFFFFFFFF, not one_shot_first, True)
+    ref.PhysicsSystemUpdate(1 / 120)
+    if one_shot_first:
+        assert _events(ref) == [(0, lo, hi)]          # lo fired and left before hi was processed
+        ref.PhysicsSystemUpdate(1 / 120)
+        assert _events(ref) == []
+    else:
+        assert _events(ref) == [(0, lo, hi), (0, hi, lo)]
+        ref.PhysicsSystemUpdate(1 / 120)
+        assert _events(ref) == [(2, lo, hi)]          # hi fired after lo had listed it: lo sees it gone one tick later
+    assert ref.TriggerIsActive(lo) != one_shot_first and ref.TriggerIsActive(hi) == one_shot_first
