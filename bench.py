@@ -14,7 +14,9 @@ Workloads (BASELINE.json `configs`):
             (configs[2]), cube4m (configs[3], with the broadphase), flat 16 M (the working set beyond the Infinity
             Cache: the honest HBM figure) and flat1m in Bullet's own orientation scheme.
     N > 1 : "subtree64" — configs[4] (variant 5b): 2,000,000 entities PER GPU in 64-node subtrees whose
-            roots are Dynamic bodies; shards are whole subtrees; gather of 31,250 root matrices per rank per step.
+            roots are Dynamic bodies; shards are whole subtrees; gather of 31,250 root matrices per rank per step.  The line
+            carries its own anchor: `single_gpu_same_workload` (rank 0's shard ticked alone, before the communicator exists),
+            `scaling_efficiency` = value / (N x that), and compute-only against compute + collective ms per step.
             ("chains4_shard" = variant 5a, 500,000 roots per rank, is selectable with --workload.)
 
 Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF:
@@ -73,8 +75,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` array (other single-GPU configurations)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the cpu_baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-core CPU leg (a 1-GPU box's CPU share)")
-    ap.add_argument("--deadline", type=float, default=240.0,
-                    help="seconds any one blocking phase of a rank may take (and, x3, the launcher's limit for the whole job)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is run this many times back to back (each bracketed by barrier + synchronize, "
+                         "max over ranks); the MEDIAN region is reported — a 20-launch region is 0.5 ms, one cold sample of it is noise")
+    ap.add_argument("--deadline", type=float, default=180.0,
+                    help="seconds any one blocking phase of a rank may take (and, x3 = 540 s, the launcher's limit for the whole job: "
+                         "inside the driver's 600 s)")
     return ap.parse_args(argv)
 
 
@@ -278,7 +284,7 @@ CONFIG_TEXT = {
 }
 
 
-def measure_extra_config(B, synth, torch, label, name, entities, steps, warmup, bullet_basis, check):
+def measure_extra_config(B, synth, torch, label, name, entities, steps, warmup, bullet_basis, check, repeats=3):
     """One more single-GPU configuration, measured like the headline (event pair around the K launches) after it."""
     from banggameengine_amd.world import FIXED_DT, GRAVITY
     wl = synth.config(name, n=entities)
@@ -290,18 +296,21 @@ def measure_extra_config(B, synth, torch, label, name, entities, steps, warmup, 
         world.tick(dt=FIXED_DT, flags=B.TICK_ALL | (B.TICK_BULLET_BASIS if bullet_basis else 0))
         world.set_velocities(wl.vel)
         world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags, ticks=warmup)
-        torch.cuda.synchronize()
-        world.profile_enable(1)
-        t0 = time.perf_counter()
-        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags, ticks=steps)
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        ms, ticks = world.profile_read()
+        walls, kernels = [], []
+        for _ in range(repeats):   # median of `repeats` regions of `steps` launches each, like the headline
+            torch.cuda.synchronize()
+            world.profile_enable(1)
+            t0 = time.perf_counter()
+            world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=flags, ticks=steps)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+            ms, ticks = world.profile_read()
+            assert ticks == steps
+            kernels.append(ms / ticks)
         world.profile_enable(0)
-        assert ticks == steps
-        kernel_ms = ms / ticks
+        wall, kernel_ms = sorted(walls)[repeats // 2], sorted(kernels)[repeats // 2]
         bpu = wl.bytes_per_update
-        out = {"label": label, "workload": name, "entities": wl.n, "steps": steps, "warmup": warmup}
+        out = {"label": label, "workload": name, "entities": wl.n, "steps": steps, "warmup": warmup, "repeats": repeats}
         if name == "cube4m":
             pairs = world.pair_count()
             bpu = 208.0 + 8.0 * pairs / wl.n
@@ -316,7 +325,7 @@ def measure_extra_config(B, synth, torch, label, name, entities, steps, warmup, 
             "algorithmic_bytes_per_launch": bpu * wl.n, "achieved_gbs": achieved, "frac": achieved / HBM_PEAK_GBS,
         })
         if check:
-            out["parity"] = parity_sample(world, name, 0, warmup + steps, bullet_basis)
+            out["parity"] = parity_sample(world, name, 0, warmup + steps * repeats, bullet_basis)
         return out
     finally:
         world.close()
@@ -464,6 +473,35 @@ def run_rank(args):
 
     gather = (n_gpus > 1 and not args.no_gather) or args.force_gather
     n_roots = info["n_roots"]
+
+    # The scaling curve's anchor, in the SAME line: before any communicator exists every rank ticks its own
+    # shard alone — same workload, same K, same timing (barrier-free wall clock around a synchronised batch + one HIP event pair
+    # around the K launches) — so that value / (N x that) can be read without a second run.
+    solo = None
+    if n_gpus > 1 or args.force_gather:
+        with deadlines.phase("single-GPU anchor (this rank's shard, no collective)"):
+            if args.warmup:
+                tick(flags, args.warmup)
+            dev_sync()
+            regions, kernels = [], []
+            for _ in range(max(1, args.repeats)):
+                world.profile_enable(1)
+                dev_sync()
+                ta = time.perf_counter()
+                tick(flags, args.steps)
+                dev_sync()
+                regions.append(time.perf_counter() - ta)
+                k_ms, k_ticks = world.profile_read()
+                kernels.append(k_ms / max(k_ticks, 1))
+            world.profile_enable(0)
+            regions.sort()
+            kernels.sort()
+            mine = torch.tensor([regions[len(regions) // 2], kernels[len(kernels) // 2]], dtype=torch.float64, device=dev)
+            slowest = mine.clone()
+            if dist.is_initialized():
+                dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+            solo = {"region_s_rank0": float(mine[0]), "kernel_ms_rank0": float(mine[1]),
+                    "region_s_slowest_rank": float(slowest[0]), "kernel_ms_slowest_rank": float(slowest[1])}
     collective = "none"
     native = False
     roots = None
@@ -554,19 +592,34 @@ def run_rank(args):
     # Timed region: exactly K steps, no per-step host work.  Without a collective the K tick launches are
     # bracketed by ONE HIP event pair recorded by the library on the launch stream (bge_world_profile_enable(1)),
     # so the roofline figure is the average launch duration inside the timed region, gaps included.
-    world.profile_enable(0 if gather else 1)
-    with deadlines.phase(f"timed region ({args.steps} steps" + (", one root gather per step)" if gather else ")")):
-        t0 = time.perf_counter()
+    # Run R times back to back; every region is exactly K steps between barrier + synchronize on both sides, its time the MAX over
+    # ranks; the median region is the line's ms_per_step / value (R and every region's time are in the line).
+    repeats = max(1, args.repeats)
+    region_s, region_kernel_ms = [], []
+    for rep in range(repeats):
+        world.profile_enable(0 if gather else 1)
+        with deadlines.phase(f"timed region {rep + 1} of {repeats} ({args.steps} steps" + (", one root gather per step)" if gather else ")")):
+            barrier()
+            t0 = time.perf_counter()
+            if not gather:
+                tick(flags, args.steps)
+            elif native:
+                # one native call enqueues K frames: tick kernels, root packing, ncclAllGather on the side stream
+                tick(flags | B.TICK_GATHER_ROOTS, args.steps)
+            else:
+                for _ in range(args.steps):
+                    step()
+            barrier()
+            t1 = time.perf_counter()
+        el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+        if dist.is_initialized():
+            with deadlines.phase("all_reduce(MAX) of the elapsed time"):
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        region_s.append(float(el.item()))
         if not gather:
-            tick(flags, args.steps)
-        elif native:
-            # one native call enqueues K frames: tick kernels, root packing, ncclAllGather on the side stream
-            tick(flags | B.TICK_GATHER_ROOTS, args.steps)
-        else:
-            for _ in range(args.steps):
-                step()
-        barrier()
-        t1 = time.perf_counter()
+            k_ms, k_ticks = world.profile_read()
+            assert k_ticks == args.steps, (k_ticks, args.steps)
+            region_kernel_ms.append(k_ms / k_ticks)
     kernel_note = "one HIP event pair around the K launches of the timed region"
     if gather:
         # the collective and the packing kernel share the stream with the tick kernels: time the tick kernels in a
@@ -580,10 +633,13 @@ def run_rank(args):
                     step()
             barrier()
         kernel_note = "event pair per tick in a second, instrumented pass of the same K steps (collective interleaved)"
-    kernel_total_ms, kernel_ticks = world.profile_read()
+    if gather:
+        kernel_total_ms, kernel_ticks = world.profile_read()
+        assert kernel_ticks == args.steps, (kernel_ticks, args.steps)
+        kernel_ms = kernel_total_ms / kernel_ticks
+    else:
+        kernel_ms = sorted(region_kernel_ms)[len(region_kernel_ms) // 2]
     world.profile_enable(0)
-    assert kernel_ticks == args.steps, (kernel_ticks, args.steps)
-    kernel_ms = kernel_total_ms / kernel_ticks
 
     gather_check = None
     if gather and native:
@@ -608,11 +664,7 @@ def run_rank(args):
         if gather_check == "MISMATCH":
             print(f"[bench] rank {rank}: gathered root table does not match (own segment ok: {own_ok})", file=sys.stderr)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if dist.is_initialized():
-        with deadlines.phase("all_reduce(MAX) of the elapsed time"):
-            dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed_s = float(elapsed.item())
+    elapsed_s = sorted(region_s)[len(region_s) // 2]   # the median region (max over ranks each)
     total_entities = per_gpu * n_gpus
     value = total_entities * args.steps / elapsed_s
 
@@ -639,6 +691,9 @@ def run_rank(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_s / args.steps * 1e3,
+            "repeats": repeats,
+            "region_ms": [r * 1e3 for r in region_s],
+            "timing": f"median of {repeats} back-to-back regions of exactly {args.steps} steps, each between barrier + synchronize, max over ranks",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -670,6 +725,19 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
+        if solo is not None:
+            solo_value = per_gpu * args.steps / solo["region_s_rank0"]
+            out["single_gpu_same_workload"] = {
+                "value": 0.0 if STUB else solo_value, "unit": "entity-updates/s",
+                "what": f"rank 0's own shard ({per_gpu} entities, {name}) ticked alone for {args.steps} steps before the communicator existed: "
+                        f"median of {repeats} regions, same event-pair / wall-clock timing as the line's",
+                "ms_per_step": solo["region_s_rank0"] / args.steps * 1e3, "kernel_ms_per_launch": solo["kernel_ms_rank0"],
+                "ms_per_step_slowest_rank": solo["region_s_slowest_rank"] / args.steps * 1e3,
+                "kernel_ms_per_launch_slowest_rank": solo["kernel_ms_slowest_rank"],
+            }
+            out["scaling_efficiency"] = None if STUB else value / (n_gpus * solo_value)
+            out["compute_only_ms_per_step"] = solo["region_s_slowest_rank"] / args.steps * 1e3
+            out["compute_plus_collective_ms_per_step"] = elapsed_s / args.steps * 1e3
         if n_gpus == 1 and not args.no_cpu and not STUB:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
             out["cpu_allcore"] = cpu_allcore(wl, args.cpu_seconds / 2, args.cpu_threads)
@@ -681,13 +749,20 @@ def run_rank(args):
             except Exception as e:  # the checker could not run (not: it ran and disagreed)
                 par = {"error": repr(e), "max_rel_err_world": float("nan"), "max_rel_err_position": float("nan"),
                        "bit_identical": False, "ok": None}
-            if dist.is_initialized() and par["ok"] is not None:
-                worst = torch.tensor([par["max_rel_err_world"], par["max_rel_err_position"], 0.0 if par["bit_identical"] else 1.0],
-                                     dtype=torch.float64, device=dev)
+            if dist.is_initialized():
+                # EVERY rank takes part: a rank whose checker could not run contributes inf and a flag — skipping the
+                # collective on that rank alone would leave the others waiting for it until the deadline
+                failed = par["ok"] is None
+                worst = torch.tensor([float("inf") if failed else par["max_rel_err_world"], float("inf") if failed else par["max_rel_err_position"],
+                                      0.0 if par["bit_identical"] else 1.0, 1.0 if failed else 0.0], dtype=torch.float64, device=dev)
                 dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-                par.update(max_rel_err_world=float(worst[0]), max_rel_err_position=float(worst[1]),
-                           bit_identical=bool(worst[2].item() == 0.0), ranks_checked=n_gpus)
-                par["ok"] = par["max_rel_err_world"] <= 1e-5 and par["max_rel_err_position"] <= 1e-5
+                if worst[3].item() != 0.0:
+                    par.update(ok=None, ranks_checked=n_gpus)
+                    par.setdefault("error", "the checker could not run on another rank")
+                else:
+                    par.update(max_rel_err_world=float(worst[0]), max_rel_err_position=float(worst[1]),
+                               bit_identical=bool(worst[2].item() == 0.0), ranks_checked=n_gpus)
+                    par["ok"] = par["max_rel_err_world"] <= 1e-5 and par["max_rel_err_position"] <= 1e-5
         if rank == 0:
             out["parity"] = par
             if par["ok"] is False:
@@ -705,6 +780,8 @@ def run_rank(args):
         check = not args.no_cpu
         for label, cname, ents, steps, warm, basis in (
                 ("configs[2] 1M entities, depth-4 chains (LDS-staged hierarchy)", "chains4", None, 400, 20, False),
+                ("configs[4] ONE GPU's shard: 2M entities in 64-node subtrees (variant 5b), no gather — the N = 1 anchor of the "
+                 "scaling curve that `--gpus N` measures on this workload", "subtree64", None, 400, 20, False),
                 ("configs[3] 4M entities + AABB broadphase", "cube4m", None, 20, 3, False),
                 ("flat 16M (2.2 GB working set: beyond the 256 MiB Infinity Cache)", "flat1m", 16_000_000, 40, 5, False),
                 ("configs[1] in Bullet's own orientation scheme (BGE_TICK_BULLET_BASIS)", "flat1m", None, 400, 20, True)):
@@ -713,10 +790,14 @@ def run_rank(args):
             except Exception as e:  # the headline stands on its own
                 extras.append({"label": label, "workload": cname, "error": repr(e)})
                 rc = rc or 5
-        try:   # (one more row of SURVEY 8(f); whatever happens here leaves the exit code alone)
+        try:   # (one more row of SURVEY 8(f))
             extras.append(measure_ground_config(B, synth, torch, None, check))
+            if extras[-1].get("parity", {}).get("ok") is False:
+                print("[bench] PARITY FAILURE on the ground plane: the device state is outside 1e-5 of the CPU port", file=sys.stderr)
+                rc = rc or 4
         except Exception as e:
             extras.append({"label": "configs[1] on the reference's ground plane", "workload": "flat1m + ground plane", "error": repr(e)})
+            rc = rc or 5
         out["configs"] = extras
 
     if rank == 0:

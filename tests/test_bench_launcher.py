@@ -34,6 +34,20 @@ def test_gpus_2_starts_two_ranks_and_reports_them():
     assert "native RCCL gather" in line["config"]["collective"]  # both ranks brought the (stub) native collective up
     assert set(line["config"]["gather_schedule_trials_ms"]) == {"0", "1"}  # both schedules were tried on every rank
     assert "STUB" in line["data"] and line["value"] == 0.0  # a stub run can never pass for a measurement
+    # every N > 1 line carries its own single-GPU anchor on the SAME workload and the median-of-R timing
+    solo = line["single_gpu_same_workload"]
+    assert solo["unit"] == "entity-updates/s" and "6400 entities, subtree64" in solo["what"] and "before the communicator" in solo["what"]
+    assert solo["ms_per_step"] > 0 and solo["kernel_ms_per_launch"] > 0 and solo["ms_per_step_slowest_rank"] >= solo["ms_per_step"] * 0.0
+    assert "scaling_efficiency" in line                                  # (None in a stub run: nothing was measured)
+    assert line["compute_only_ms_per_step"] > 0 and line["compute_plus_collective_ms_per_step"] > 0
+    assert line["repeats"] == 5 and len(line["region_ms"]) == 5 and "median of 5" in line["timing"]
+    assert abs(line["ms_per_step"] - sorted(line["region_ms"])[2] / 5) < 1e-9    # the median region / K
+
+
+def test_default_deadline_keeps_the_launcher_inside_the_drivers_limit():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert 3 * bench.parse_args([]).deadline < 600
 
 
 def test_one_rank_without_the_native_collective_makes_every_rank_fall_back():
