@@ -212,6 +212,38 @@ int orc_get_ground_contacts(void* h, uint32_t id, float* out32)
     }
     return m.n;
 }
+// Dynamic boxes against the scene's Static / Kinematic box colliders (boxbox_ref.h)
+void orc_set_static_contacts(void* h, int enabled) { S(h)->physics.staticContacts = enabled != 0; }
+void orc_set_legacy_ground_solver(void* h, int enabled) { S(h)->physics.legacyGroundSolver = enabled != 0; }
+void orc_set_restitution(void* h, uint32_t id, float restitution)
+{
+    if (RefRigidBody* b = S(h)->scene.GetRigidBody(id)) b->restitution = restitution;
+}
+// a body's manifolds with boxes: returns how many; hdr[2 k] = the other entity, hdr[2 k + 1] = points; per point 12 floats:
+// localA.xyz, localB.xyz, normalWorldOnB.xyz, distance, appliedImpulse, appliedImpulseLateral1
+int orc_get_box_contacts(void* h, uint32_t id, uint32_t* hdr8, float* out192)
+{
+    auto& rts = S(h)->physics.Runtimes();
+    auto it = rts.find(id);
+    if (it == rts.end()) return 0;
+    const auto& boxes = it->second.boxes;
+    for (size_t k = 0; k < boxes.size() && k < 4; ++k) {
+        const auto& m = boxes[k];
+        if (hdr8) {
+            hdr8[2 * k] = m.other;
+            hdr8[2 * k + 1] = static_cast<uint32_t>(m.n);
+        }
+        for (int j = 0; j < m.n && out192; ++j) {
+            float* o = out192 + 48 * k + 12 * j;
+            const auto& c = m.p[j];
+            o[0] = c.localA.x; o[1] = c.localA.y; o[2] = c.localA.z;
+            o[3] = c.localB.x; o[4] = c.localB.y; o[5] = c.localB.z;
+            o[6] = c.normalB.x; o[7] = c.normalB.y; o[8] = c.normalB.z;
+            o[9] = c.distance; o[10] = c.appliedImpulse; o[11] = c.appliedImpulseLateral1;
+        }
+    }
+    return static_cast<int>(boxes.size());
+}
 uint64_t orc_count_dirty(void* h) { return S(h)->scene.CountDirtyTransforms(); }
 uint64_t orc_transform_count(void* h) { return S(h)->scene.GetTransformCount(); }
 

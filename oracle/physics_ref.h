@@ -78,6 +78,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "boxbox_ref.h"
 #include "bullet_math.h"
 #include "contact_ref.h"
 #include "ecs_ref.h"
@@ -108,10 +109,14 @@ struct RefBodyRuntime {
     float aabbMax[3] = {0, 0, 0};
     // ground contact (contact_ref.h): the collider as Bullet holds it, mass properties, the manifold with the plane
     ct::Shape shape;
-    float mass = 0.0f, friction = 0.5f;
+    float mass = 0.0f, friction = 0.5f, restitution = 0.0f;
     bt::Vec3 localInertia{0, 0, 0}, invInertiaLocal{0, 0, 0};
     float contactBreakingThreshold = 0.02f;
     ct::Manifold ground;
+    // contacts with Static / Kinematic boxes (boxbox_ref.h): this Dynamic body's manifolds, ascending entity id of the other box
+    std::vector<ct::BoxManifold> boxes;
+    std::vector<uint32_t> boxGeneration; // generation of the other body when the manifold was made (a re-created body is a new pair)
+    uint32_t generation = 0;             // bumped whenever the btRigidBody is (re)created
 };
 
 // Trigger volumes.  Follows:
@@ -187,6 +192,11 @@ public:
     // solver for it (contact_ref.h).  Off by default: BASELINE's workloads are free bodies.  A body whose
     // mask lacks btBroadphaseProxy::StaticFilter (2) does not collide with it.
     bool groundPlane = false;
+    // Dynamic boxes collide with the Static / Kinematic BOX colliders of the scene (btBoxBoxCollisionAlgorithm, boxbox_ref.h) —
+    // what the reference's world does for every pair the dispatcher accepts (PhysicsSystem.cpp:122-128); capsules against boxes
+    // (GJK / EPA) are not restated.  Off by default, like the plane: BASELINE's workloads are free bodies.
+    bool staticContacts = false;
+    bool legacyGroundSolver = false; // tests only: plane-only bodies through round 2's SolveBodyAgainstGround (must give the same bits as SolveBody)
 
     std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
     std::unordered_map<EntityId, RefTriggerRuntime>& TriggerRuntimes() { return triggerRuntime_; }
@@ -300,7 +310,11 @@ private:
             rt.localInertia = mass > 0.0f ? ct::LocalInertia(rt.shape, mass) : bt::Vec3{0, 0, 0};
             rt.invInertiaLocal = ct::InvInertiaLocal(rt.localInertia);
             rt.friction = body.friction;
+            rt.restitution = body.restitution; // info.m_restitution (:438)
             rt.ground.Clear(); // removeRigidBody drops the broadphase pair and with it the manifold
+            rt.boxes.clear();
+            rt.boxGeneration.clear();
+            rt.generation += 1;
             PoseFromTransform(rt, *transform);
             rt.linvel = bt::Vec3{0, 0, 0};
             rt.angvel = bt::Vec3{0, 0, 0};
@@ -338,15 +352,15 @@ private:
     void StepSimulation(float dt)
     {
         const bt::Vec3 g{0.0f, gravityY, 0.0f};
-        for (auto& kv : runtime_) {
-            RefBodyRuntime& rt = kv.second;
-            if (!rt.hasBody) continue;
-            const bool dynamic = rt.type == RefBodyType::Dynamic && rt.invMass != 0.0f;
-
-            const bool spinning = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
-            const bool rotate = orientMode != kOrientIdeal || spinning;
-
-            if (computeAabbs) {
+        // predictUnconstraintMotion + updateAabbs for every body, from the state the sub-step starts with (a body's fed box
+        // depends on nothing but its own state, so this pass is what the per-body loop below used to do in place)
+        if (computeAabbs || staticContacts) {
+            for (auto& kv : runtime_) {
+                RefBodyRuntime& rt = kv.second;
+                if (!rt.hasBody) continue;
+                const bool dynamic = rt.type == RefBodyType::Dynamic && rt.invMass != 0.0f;
+                const bool spinning = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
+                const bool rotate = orientMode != kOrientIdeal || spinning;
                 bt::AabbOfPose(rt.origin, rt.basis, rt.aabbHalfExtents, rt.aabbMin, rt.aabbMax);
                 if (dynamic) {
                     // predicted (interpolation) transform uses the velocity BEFORE the gravity impulse
@@ -362,7 +376,33 @@ private:
                     }
                 }
             }
+        }
+        // the boxes a Dynamic box can rest on: every Static / Kinematic body with a box collider, ascending entity id
+        std::vector<std::pair<EntityId, const RefBodyRuntime*>> obstacles;
+        if (staticContacts) {
+            for (const auto& kv : runtime_) {
+                const RefBodyRuntime& o = kv.second;
+                if (o.hasBody && !o.shape.capsule && !(o.type == RefBodyType::Dynamic && o.invMass != 0.0f)) obstacles.emplace_back(kv.first, &o);
+            }
+            std::sort(obstacles.begin(), obstacles.end());
+        }
+        for (auto& kv : runtime_) {
+            RefBodyRuntime& rt = kv.second;
+            if (!rt.hasBody) continue;
+            const bool dynamic = rt.type == RefBodyType::Dynamic && rt.invMass != 0.0f;
             if (!dynamic) continue;
+            const bool spinning = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
+
+            // performDiscreteCollisionDetection comes BEFORE the island build: a body that wants to sleep (isActive() is still true
+            // for WANTS_DEACTIVATION) is collided once more — its manifolds are refreshed — and only then falls asleep; a sleeping
+            // body's pairs with static objects are skipped (btCollisionDispatcher::needsCollision: neither object is active)
+            const bool collides = rt.activation != kIslandSleeping;
+            const bool withGround = collides && groundPlane && (rt.mask & 2u) != 0u;
+            if (withGround) {
+                // the pair (ground, body): group StaticFilter = 2 against the body's mask, the body's group against AllFilter
+                ct::CollideWithGround(rt.ground, rt.shape, rt.contactBreakingThreshold, rt.origin, rt.basis);
+            }
+            if (collides && staticContacts && !rt.shape.capsule) CollideWithBoxes(kv.first, rt, obstacles);
 
             // buildIslands: a free body is a one-body island; "all sleeping" unless ACTIVE_TAG / DISABLE_DEACTIVATION
             if (rt.activation == kWantsDeactivation) rt.activation = kIslandSleeping;
@@ -378,25 +418,25 @@ private:
             // a division per component in the reference's build (btRigidBody::setGravity, check_bullet_order.py)
             const bt::Vec3 force{g.x / rt.invMass, g.y / rt.invMass, g.z / rt.invMass};
             bool solved = false;
-            if (groundPlane && (rt.mask & 2u) != 0u) {
-                // performDiscreteCollisionDetection for the pair (ground, body): group StaticFilter = 2 against the body's
-                // mask, the body's group against AllFilter; then the island {body} through the solver.  A body without a
-                // contact and without angular velocity takes the plain update below — the same arithmetic, (v + 0) + impulse.
-                ct::CollideWithGround(rt.ground, rt.shape, rt.contactBreakingThreshold, rt.origin, rt.basis);
-                if (rt.ground.n > 0 || spinning) {
-                    ct::BodyState b{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
-                    const bool moved = ct::SolveBodyAgainstGround(b, rt.ground, rt.shape, rt.invMass, rt.invInertiaLocal, rt.localInertia,
-                                                                  rt.friction, force, dt);
-                    rt.linvel = b.linVel;
-                    rt.angvel = b.angVel;
-                    if (moved) { // the split impulse corrected the pose
-                        rt.origin = b.origin;
-                        rt.orn = b.orn;
-                        rt.basis = b.basis;
-                        rt.freshPose = true;
-                    }
-                    solved = true;
+            bool touching = withGround && rt.ground.n > 0;
+            for (const ct::BoxManifold& bm : rt.boxes) touching = touching || bm.n > 0;
+            if ((withGround || !rt.boxes.empty()) && (touching || spinning)) {
+                // the island {body} through the solver.  A body without a contact and without angular velocity takes the plain
+                // update below — the same arithmetic, (v + 0) + impulse.
+                ct::BodyState b{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
+                const bool moved = (legacyGroundSolver && withGround && rt.boxes.empty())
+                                       ? ct::SolveBodyAgainstGround(b, rt.ground, rt.shape, rt.invMass, rt.invInertiaLocal, rt.localInertia, rt.friction, force, dt)
+                                       : ct::SolveBody(b, withGround ? &rt.ground : nullptr, rt.boxes.data(), static_cast<int>(rt.boxes.size()), rt.invMass,
+                                                       rt.invInertiaLocal, rt.localInertia, rt.friction, force, dt);
+                rt.linvel = b.linVel;
+                rt.angvel = b.angVel;
+                if (moved) { // the split impulse corrected the pose
+                    rt.origin = b.origin;
+                    rt.orn = b.orn;
+                    rt.basis = b.basis;
+                    rt.freshPose = true;
                 }
+                solved = true;
             }
             if (!solved) {
                 rt.linvel.x = rt.linvel.x + (force.x * rt.invMass) * dt;
@@ -430,6 +470,44 @@ private:
                     rt.activation = kWantsDeactivation;
             }
         }
+    }
+
+    // The Dynamic box `rt` against the boxes it can touch this step: pairs = fed AABBs overlap and the filter passes both ways
+    // (the history-free core of the pair cache), at most ct::kMaxBoxManifolds of them, lowest entity ids first.  A manifold
+    // lives as long as its pair; a re-created other body is a new pair.
+    void CollideWithBoxes(EntityId self, RefBodyRuntime& rt, const std::vector<std::pair<EntityId, const RefBodyRuntime*>>& obstacles)
+    {
+        std::vector<ct::BoxManifold> next;
+        std::vector<uint32_t> nextGen;
+        for (const auto& ob : obstacles) {
+            if (static_cast<int>(next.size()) == ct::kMaxBoxManifolds) break;
+            const RefBodyRuntime& o = *ob.second;
+            if (ob.first == self) continue;
+            if ((rt.layer & o.mask) == 0 || (o.layer & rt.mask) == 0) continue;
+            bool overlap = true;
+            for (int a = 0; a < 3; ++a) overlap = overlap && rt.aabbMin[a] <= o.aabbMax[a] && rt.aabbMax[a] >= o.aabbMin[a];
+            if (!overlap) continue;
+            ct::BoxManifold m;
+            bool found = false;
+            for (size_t k = 0; k < rt.boxes.size(); ++k) {
+                if (rt.boxes[k].other == ob.first && rt.boxGeneration[k] == o.generation) {
+                    m = rt.boxes[k];
+                    found = true;
+                }
+            }
+            if (!found) {
+                m.other = ob.first;
+                m.breaking = std::min(rt.contactBreakingThreshold, o.contactBreakingThreshold);
+                m.friction = std::max(-10.0f, std::min(10.0f, rt.friction * o.friction)); // btManifoldResult::calculateCombinedFriction
+                m.restitution = rt.restitution * o.restitution;                             // ... calculateCombinedRestitution
+            }
+            const ct::BoxPose a{rt.origin, rt.basis, rt.shape.dims}, b{o.origin, o.basis, o.shape.dims};
+            ct::CollideBoxBox(m, a, b);
+            next.push_back(m);
+            nextGen.push_back(o.generation);
+        }
+        rt.boxes.swap(next);
+        rt.boxGeneration.swap(nextGen);
     }
 
     bt::Quat CurrentOrn(const RefBodyRuntime& rt) const

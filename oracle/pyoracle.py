@@ -64,6 +64,11 @@ class _Lib:
         l.orc_last_substeps.restype = C.c_int
         l.orc_set_ground_plane.argtypes = [C.c_void_p, C.c_int]
         l.orc_set_friction.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+        l.orc_set_restitution.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+        l.orc_set_static_contacts.argtypes = [C.c_void_p, C.c_int]
+        l.orc_set_legacy_ground_solver.argtypes = [C.c_void_p, C.c_int]
+        l.orc_get_box_contacts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        l.orc_get_box_contacts.restype = C.c_int
         l.orc_get_ground_contacts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.orc_get_ground_contacts.restype = C.c_int
         l.orc_set_physics_options.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
@@ -309,6 +314,24 @@ class RefScene:
 
     def SetFriction(self, eid, friction):
         lib().orc_set_friction(self.h, eid, float(friction))
+
+    def SetRestitution(self, eid, restitution):
+        lib().orc_set_restitution(self.h, eid, float(restitution))
+
+    def SetStaticContacts(self, enabled=True):
+        """Dynamic boxes collide with the Static / Kinematic box colliders of the scene (Bullet's btBoxBoxCollisionAlgorithm)."""
+        lib().orc_set_static_contacts(self.h, int(enabled))
+
+    def SetLegacyGroundSolver(self, enabled=True):
+        lib().orc_set_legacy_ground_solver(self.h, int(enabled))
+
+    def BoxContacts(self, eid):
+        """[(other entity id, rows)]: rows[j] = localA.xyz, localB.xyz, normalWorldOnB.xyz, distance, appliedImpulse,
+        appliedImpulseLateral1 of the j-th point of the body's manifold with that box; ascending entity id."""
+        hdr = np.zeros((4, 2), np.uint32)
+        out = np.zeros((4, 4, 12), np.float32)
+        n = lib().orc_get_box_contacts(self.h, eid, _vp(hdr), _vp(out))
+        return [(int(hdr[k, 0]), out[k, :hdr[k, 1]].copy()) for k in range(min(n, 4))]
 
     def GroundContacts(self, eid):
         """(n, rows): rows[k] = localA.xyz, appliedImpulse, localB.x, distance, localB.z, appliedImpulseLateral1 of the body's k-th contact."""

@@ -370,3 +370,175 @@ def test_a_one_shot_trigger_leaves_the_world_inside_the_loop(one_shot_first):
         ref.PhysicsSystemUpdate(1 / 120)
         assert _events(ref) == [(2, lo, hi)]          # hi fired after lo had listed it: lo sees it gone one tick later
     assert ref.TriggerIsActive(lo) != one_shot_first and ref.TriggerIsActive(hi) == one_shot_first
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Dynamic boxes on Static / Kinematic box colliders (oracle/boxbox_ref.h)
+def _box_scene(drop_pos=(2.0, 2.0, 1.0), drop_euler=(0.0, 0.0, 0.0), drop_size=(0.5, 0.5, 0.5), mass=1.0, friction=0.5, restitution=0.0,
+               ground_restitution=0.0, plane=True, mode=po.ORIENT_IDEAL):
+    """demo.json's Ground (assets/scenes/demo.json:67-91: a Static 50 x 1 x 50 box centred at y = -0.01, friction 1: its top is at
+    y = 0.99) with a Dynamic box above it — what the reference's world collides through btBoxBoxCollisionAlgorithm."""
+    ref = po.RefScene()
+    ref.SetPhysicsOptions(-9.81, mode, False)
+    ground = ref.CreateEntity()
+    ref.AddTransform(ground, (0.0, -0.01, 0.0), (0, 0, 0), (0.05, 1.0, 0.05))
+    ref.AddCollider(ground, 0, (50.0, 1.0, 50.0))
+    ref.AddRigidBody(ground, po.BODY_STATIC, 0.0, 1, 0xFFFFFFFF)
+    ref.SetFriction(ground, 1.0)
+    ref.SetRestitution(ground, ground_restitution)
+    box = ref.CreateEntity()
+    ref.AddTransform(box, drop_pos, drop_euler, (1, 1, 1))
+    ref.AddCollider(box, 0, drop_size)
+    ref.AddRigidBody(box, po.BODY_DYNAMIC, mass, 1, 0xFFFFFFFF)
+    ref.SetFriction(box, friction)
+    ref.SetRestitution(box, restitution)
+    ref.SetGroundPlane(plane)
+    ref.SetStaticContacts(True)
+    ref.n = 2
+    return ref, ground, box
+
+
+@pytest.mark.parametrize("mode", [po.ORIENT_IDEAL, po.ORIENT_BASIS])
+def test_box_dropped_into_the_demo_scene_rests_on_the_ground_box_and_sleeps(mode):
+    """VERDICT r02 missing #1: in the reference a body dropped over demo.json's Ground lands on the BOX (top y = 0.99), not on
+    the plane y = 0 inside it.  A unit box comes to rest at y = 0.99 + 0.5 on four contact points and falls asleep."""
+    ref, ground, box = _box_scene(drop_euler=(0.2, 0.4, -0.1), mode=mode)
+    for _ in range(700):
+        ref.PhysicsSystemUpdate(1 / 120)
+        ref.TransformSystemUpdate()
+    t = ref.GetTransform(box)
+    assert abs(t["position"][1] - 1.49) < 0.01, t["position"]
+    contacts = ref.BoxContacts(box)
+    assert len(contacts) == 1 and contacts[0][0] == ground and len(contacts[0][1]) == 4
+    n_ground, _ = ref.GroundContacts(box)
+    assert n_ground == 0                                                    # it never reached the plane
+    rows = contacts[0][1]
+    assert np.allclose(rows[:, 6:9], [0, 1, 0], atol=1e-3)                  # normals on the ground box point up
+    assert (rows[:, 10] > 0).all()                                          # every point carries load
+    assert abs(rows[:, 10].sum() * 120 - 9.81) < 0.05                       # ... the body's weight, per 1/120 s step
+    st, _ = ref.bulk_activation()
+    assert st[box - 1] == 2                                                 # ISLAND_SLEEPING
+
+
+def test_without_static_contacts_the_box_falls_through_to_the_plane():
+    ref, ground, box = _box_scene()
+    ref.SetStaticContacts(False)
+    for _ in range(400):
+        ref.PhysicsSystemUpdate(1 / 120)
+        ref.TransformSystemUpdate()
+    assert abs(ref.GetTransform(box)["position"][1] - 0.5) < 0.01
+    assert ref.BoxContacts(box) == []
+
+
+def test_restitution_is_live_on_box_contacts_and_needs_both_bodies():
+    """btManifoldResult::calculateCombinedRestitution is the PRODUCT of the two bodies' values (RigidBody::restitution,
+    PhysicsSystem.cpp:438): a bouncy box on a ground of restitution 0 does not bounce, on a ground of restitution 0.8 it does."""
+    def apex_after_first_impact(ground_rest):
+        ref, ground, box = _box_scene(drop_pos=(0, 3.0, 0), restitution=0.9, ground_restitution=ground_rest, plane=False)
+        ys = []
+        for _ in range(240):
+            ref.PhysicsSystemUpdate(1 / 120)
+            ref.TransformSystemUpdate()
+            ys.append(ref.GetTransform(box)["position"][1])
+        ys = np.array(ys)
+        k = int(np.argmin(ys[:120]))
+        return float(ys[k:].max())
+    assert apex_after_first_impact(0.0) < 1.55
+    assert apex_after_first_impact(0.8) > 2.0
+
+
+def test_friction_with_a_box_is_the_product_of_both_frictions():
+    """Sliding along demo.json's Ground (friction 1): combined friction = body friction x 1; a slippery body slides further."""
+    def slide(f):
+        ref, ground, box = _box_scene(drop_pos=(0, 1.5, 0), friction=f, plane=False)
+        ref.PhysicsSystemUpdate(1 / 120)
+        ref.TransformSystemUpdate()
+        ref.SetVelocity(box, (3.0, 0.0, 0.0))
+        for _ in range(300):
+            ref.PhysicsSystemUpdate(1 / 120)
+            ref.TransformSystemUpdate()
+        return ref.GetTransform(box)["position"][0]
+    assert slide(0.05) > slide(0.5) + 1.0 > 1.0
+
+
+def test_a_box_leans_on_a_wall_and_the_floor_at_once_and_a_moved_wall_lets_go():
+    """Two manifolds for one body (floor + wall, ascending entity id), both in one island's rows; the wall is Kinematic: moved away
+    (a teleport, the only way the reference moves one) the pair ends and its manifold with it."""
+    ref, ground, box = _box_scene(drop_pos=(0.0, 1.6, 0.0), plane=False)
+    wall = ref.CreateEntity()
+    ref.AddTransform(wall, (0.9, 2.0, 0.0), (0, 0, 0), (1, 1, 1))
+    ref.AddCollider(wall, 0, (0.4, 2.0, 2.0))
+    ref.AddRigidBody(wall, po.BODY_KINEMATIC, 0.0, 1, 0xFFFFFFFF)
+    ref.n = 3
+    ref.PhysicsSystemUpdate(1 / 120)
+    ref.TransformSystemUpdate()
+    ref.SetVelocity(box, (1.5, 0.0, 0.0))                     # pushed against the wall (its face is at x = 0.5: already touching)
+    seen_two = False
+    for _ in range(200):
+        ref.PhysicsSystemUpdate(1 / 120)
+        ref.TransformSystemUpdate()
+        c = ref.BoxContacts(box)
+        seen_two = seen_two or (len(c) == 2 and all(len(r) > 0 for _, r in c))
+    assert seen_two
+    x = float(ref.GetTransform(box)["position"][0])
+    assert x < 0.05                                           # the wall stopped it
+    ref.SetTRS(wall, pos=(x + 0.9 - 0.01, 2.0, 0.0))          # the wall comes to the box: a pair again, a fresh manifold
+    ref.PhysicsSystemUpdate(1 / 120)
+    ref.TransformSystemUpdate()
+    c = ref.BoxContacts(box)
+    assert [o for o, _ in c] == [ground, wall] and len(c[1][1]) > 0
+    ref.SetTRS(wall, pos=(30.0, 2.0, 0.0))
+    ref.PhysicsSystemUpdate(1 / 120)
+    ref.TransformSystemUpdate()
+    assert [o for o, _ in ref.BoxContacts(box)] == [ground]
+
+
+def test_general_solver_without_boxes_is_the_ground_solver_bit_for_bit():
+    """ct::SolveBody with no box manifold must be ct::SolveBodyAgainstGround operation for operation: the plane scenes of round 2
+    (and the GPU's plane kernel, which is checked against them) went through the old function.  1,000 boxes and capsules of mixed
+    size, mass, friction and orientation dropped on the plane, two oracles in lockstep — one through each function — every pose,
+    velocity and contact point compared bit for bit every tenth tick while they land, tumble, rest and fall asleep."""
+    n = 1000
+    rng = np.random.default_rng(5)
+    wl = synth.Workload("ground", synth.FLAT, n, 77)
+    wl.pos[:, 0] = rng.uniform(-40, 40, n).astype(np.float32)
+    wl.pos[:, 2] = rng.uniform(-40, 40, n).astype(np.float32)
+    wl.pos[:, 1] = rng.uniform(0.2, 2.0, n).astype(np.float32)
+    wl.body_type[:] = 1
+    shape = rng.choice([0, 0, 1], n).astype(np.uint8)
+    size = rng.uniform(0.15, 0.9, (n, 3)).astype(np.float32)
+    mass = rng.choice([0.3, 1.0, 40.0], n).astype(np.float32)
+    refs = []
+    for legacy in (False, True):
+        ref = build_oracle(wl, shape=shape, size=size, mass=mass)
+        for i in range(n):
+            ref.SetFriction(i + 1, float(rng.choice([0.05, 0.5, 3.0])) if not legacy else refs[0]._fr[i])
+        if not legacy:
+            ref._fr = [0.0] * n
+        ref.SetGroundPlane(True)
+        ref.SetLegacyGroundSolver(legacy)
+        refs.append(ref)
+    # (same frictions in both: set them again from one draw)
+    fr = np.random.default_rng(6).choice([0.05, 0.5, 3.0], n)
+    refs = []
+    for legacy in (False, True):
+        ref = build_oracle(wl, shape=shape, size=size, mass=mass)
+        for i in range(n):
+            ref.SetFriction(i + 1, float(fr[i]))
+        ref.SetGroundPlane(True)
+        ref.SetLegacyGroundSolver(legacy)
+        refs.append(ref)
+    for tick in range(420):
+        for ref in refs:
+            ref.PhysicsSystemUpdate(1 / 120)
+            ref.TransformSystemUpdate()
+        if tick % 10:
+            continue
+        a, b = refs[0].bulk_bodies(), refs[1].bulk_bodies()
+        for key in ("origin", "quat", "linvel", "angvel"):
+            assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), (tick, key)
+        for e in range(1, n + 1, 9):
+            (na, pa), (nb, pb) = refs[0].GroundContacts(e), refs[1].GroundContacts(e)
+            assert na == nb and np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), (tick, e)
+    st, _ = refs[0].bulk_activation()
+    assert (st == 2).sum() > 0.5 * n
