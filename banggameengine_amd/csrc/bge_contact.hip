@@ -20,6 +20,7 @@
 
 #include <algorithm>
 
+#include "bge_boxbox_device.hpp"
 #include "bge_device_math.hpp"
 #include "bge_flatten.hpp"
 #include "bge_kernels.hpp"
@@ -598,10 +599,14 @@ __device__ void ground_body(const WorldView& w, const GroundParams& g, uint32_t 
     if ((f0 & kTypeMask) != 2u) return; // Dynamic bodies only (with a Transform, or orphaned): nothing else responds to a contact
     const uint32_t ci0 = w.cinfo[slot];
     if (!(ci0 & kCiGroundMask)) return; // the body's mask excludes the ground's group (StaticFilter)
+    bool collide_only = false;
     if (f0 & kDrowsy) {
-        // asleep, or falling asleep at this step's island build: not collided (both objects inactive), not solved
+        // asleep: not collided (both objects inactive: btCollisionDispatcher::needsCollision), not solved.  Falling asleep at this
+        // step's island build (WANTS_DEACTIVATION): isActive() is still true during performDiscreteCollisionDetection, which comes
+        // first — the pair is collided once more, its manifold refreshed, and nothing is solved
         const uint32_t dz = w.deact[slot];
-        if (dz == kDeactWants || dz == kDeactSleeping) return;
+        if (dz == kDeactSleeping) return;
+        collide_only = dz == kDeactWants;
     }
     const uint32_t cls = f0 >> kMassShift;
     float inv_mass;
@@ -648,6 +653,17 @@ __device__ void ground_body(const WorldView& w, const GroundParams& g, uint32_t 
     }
     ct_collide(p, n, shape, breaking, pos, basis);
     uint32_t ci = (ci0 & ~(7u << kCiCountShift)) | (static_cast<uint32_t>(n) << kCiCountShift);
+    if (collide_only) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < n) {
+                reinterpret_cast<float4*>(w.manifold)[8ull * slot + 2 * i] = make_float4(p[i].localA.x, p[i].localA.y, p[i].localA.z, p[i].appliedImpulse);
+                reinterpret_cast<float4*>(w.manifold)[8ull * slot + 2 * i + 1] = make_float4(p[i].localB.x, p[i].distance, p[i].localB.z, p[i].appliedLateral);
+            }
+        }
+        if (ci != ci0) w.cinfo[slot] = ci;
+        return; // k_tick puts it to sleep
+    }
     if (n == 0 && !spin) {
         if (ci != ci0) w.cinfo[slot] = ci;
         return; // k_tick's plain update
@@ -741,8 +757,31 @@ __global__ void __launch_bounds__(256) k_ground_select(WorldView w, GroundParams
         if (type == 2u) st3(w.euler, slot, bt_transform_euler_from_mat(bt_mat_from_quat(q)));
         if (f != f_in) w.flags[slot] = f;
     }
-    need = need && type == 2u && (ci0 & kCiGroundMask) != 0;
-    need = need && !((f & kDrowsy) && (dz == kDeactWants || dz == kDeactSleeping));
+    // (a body that wants to sleep is still collided this step — only a sleeping one is skipped)
+    const bool awake = in_range && type == 2u && !((f & kDrowsy) && dz == kDeactSleeping);
+    // Static / Kinematic box colliders on: a Dynamic BOX that holds manifolds with boxes, or whose reach (conservative: the L1 norm
+    // of its half extents bounds its AABB at any orientation, plus this step's motion, plus Bullet's 0.02) touches an obstacle's
+    // fed AABB, goes to k_contact_boxes — which decides the pairs exactly and handles the plane for that body too
+    bool boxes = false;
+    if (g.n_obstacles != 0u || (ci0 & kCiBoxes)) {
+        if (awake && !(ci0 & kCiCapsule)) {
+            boxes = (ci0 & kCiBoxes) != 0;
+            if (!boxes) {
+                const float4 cs = w.cshape[slot];
+                const F3 pos = ld3(w.pos, slot);
+                const F3 v = ld3(w.vel, slot);
+                const float reach = (__builtin_fabsf(cs.x) + __builtin_fabsf(cs.y) + __builtin_fabsf(cs.z)) * 1.01f + 0.05f;
+                const float rx = reach + __builtin_fabsf(v.x) * g.dt * 1.01f, ry = reach + __builtin_fabsf(v.y) * g.dt * 1.01f,
+                            rz = reach + __builtin_fabsf(v.z) * g.dt * 1.01f;
+                for (uint32_t k = 0; k < g.n_obstacles && !boxes; ++k) {
+                    const float* bb = g.obstacles[k].aabb;
+                    boxes = pos.x - rx <= bb[3] && pos.x + rx >= bb[0] && pos.y - ry <= bb[4] && pos.y + ry >= bb[1] && pos.z - rz <= bb[5] &&
+                            pos.z + rz >= bb[2];
+                }
+            }
+        }
+    }
+    need = awake && !boxes && g.plane != 0u && (ci0 & kCiGroundMask) != 0;
     if (__any(need)) {
         const uint32_t n = (ci0 >> kCiCountShift) & 7u;
         if (need && n == 0u && !(f & kSpin)) {
@@ -754,6 +793,16 @@ __global__ void __launch_bounds__(256) k_ground_select(WorldView w, GroundParams
             shape.dims = F3{cs.x, cs.y, cs.z};
             const float reach = (__builtin_fabsf(cs.x) + __builtin_fabsf(cs.y) + __builtin_fabsf(cs.z)) * 1.01f + 0.01f;
             if (pos.y - reach > ct_breaking_threshold(shape)) need = false;
+        }
+    }
+    {
+        const unsigned long long mb = __ballot(boxes);
+        if (mb != 0) { // (rare: one list, one atomic per wave)
+            const uint32_t lane = threadIdx.x & 63u;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&g.box_count[0], static_cast<uint32_t>(__popcll(mb)));
+            base = __shfl(base, 0, 64);
+            if (boxes) g.box_list[base + static_cast<uint32_t>(__popcll(mb & ((1ull << lane) - 1ull)))] = slot;
         }
     }
     const unsigned long long m = __ballot(need);
@@ -801,6 +850,601 @@ __global__ void __launch_bounds__(128, BGE_GROUND_MIN_BLOCKS) k_ground(WorldView
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 3: Dynamic boxes on the Static / Kinematic BOX colliders of the scene (Bullet's btBoxBoxCollisionAlgorithm; the reference's
+// demo.json "Ground" is one).  oracle/boxbox_ref.h + physics_ref.h (CollideWithBoxes, ct::SolveBody) are the specification; the
+// choices Bullet's history-dependence forces are stated there (the Dynamic body is body A; pairs = fed AABBs overlap + filter; at
+// most kBoxManifolds manifolds, lowest entity ids).  Capsules against boxes (GJK) are not built.
+//   k_obstacles       one thread per Static / Kinematic box body (a compact list the host keeps, ascending entity): pose as Bullet
+//                     holds it at this sub-step (a dirty body's from its Transform), fed AABB, material -> ObstacleRec
+//   k_ground_select   routes a Dynamic box that holds box manifolds, or whose reach touches an obstacle's AABB, to box_list
+//   k_contact_boxes   one thread per listed body: exact pairs, box-box detector into the body's persistent manifolds (rows of
+//                     bmanifold, kept in global memory), the plane manifold as k_ground has it, then ONE solver for the island
+//                     {body}: plane rows, then every box manifold's rows in ascending entity — with rows in scratch memory and
+//                     loops, not unrolled registers: this kernel serves the handful of bodies that rest on a static box, and is
+//                     sized for correctness (k_ground stays the fast path for everything that touches only the plane).
+__global__ void __launch_bounds__(64) k_obstacles(WorldView w, GroundParams g)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= g.n_obstacles) return;
+    const uint32_t slot = g.obstacle_slots[k];
+    ObstacleRec r;
+    const uint32_t f = w.flags[slot];
+    const uint32_t type = f & kTypeMask;
+    const uint32_t ci = w.cinfo[slot];
+    r.live = (type == 1u || type == 3u) && !(ci & kCiCapsule) ? 1u : 0u;
+    const F3 pos = ld3(w.pos, slot);
+    // SyncKinematicBodiesToPhysics runs before the step: a dirty body is posed from its Transform (k_ground_select / k_tick store that
+    // quaternion; this kernel runs before them)
+    const bool repose = g.repose && (f & kValid) && (f & (kTDirty | kBDirty));
+    const Q4 q = repose ? bt_quat_from_transform_euler(ld3(w.euler, slot)) : ld4(w.quat, slot);
+    const M3 basis = bt_mat_from_quat(q);
+    const float4 cs = w.cshape[slot];
+    CtShape shape;
+    shape.capsule = false;
+    shape.dims = F3{cs.x, cs.y, cs.z};
+    float mn[3], mx[3];
+    bt_aabb_of_pose(pos, basis, ld3(w.half_extent, slot), mn, mx);
+    r.origin[0] = pos.x; r.origin[1] = pos.y; r.origin[2] = pos.z;
+    r.half[0] = cs.x; r.half[1] = cs.y; r.half[2] = cs.z;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.basis[3 * i + j] = basis.m[i][j];
+        r.aabb[i] = mn[i];
+        r.aabb[3 + i] = mx[i];
+    }
+    r.friction = w.cfriction[slot];
+    r.restitution = w.crestitution[slot];
+    r.breaking = ct_breaking_threshold(shape);
+    r.entity = g.entity_of_slot[slot];
+    r.group = w.group[slot];
+    r.mask = w.mask[slot];
+    r.generation = g.obstacle_gen[k];
+    r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    g.obstacles[k] = r;
+}
+
+// a box manifold's points live in global memory: 12 floats each (localA, localB, normalWorldOnB, distance, appliedImpulse, lateral)
+__device__ __forceinline__ F3 bp_get3(const float* p, int at) { return F3{p[at], p[at + 1], p[at + 2]}; }
+__device__ __forceinline__ void bp_put3(float* p, int at, const F3& v)
+{
+    p[at] = v.x;
+    p[at + 1] = v.y;
+    p[at + 2] = v.z;
+}
+
+// btPersistentManifold::sortCachedPoints on a full row (oracle/boxbox_ref.h SortCachedBoxPoints)
+__device__ int bp_sort_cached_points(const float* pts, const F3& newLocalA, float newDistance)
+{
+    int maxPenetrationIndex = -1;
+    float maxPenetration = newDistance;
+    for (int i = 0; i < 4; ++i) {
+        const float d = pts[12 * i + 9];
+        if (d < maxPenetration) {
+            maxPenetrationIndex = i;
+            maxPenetration = d;
+        }
+    }
+    float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const F3 p0 = bp_get3(pts, 0), p1 = bp_get3(pts, 12), p2 = bp_get3(pts, 24), p3 = bp_get3(pts, 36);
+    if (maxPenetrationIndex != 0) {
+        const F3 c = cross3(sub3(newLocalA, p1), sub3(p3, p2));
+        res[0] = dot3(c, c);
+    }
+    if (maxPenetrationIndex != 1) {
+        const F3 c = cross3(sub3(newLocalA, p0), sub3(p3, p2));
+        res[1] = dot3(c, c);
+    }
+    if (maxPenetrationIndex != 2) {
+        const F3 c = cross3(sub3(newLocalA, p0), sub3(p3, p1));
+        res[2] = dot3(c, c);
+    }
+    if (maxPenetrationIndex != 3) {
+        const F3 c = cross3(sub3(newLocalA, p0), sub3(p2, p1));
+        res[3] = dot3(c, c);
+    }
+    int maxIndex = -1;
+    float maxVal = -1.0e18f;
+    for (int i = 0; i < 4; ++i) {
+        const float a = __builtin_fabsf(res[i]);
+        if (a > maxVal) {
+            maxIndex = i;
+            maxVal = a;
+        }
+    }
+    return maxIndex;
+}
+
+// btBoxBoxCollisionAlgorithm::processCollision, body0 = the Dynamic box (oracle/boxbox_ref.h CollideBoxBox); returns the point count
+__device__ int bp_collide(float* pts, int n, float breaking, const F3& originA, const M3& basisA, const F3& halfA, const ObstacleRec& o)
+{
+    const F3 originB = F3{o.origin[0], o.origin[1], o.origin[2]};
+    M3 basisB;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) basisB.m[i][j] = o.basis[3 * i + j];
+    }
+    boxbox::Out out;
+    boxbox::box_box(originA, basisA, halfA, originB, basisB, F3{o.half[0], o.half[1], o.half[2]}, out);
+    for (int k = 0; k < out.n; ++k) {
+        const float depth = out.depth[k];
+        if (depth > breaking) continue;
+        const F3 normalOnB = out.normalOnB;
+        const F3 pointInWorld = out.point[k];
+        const F3 pointA = add3(pointInWorld, scale3(normalOnB, depth));
+        const F3 localA = mat_t_vec(basisA, sub3(pointA, originA));
+        const F3 localB = mat_t_vec(basisB, sub3(pointInWorld, originB));
+        float shortest = breaking * breaking;
+        int nearest = -1;
+        for (int i = 0; i < n; ++i) {
+            const F3 diffA = sub3(bp_get3(pts, 12 * i), localA);
+            const float d2 = dot3(diffA, diffA);
+            if (d2 < shortest) {
+                shortest = d2;
+                nearest = i;
+            }
+        }
+        float applied = 0.0f, lateral = 0.0f;
+        int insert;
+        if (nearest >= 0) {
+            insert = nearest;
+            applied = pts[12 * nearest + 10];
+            lateral = pts[12 * nearest + 11];
+        } else {
+            insert = n;
+            if (insert == 4) {
+                insert = bp_sort_cached_points(pts, localA, depth);
+            } else {
+                n++;
+            }
+            if (insert < 0) insert = 0;
+        }
+        float* d = pts + 12 * insert;
+        bp_put3(d, 0, localA);
+        bp_put3(d, 3, localB);
+        bp_put3(d, 6, normalOnB);
+        d[9] = depth;
+        d[10] = applied;
+        d[11] = lateral;
+    }
+    // refreshContactPoints(body0 transform, body1 transform)
+    for (int i = n - 1; i >= 0; --i) {
+        float* c = pts + 12 * i;
+        const F3 worldA = add3(mat_vec(basisA, bp_get3(c, 0)), originA);
+        const F3 worldB = add3(mat_vec(basisB, bp_get3(c, 3)), originB);
+        c[9] = dot3(sub3(worldA, worldB), bp_get3(c, 6));
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        float* c = pts + 12 * i;
+        const float distance = c[9];
+        bool remove = !(distance <= breaking);
+        if (!remove) {
+            const F3 nB = bp_get3(c, 6);
+            const F3 worldA = add3(mat_vec(basisA, bp_get3(c, 0)), originA);
+            const F3 worldB = add3(mat_vec(basisB, bp_get3(c, 3)), originB);
+            const F3 projectedPoint = sub3(worldA, scale3(nB, distance));
+            const F3 projectedDifference = sub3(worldB, projectedPoint);
+            const float distance2d = dot3(projectedDifference, projectedDifference);
+            remove = distance2d > breaking * breaking;
+        }
+        if (remove) {
+            const int last = n - 1;
+            if (i != last) {
+                for (int k = 0; k < 12; ++k) c[k] = pts[12 * last + k];
+            }
+            for (int k = 0; k < 12; ++k) pts[12 * last + k] = 0.0f;
+            n--;
+        }
+    }
+    return n;
+}
+
+// btPlaneSpace1, first tangent
+__device__ __forceinline__ F3 ct_plane_space1(const F3& n)
+{
+    if (__builtin_fabsf(n.z) > 0.7071067811865475244008443621048490f) {
+        const float a = n.y * n.y + n.z * n.z;
+        const float k = 1.0f / __builtin_sqrtf(a);
+        return F3{0.0f, -n.z * k, n.y * k};
+    }
+    const float a = n.x * n.x + n.y * n.y;
+    const float k = 1.0f / __builtin_sqrtf(a);
+    return F3{-n.y * k, n.x * k, 0.0f};
+}
+
+constexpr int kMaxContactRows = 4 * (1 + static_cast<int>(kBoxManifolds));
+
+// One contact's rows (setupContactConstraint + the friction row of convertContact), appended to the island's pools and warm
+// started: oracle/boxbox_ref.h SolveBody's loop body, one operation after the other
+__device__ void ct_add_contact(CtBody& sb, CtRow* normalRow, CtRow* frictionRow, int j, const F3& origin, const F3& bodyLinVel, const F3& bodyAngVel,
+                               const M3& invI, float invMassScalar, float invTimeStep, const F3& worldA, const F3& n, float distance,
+                               float friction, float combinedRestitution, float appliedIn, float lateralIn)
+{
+    constexpr float kErp2 = 0.2f, kSplitThreshold = -0.04f, kWarmstart = 0.85f, kSor = 1.0f, kRestitutionVelocityThreshold = 0.2f;
+    CtRow c = ct_zero_row();
+    const F3 rel_pos1 = sub3(worldA, origin);
+    const F3 vel1 = add3(add3(sb.linVel, sb.extForce), cross3(add3(sb.angVel, sb.extTorque), rel_pos1));
+    const F3 vel = sub3(vel1, F3{0.0f, 0.0f, 0.0f});
+    const float rel_vel = dot3(n, vel);
+    const float relaxation = kSor;
+    const F3 torqueAxis0 = cross3(rel_pos1, n);
+    c.angularComp = mat_vec(invI, torqueAxis0);
+    {
+        const F3 vec = cross3(c.angularComp, rel_pos1);
+        const float denom0 = invMassScalar + dot3(n, vec);
+        const float cfm0 = 0.0f * invTimeStep;
+        c.jacDiagABInv = relaxation / (denom0 + 0.0f + cfm0);
+    }
+    c.normal = n;
+    c.relposCrossN = torqueAxis0;
+    const float penetration = distance + 0.0f;
+    c.friction = friction;
+    float restitution = 0.0f;
+    if (combinedRestitution != 0.0f) {
+        const F3 rbVel = add3(bodyLinVel, cross3(bodyAngVel, rel_pos1));
+        const float rbRelVel = dot3(n, sub3(rbVel, F3{0.0f, 0.0f, 0.0f}));
+        restitution = __builtin_fabsf(rbRelVel) < kRestitutionVelocityThreshold ? 0.0f : combinedRestitution * -rbRelVel;
+        if (restitution <= 0.0f) restitution = 0.0f;
+    }
+    c.applied = appliedIn * kWarmstart;
+    {
+        const F3 lin = F3{c.normal.x * sb.invMass.x, c.normal.y * sb.invMass.y, c.normal.z * sb.invMass.z};
+        sb.dLin = add3(sb.dLin, scale3(lin, c.applied));
+        sb.dAng = add3(sb.dAng, scale3(c.angularComp, c.applied * 1.0f));
+    }
+    c.appliedPush = 0.0f;
+    {
+        const float vel1Dotn = dot3(c.normal, add3(sb.linVel, sb.extForce)) + dot3(c.relposCrossN, add3(sb.angVel, sb.extTorque));
+        const float vel2Dotn = 0.0f + 0.0f;
+        const float rel_vel2 = vel1Dotn + vel2Dotn;
+        float positionalError = 0.0f;
+        float velocityError = restitution - rel_vel2;
+        if (penetration > 0.0f) {
+            positionalError = 0.0f;
+            velocityError -= penetration * invTimeStep;
+        } else {
+            positionalError = -penetration * kErp2 * invTimeStep;
+        }
+        const float penetrationImpulse = positionalError * c.jacDiagABInv;
+        const float velocityImpulse = velocityError * c.jacDiagABInv;
+        if (penetration > kSplitThreshold) {
+            c.rhs = penetrationImpulse + velocityImpulse;
+            c.rhsPenetration = 0.0f;
+        } else {
+            c.rhs = velocityImpulse;
+            c.rhsPenetration = penetrationImpulse;
+        }
+        c.cfm = 0.0f * c.jacDiagABInv;
+        c.lower = 0.0f;
+        c.upper = 1e10f;
+    }
+    F3 dir = sub3(vel, scale3(n, rel_vel));
+    const float lat_rel_vel = dot3(dir, dir);
+    if (lat_rel_vel > kBtEpsilon) {
+        dir = scale3(dir, 1.0f / __builtin_sqrtf(lat_rel_vel));
+    } else {
+        dir = ct_plane_space1(n);
+    }
+    CtRow fr = ct_zero_row();
+    fr.friction = friction;
+    fr.normal = dir;
+    fr.relposCrossN = cross3(rel_pos1, dir);
+    fr.angularComp = mat_vec(invI, fr.relposCrossN);
+    {
+        const F3 vec = cross3(fr.angularComp, rel_pos1);
+        const float denom0 = invMassScalar + dot3(dir, vec);
+        fr.jacDiagABInv = relaxation / (denom0 + 0.0f);
+    }
+    {
+        const float vel1Dotn = dot3(fr.normal, add3(sb.linVel, sb.extForce)) + dot3(fr.relposCrossN, sb.angVel);
+        const float vel2Dotn = 0.0f + 0.0f;
+        const float rv = vel1Dotn + vel2Dotn;
+        const float velocityError = 0.0f - rv;
+        const float velocityImpulse = velocityError * fr.jacDiagABInv;
+        fr.rhs = 0.0f + velocityImpulse;
+        fr.rhsPenetration = 0.0f;
+        fr.cfm = 0.0f;
+        fr.lower = -fr.friction;
+        fr.upper = fr.friction;
+    }
+    fr.applied = lateralIn * kWarmstart;
+    {
+        const F3 lin = scale3(fr.normal, invMassScalar);
+        sb.dLin = add3(sb.dLin, scale3(lin, fr.applied));
+        sb.dAng = add3(sb.dAng, scale3(fr.angularComp, fr.applied * 1.0f));
+    }
+    normalRow[j] = c;
+    frictionRow[j] = fr;
+}
+
+template <bool BASIS>
+__device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t slot)
+{
+    const uint32_t f0 = w.flags[slot];
+    if ((f0 & kTypeMask) != 2u) return;
+    const uint32_t ci0 = w.cinfo[slot];
+    if (ci0 & kCiCapsule) return; // (never routed here)
+    bool collide_only = false;
+    if (f0 & kDrowsy) {
+        const uint32_t dz = w.deact[slot];
+        if (dz == kDeactSleeping) return;
+        collide_only = dz == kDeactWants;
+    }
+    const uint32_t cls = f0 >> kMassShift;
+    float inv_mass;
+    F3 force;
+    if (cls != kMassClassArray) {
+        const float4 gf = w.grav_palette[cls];
+        inv_mass = gf.w;
+        force = F3{gf.x, gf.y, gf.z};
+    } else {
+        inv_mass = w.inv_mass[slot];
+        force = F3{g.gx / inv_mass, g.gy / inv_mass, g.gz / inv_mass};
+    }
+    if (inv_mass == 0.0f) return;
+    const float4 cs = w.cshape[slot];
+    CtShape shape;
+    shape.capsule = false;
+    shape.dims = F3{cs.x, cs.y, cs.z};
+    int n = static_cast<int>((ci0 >> kCiCountShift) & 7u);
+    const bool spin = (f0 & kSpin) != 0;
+    F3 pos = ld3(w.pos, slot);
+    const float breaking = ct_breaking_threshold(shape);
+    Q4 q = ld4(w.quat, slot);
+    M3 basis = bt_mat_from_quat(q);
+    F3 v = ld3(w.vel, slot);
+    F3 av = spin ? ld3(w.angvel, slot) : F3{0.0f, 0.0f, 0.0f};
+    // the AABB Bullet feeds its broadphase (predictUnconstraintMotion / updateAabbs: pose and velocity as the sub-step starts)
+    float fed_mn[3], fed_mx[3];
+    {
+        const F3 he = ld3(w.half_extent, slot);
+        float mn[3], mx[3], mn2[3], mx2[3];
+        bt_aabb_of_pose(pos, basis, he, mn, mx);
+        const F3 pp{pos.x + v.x * g.dt, pos.y + v.y * g.dt, pos.z + v.z * g.dt};
+        if (BASIS || spin) {
+            const M3 r2 = bt_mat_from_quat(bt_integrate_orientation(BASIS ? bt_quat_from_mat(basis) : q, av, g.dt));
+            bt_aabb_of_pose(pp, r2, he, mn2, mx2);
+        } else {
+            bt_aabb_of_pose(pp, basis, he, mn2, mx2);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            fed_mn[a] = mn2[a] < mn[a] ? mn2[a] : mn[a];
+            fed_mx[a] = mx2[a] > mx[a] ? mx2[a] : mx[a];
+        }
+    }
+    // ---- the plane (k_ground's ground_body, for this body)
+    const bool plane_ok = g.plane != 0u && (ci0 & kCiGroundMask) != 0;
+    CtPoint p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = ct_empty_point();
+        if (plane_ok && i < n) {
+            const float4 a = reinterpret_cast<const float4*>(w.manifold)[8ull * slot + 2 * i];
+            const float4 b = reinterpret_cast<const float4*>(w.manifold)[8ull * slot + 2 * i + 1];
+            p[i].localA = F3{a.x, a.y, a.z};
+            p[i].appliedImpulse = a.w;
+            p[i].localB = F3{b.x, 0.0f, b.z};
+            p[i].distance = b.y;
+            p[i].appliedLateral = b.w;
+        }
+    }
+    if (plane_ok) ct_collide(p, n, shape, breaking, pos, basis);
+    // ---- the boxes: exact pairs (fed AABBs overlap non-strictly, filter both ways), the kBoxManifolds lowest entities
+    uint32_t* rows = w.bmanifold + static_cast<uint64_t>(slot) * (kBoxManifolds * kBoxManifoldWords);
+    const bool rows_live = (ci0 & kCiBoxes) != 0;
+    const uint32_t my_entity = g.entity_of_slot[slot];
+    const uint32_t grp = w.group[slot], msk = w.mask[slot];
+    uint32_t accepted[kBoxManifolds];
+    int row_of[kBoxManifolds];
+    int n_acc = 0;
+    for (uint32_t k = 0; k < g.n_obstacles && n_acc < static_cast<int>(kBoxManifolds); ++k) {
+        const ObstacleRec& o = g.obstacles[k];
+        if (!o.live || o.entity == my_entity) continue;
+        if ((grp & o.mask) == 0u || (o.group & msk) == 0u) continue;
+        const bool overlap = fed_mn[0] <= o.aabb[3] && fed_mx[0] >= o.aabb[0] && fed_mn[1] <= o.aabb[4] && fed_mx[1] >= o.aabb[1] &&
+                             fed_mn[2] <= o.aabb[5] && fed_mx[2] >= o.aabb[2];
+        if (!overlap) continue;
+        accepted[n_acc] = k;
+        row_of[n_acc] = -1;
+        n_acc++;
+    }
+    // a manifold lives as long as its pair: rows whose box is no longer a partner (or was re-created) are freed
+    uint32_t row_used = 0;
+    for (uint32_t e = 0; e < kBoxManifolds; ++e) {
+        uint32_t* hdr = rows + e * kBoxManifoldWords;
+        bool keep = false;
+        if (rows_live && hdr[0] != kBoxNone) {
+            for (int a = 0; a < n_acc; ++a) {
+                const ObstacleRec& o = g.obstacles[accepted[a]];
+                if (o.entity == hdr[0] && o.generation == hdr[2]) {
+                    row_of[a] = static_cast<int>(e);
+                    keep = true;
+                }
+            }
+        }
+        if (keep) {
+            row_used |= 1u << e;
+        } else if (!rows_live || hdr[0] != kBoxNone) {
+            hdr[0] = kBoxNone;
+            hdr[1] = 0u;
+        }
+    }
+    bool touching = plane_ok && n > 0;
+    for (int a = 0; a < n_acc; ++a) {
+        const ObstacleRec& o = g.obstacles[accepted[a]];
+        if (row_of[a] < 0) {
+            uint32_t e = 0;
+            while (row_used & (1u << e)) ++e; // (n_acc <= kBoxManifolds: there is a free row)
+            row_of[a] = static_cast<int>(e);
+            row_used |= 1u << e;
+            uint32_t* hdr = rows + e * kBoxManifoldWords;
+            hdr[0] = o.entity;
+            hdr[1] = 0u;
+            hdr[2] = o.generation;
+            hdr[3] = 0u;
+        }
+        uint32_t* hdr = rows + static_cast<uint32_t>(row_of[a]) * kBoxManifoldWords;
+        const float pair_breaking = fminf(breaking, o.breaking); // btCollisionDispatcher::getNewManifold
+        const int np = bp_collide(reinterpret_cast<float*>(hdr + 4), static_cast<int>(hdr[1]), pair_breaking, pos, basis, shape.dims, o);
+        hdr[1] = static_cast<uint32_t>(np);
+        touching = touching || np > 0;
+    }
+    uint32_t ci = (ci0 & ~((7u << kCiCountShift) | kCiBoxes)) | (static_cast<uint32_t>(n) << kCiCountShift) | (n_acc > 0 ? kCiBoxes : 0u);
+    auto store_plane = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (plane_ok && i < n) {
+                reinterpret_cast<float4*>(w.manifold)[8ull * slot + 2 * i] = make_float4(p[i].localA.x, p[i].localA.y, p[i].localA.z, p[i].appliedImpulse);
+                reinterpret_cast<float4*>(w.manifold)[8ull * slot + 2 * i + 1] = make_float4(p[i].localB.x, p[i].distance, p[i].localB.z, p[i].appliedLateral);
+            }
+        }
+    };
+    if (collide_only || !((plane_ok || n_acc > 0) && (touching || spin))) {
+        store_plane();
+        if (ci != ci0) w.cinfo[slot] = ci;
+        return; // k_tick puts it to sleep / takes the plain update
+    }
+    if (g.want_aabb) {
+        float* bb = w.aabb + 6ull * slot;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            bb[a] = fed_mn[a];
+            bb[3 + a] = fed_mx[a];
+        }
+    }
+    // ---- solveGroup for the island {body} (oracle/boxbox_ref.h SolveBody)
+    constexpr int kIterations = 10;
+    constexpr float kSplitTurnErp = 0.1f;
+    const float mass = w.cmass[slot];
+    const F3 localInertia = ct_local_inertia(shape, mass);
+    const F3 invInertiaLocal = ct_inv_inertia_local(localInertia);
+    Q4 orn = BASIS ? bt_quat_from_mat(basis) : q;
+    const M3 invI = ct_inv_inertia_world(basis, invInertiaLocal);
+    const float bodyFriction = w.cfriction[slot], bodyRestitution = w.crestitution[slot];
+    CtBody sb;
+    sb.dLin = sb.dAng = sb.push = sb.turn = F3{0.0f, 0.0f, 0.0f};
+    sb.invMass = F3{inv_mass, inv_mass, inv_mass};
+    sb.linVel = v;
+    sb.angVel = av;
+    sb.extForce = scale3(scale3(force, inv_mass), g.dt);
+    sb.extTorque = F3{0.0f, 0.0f, 0.0f};
+    sb.extTorque = add3(sb.extTorque, ct_gyroscopic_impulse(localInertia, av, orn, g.dt));
+    CtRow normalRow[kMaxContactRows], frictionRow[kMaxContactRows];
+    const float invTimeStep = 1.0f / g.dt;
+    int n_rows = 0;
+    if (plane_ok) {
+        const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, bodyFriction * 1.0f));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < n) {
+                ct_add_contact(sb, normalRow, frictionRow, n_rows, pos, v, av, invI, inv_mass, invTimeStep, p[j].worldA, F3{0.0f, 1.0f, 0.0f}, p[j].distance,
+                               combinedFriction, 0.0f, p[j].appliedImpulse, p[j].appliedLateral);
+                n_rows++;
+            }
+        }
+    }
+    for (int a = 0; a < n_acc; ++a) { // (accepted is in ascending entity: the island's manifold order)
+        const ObstacleRec& o = g.obstacles[accepted[a]];
+        const uint32_t* hdr = rows + static_cast<uint32_t>(row_of[a]) * kBoxManifoldWords;
+        const float* pts = reinterpret_cast<const float*>(hdr + 4);
+        const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, bodyFriction * o.friction)); // btManifoldResult::calculateCombinedFriction
+        const float combinedRestitution = bodyRestitution * o.restitution;
+        const int np = static_cast<int>(hdr[1]);
+        for (int j = 0; j < np; ++j) {
+            const float* c = pts + 12 * j;
+            const F3 worldA = add3(mat_vec(basis, bp_get3(c, 0)), pos); // what refreshContactPoints left in m_positionWorldOnA
+            ct_add_contact(sb, normalRow, frictionRow, n_rows, pos, v, av, invI, inv_mass, invTimeStep, worldA, bp_get3(c, 6), c[9], combinedFriction,
+                           combinedRestitution, c[10], c[11]);
+            n_rows++;
+        }
+    }
+#pragma unroll 1
+    for (int it = 0; it < kIterations; ++it) {
+#pragma unroll 1
+        for (int j = 0; j < n_rows; ++j) ct_resolve_split(sb, normalRow[j]);
+    }
+#pragma unroll 1
+    for (int it = 0; it < kIterations; ++it) {
+#pragma unroll 1
+        for (int j = 0; j < n_rows; ++j) ct_resolve_row(sb, normalRow[j], false);
+#pragma unroll 1
+        for (int j = 0; j < n_rows; ++j) {
+            const float totalImpulse = normalRow[j].applied;
+            if (totalImpulse > 0.0f) {
+                frictionRow[j].lower = -(frictionRow[j].friction * totalImpulse);
+                frictionRow[j].upper = frictionRow[j].friction * totalImpulse;
+                ct_resolve_row(sb, frictionRow[j], true);
+            }
+        }
+    }
+    {
+        int j = 0;
+        if (plane_ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < n) {
+                    p[i].appliedImpulse = normalRow[j].applied;
+                    p[i].appliedLateral = frictionRow[j].applied;
+                    j++;
+                }
+            }
+        }
+        for (int a = 0; a < n_acc; ++a) {
+            uint32_t* hdr = rows + static_cast<uint32_t>(row_of[a]) * kBoxManifoldWords;
+            float* pts = reinterpret_cast<float*>(hdr + 4);
+            const int np = static_cast<int>(hdr[1]);
+            for (int i = 0; i < np; ++i) {
+                pts[12 * i + 10] = normalRow[j].applied;
+                pts[12 * i + 11] = frictionRow[j].applied;
+                j++;
+            }
+        }
+    }
+    sb.linVel = add3(sb.linVel, sb.dLin);
+    sb.angVel = add3(sb.angVel, sb.dAng);
+    bool moved = false;
+    if (sb.push.x != 0.0f || sb.push.y != 0.0f || sb.push.z != 0.0f || sb.turn.x != 0.0f || sb.turn.y != 0.0f || sb.turn.z != 0.0f) {
+        pos = add3(pos, scale3(sb.push, g.dt));
+        orn = bt_integrate_orientation(orn, scale3(sb.turn, kSplitTurnErp), g.dt);
+        moved = true;
+    }
+    v = add3(sb.linVel, sb.extForce);
+    av = add3(sb.angVel, sb.extTorque);
+    st3(w.vel, slot, v);
+    st3(w.angvel, slot, av);
+    if (moved) {
+        st3(w.pos, slot, pos);
+        st4(w.quat, slot, orn);
+        ci |= kCiMoved;
+    }
+    store_plane();
+    w.cinfo[slot] = ci | kCiSolved;
+    const bool spin_now = av.x != 0.0f || av.y != 0.0f || av.z != 0.0f;
+    const uint32_t f = spin_now ? (f0 | kSpin) : (f0 & ~kSpin);
+    if (f != f0) w.flags[slot] = f;
+}
+
+template <bool BASIS>
+__global__ void __launch_bounds__(64) k_contact_boxes(WorldView w, GroundParams g)
+{
+    const uint32_t n_list = g.box_count[0];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = g.box_list[i];
+        if (slot < g.n_slots) contact_body<BASIS>(w, g, slot);
+    }
+    // the workgroup that finishes last empties the list for the next sub-step's k_ground_select (every workgroup has read the count)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&g.box_count[1], 1u) == gridDim.x - 1u) {
+            g.box_count[0] = 0;
+            g.box_count[1] = 0;
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundParams& g, bool bullet_basis)
@@ -809,12 +1453,16 @@ hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundPar
     const dim3 sgrid(static_cast<uint32_t>((g.n_slots + 255) / 256)), sblock(256);
     // what is resident: 2 x BGE_GROUND_MIN_BLOCKS workgroups of 128 threads on each of the 256 CUs (a multiple of the shard count)
     const dim3 grid(512u * BGE_GROUND_MIN_BLOCKS), block(128);
+    const bool boxes = g.box_list != nullptr; // Static / Kinematic box colliders are on
+    if (boxes && g.n_obstacles) hipLaunchKernelGGL(k_obstacles, dim3((g.n_obstacles + 63u) / 64u), dim3(64), 0, stream, w, g);
     if (bullet_basis) {
         hipLaunchKernelGGL(k_ground_select<true>, sgrid, sblock, 0, stream, w, g);
-        hipLaunchKernelGGL(k_ground<true>, grid, block, 0, stream, w, g);
+        if (g.plane) hipLaunchKernelGGL(k_ground<true>, grid, block, 0, stream, w, g);
+        if (boxes) hipLaunchKernelGGL(k_contact_boxes<true>, dim3(256), dim3(64), 0, stream, w, g);
     } else {
         hipLaunchKernelGGL(k_ground_select<false>, sgrid, sblock, 0, stream, w, g);
-        hipLaunchKernelGGL(k_ground<false>, grid, block, 0, stream, w, g);
+        if (g.plane) hipLaunchKernelGGL(k_ground<false>, grid, block, 0, stream, w, g);
+        if (boxes) hipLaunchKernelGGL(k_contact_boxes<false>, dim3(256), dim3(64), 0, stream, w, g);
     }
     return hipGetLastError();
 }

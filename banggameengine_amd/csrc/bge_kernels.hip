@@ -807,6 +807,7 @@ __global__ void k_init_slots(uint64_t n_slots, const uint32_t* __restrict__ stru
     w.cshape[s] = make_float4(0.5f, 0.5f, 0.5f, 0.0f);
     w.cmass[s] = 0.0f;
     w.cfriction[s] = 0.5f; // RigidBody::friction default (src/ecs/PhysicsComponents.h:32)
+    w.crestitution[s] = 0.0f; // RigidBody::restitution default (:33)
     w.cinfo[s] = kCiGroundMask;
     // mtxIdentity(local), mtxIdentity(world)
     for (int k = 0; k < 16; ++k) w.world[16 * s + k] = (k % 5 == 0) ? 1.0f : 0.0f;

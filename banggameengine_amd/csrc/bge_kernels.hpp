@@ -42,6 +42,11 @@ struct WorldView {
     uint32_t* cinfo;          // [slots]     kCi* bits below
     float* manifold;          // [slots][32] four contact points x (localA.xyz, appliedImpulse, localB.x, distance, localB.z, appliedImpulseLateral1);
                               //             allocated when the ground plane is switched on
+    // contacts with the Static / Kinematic box colliders of the scene (round 3; bge_contact.hip, allocated when they are switched on)
+    float* crestitution;      // [slots]     RigidBody::restitution (live on box contacts only: the plane's is 0, and the two multiply)
+    uint32_t* bmanifold;      // [slots][kBoxManifolds][kBoxManifoldWords] a Dynamic box's manifolds with boxes, in no particular order:
+                              //             words 0..3 = other entity, points, the other body's generation, 0; then four points x 12 floats
+                              //             (localA.xyz, localB.xyz, normalWorldOnB.xyz, distance, appliedImpulse, appliedImpulseLateral1)
     uint32_t* frozen;         // [slots / 32] bit per slot, or null: a root whose parent entity lost its Transform keeps the world matrix it had
                               //             (parent * local) until something marks it dirty — TransformSystem::Update recomputes a node only when
                               //             it or an ancestor is dirty, and Scene::RemoveTransform marks nobody (tiles with kHdrFrozen look here)
@@ -53,6 +58,27 @@ constexpr uint32_t kCiGroundMask = 2u;   // the body's mask contains the ground'
 constexpr uint32_t kCiSolved = 4u;       // k_ground ran the solver for this body in this sub-step: velocities are final, gravity included
 constexpr uint32_t kCiMoved = 8u;        // ... and the split impulse corrected the pose (rotationEuler must be rewritten)
 constexpr uint32_t kCiCountShift = 4;    // bits 4..6: contact points in the manifold (0..4)
+constexpr uint32_t kCiBoxes = 0x80u;     // the body holds at least one manifold with a box (its bmanifold rows are live)
+
+// A Dynamic box keeps at most this many manifolds with Static / Kinematic boxes (the lowest entity ids; Bullet has no limit —
+// oracle/boxbox_ref.h kMaxBoxManifolds, a stated specification choice)
+constexpr uint32_t kBoxManifolds = 4;
+constexpr uint32_t kBoxManifoldWords = 52;
+constexpr uint32_t kBoxNone = 0xffffffffu; // `other` of a free manifold row
+
+// What a Dynamic box can rest on: one record per Static / Kinematic body with a box collider, ascending entity index, rebuilt by
+// k_obstacles at the head of every sub-step (pose as Bullet holds it after SyncKinematicBodiesToPhysics, fed AABB, material)
+struct ObstacleRec {
+    float origin[3];
+    float half[3];     // btBoxShape::getHalfExtentsWithMargin()
+    float basis[9];
+    float aabb[6];     // min xyz, max xyz: shape AABB at the pose + 0.02 (updateSingleAabb)
+    float friction, restitution, breaking;
+    uint32_t entity, group, mask, generation;
+    uint32_t live;     // 0: the slot no longer carries such a body
+    uint32_t pad[3];
+};
+static_assert(sizeof(ObstacleRec) == 128, "one record = two float4 x 4 lines");
 
 struct GroundParams {
     float dt;
@@ -64,6 +90,15 @@ struct GroundParams {
     uint32_t* list_count;      // [16 * shard] entries of a shard's segment, [16 * shard + 1] the shard's ticket counter in k_ground; all
                                // zero between sub-steps (the last workgroup of each shard sees to it)
     uint64_t shard_cap;        // ground_shard_cap(n_slots)
+    uint32_t plane;            // the static plane y = 0 is in the world (bge_world_set_ground_plane)
+    // Static / Kinematic box colliders (bge_world_set_static_contacts): null / 0 when off
+    const uint32_t* obstacle_slots; // [n_obstacles] ascending entity index
+    const uint32_t* obstacle_gen;   // [n_obstacles] generation of each body (bumped by every re-creation)
+    ObstacleRec* obstacles;         // [n_obstacles] written by k_obstacles
+    uint32_t n_obstacles;
+    const uint32_t* entity_of_slot;
+    uint32_t* box_list;        // [n_slots] slots k_ground_select hands to k_contact_boxes
+    uint32_t* box_count;       // [0] entries of box_list, [1] workgroups of k_contact_boxes that are done (both zero between sub-steps)
 };
 constexpr uint32_t kGroundShards = 64;
 // slots the select workgroups b = shard, shard + 64, ... (256 slots each) can send at most

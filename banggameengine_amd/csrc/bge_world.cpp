@@ -154,6 +154,15 @@ struct bge_world {
     DevBuf root_worlds, counter, stage, stage2, mass_palette, normal, deact, filter_class, filter_table, grav_palette;
     DevBuf cshape, cmass, cfriction, cinfo, manifold; // ground contact (bge_contact.hip); manifold allocated when the plane is switched on
     DevBuf ground_list, ground_count;                 // slots k_ground_select hands to the solver; count + ticket words
+    // Dynamic boxes on the Static / Kinematic box colliders of the scene (round 3, bge_contact.hip): off by default, like the plane
+    bool static_contacts = false;
+    DevBuf crestitution;                              // RigidBody::restitution per slot (allocated with the layout, zero = the component default)
+    DevBuf bmanifold;                                 // kBoxManifolds manifold rows per slot (allocated when the feature is switched on)
+    DevBuf obstacle_slots, obstacle_gen, obstacles, box_list, box_count;
+    uint32_t n_obstacles = 0;
+    bool obstacles_stale = true;                      // the compact list of Static / Kinematic box bodies must be rebuilt
+    std::vector<uint8_t> body_shape_host;             // bge_shape per entity index as last uploaded
+    std::vector<uint32_t> body_gen_host;              // how often the entity's body was (re)created: a re-created box is a new pair
     std::vector<std::vector<uint32_t>> trig_scratch;  // process_trigger_pairs: this tick's body overlaps per trigger (capacity kept)
     std::vector<std::vector<uint32_t>> trig_scratch_ghosts; // ... and the ghosts met, as trigger indices
     std::vector<uint32_t> trig_union;                 // ... and the union being diffed
@@ -307,13 +316,15 @@ struct bge_world {
         view.cfriction = cfriction.as<float>();
         view.cinfo = cinfo.as<uint32_t>();
         view.manifold = manifold.as<float>();
+        view.crestitution = crestitution.as<float>();
+        view.bmanifold = bmanifold.as<uint32_t>();
         view.frozen = frozen.as<uint32_t>();
     }
     void release_all()
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &frozen, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &crestitution, &bmanifold, &obstacle_slots, &obstacle_gen, &obstacles, &box_list, &box_count, &frozen, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists, &ground_list, &ground_count}) {
             b->release();
         }
@@ -594,6 +605,41 @@ void process_triggers_without_a_step(bge_world* w)
     }
 }
 
+// The compact list of what a Dynamic box can rest on — every Static / Kinematic body with a box collider, ascending entity index,
+// with the generation of its btRigidBody — and the buffers of the box-contact path (bge_contact.hip); rebuilt after body uploads
+// and re-topologies only.
+int prepare_obstacles(bge_world* w, uint64_t n_slots)
+{
+    if (w->box_list.bytes < n_slots * 4 || !w->box_count.p) {
+        HIP_TRY(w->box_list.ensure(std::max<uint64_t>(n_slots, 1) * 4));
+        HIP_TRY(w->box_count.ensure(64));
+        HIP_TRY(hipMemsetAsync(w->box_count.p, 0, 64, w->stream));
+    }
+    if (!w->obstacles_stale) return BGE_OK;
+    std::vector<uint32_t> slots, gens;
+    for (uint64_t e = 0; e < w->flat.n_entities && e < w->body_type_host.size(); ++e) {
+        const uint8_t t = w->body_type_host[e];
+        if (t != BGE_BODY_STATIC && t != BGE_BODY_KINEMATIC) continue;
+        if (e < w->body_shape_host.size() && w->body_shape_host[e] == BGE_SHAPE_CAPSULE) continue;
+        const uint32_t sl = w->flat.slot_of_entity[e];
+        if (sl == bge::kNone) continue;
+        slots.push_back(sl);
+        gens.push_back(e < w->body_gen_host.size() ? w->body_gen_host[e] : 0u);
+    }
+    w->n_obstacles = static_cast<uint32_t>(slots.size());
+    const size_t n = std::max<size_t>(slots.size(), 1);
+    HIP_TRY(hipStreamSynchronize(w->stream)); // (a kernel of the previous tick may still read the old list)
+    HIP_TRY(w->obstacle_slots.ensure(n * 4));
+    HIP_TRY(w->obstacle_gen.ensure(n * 4));
+    HIP_TRY(w->obstacles.ensure(n * sizeof(bge::ObstacleRec)));
+    if (!slots.empty()) {
+        HIP_TRY(hipMemcpy(w->obstacle_slots.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w->obstacle_gen.p, gens.data(), gens.size() * 4, hipMemcpyHostToDevice));
+    }
+    w->obstacles_stale = false;
+    return BGE_OK;
+}
+
 // sum the recorded event pairs into the carry (synchronises the stream)
 int fold_profile(bge_world* w)
 {
@@ -744,7 +790,8 @@ try {
         for (auto [buf, width] : std::initializer_list<std::pair<DevBuf*, uint32_t>>{
                  {&w->pos, 3}, {&w->euler, 3}, {&w->scale, 3}, {&w->world, 16}, {&w->vel, 3}, {&w->angvel, 3},
                  {&w->quat, 4}, {&w->inv_mass, 1}, {&w->deact, 1}, {&w->filter_class, 1}, {&w->half_extent, 3}, {&w->group, 1}, {&w->mask, 1}, {&w->aabb, 6},
-                 {&w->cshape, 4}, {&w->cmass, 1}, {&w->cfriction, 1}, {&w->cinfo, 1}, {&w->manifold, 32}}) {
+                 {&w->cshape, 4}, {&w->cmass, 1}, {&w->cfriction, 1}, {&w->cinfo, 1}, {&w->manifold, 32}, {&w->crestitution, 1},
+                 {&w->bmanifold, bge::kBoxManifolds * bge::kBoxManifoldWords}}) {
             if (buf->p) carries.push_back(Carry{buf, width, TmpBuf{}}); // (the manifold store exists only with the ground plane on)
         }
         for (Carry& c : carries) {
@@ -867,6 +914,12 @@ try {
         HIP_TRY(w->manifold.ensure(S * 128));
         HIP_TRY(hipMemsetAsync(w->manifold.p, 0, w->manifold.bytes, w->stream));
     }
+    HIP_TRY(w->crestitution.ensure(S * 4)); // (k_init_slots writes the default, the carry below the surviving values)
+    if (w->bmanifold.p) { // (exists from the first bge_world_set_static_contacts(1) on and follows every layout, like the plane's store)
+        HIP_TRY(w->bmanifold.ensure(S * bge::kBoxManifolds * bge::kBoxManifoldWords * 4));
+        HIP_TRY(hipMemsetAsync(w->bmanifold.p, 0xff, w->bmanifold.bytes, w->stream));
+    }
+    w->obstacles_stale = true; // slots moved
     HIP_TRY(w->root_worlds.ensure(std::max<size_t>(nf.root_slots.size(), 1) * 64));
     HIP_TRY(w->counter.ensure(64));
     HIP_TRY(w->mass_palette.ensure(256 * sizeof(float2)));
@@ -1073,6 +1126,11 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
                     w->body_since[e] = w->physics_updates; // not in the reference's world before the next update
                 }
                 w->body_type_host[e] = now;
+                if (w->body_shape_host.size() < w->body_type_host.size()) w->body_shape_host.resize(w->body_type_host.size(), BGE_SHAPE_BOX);
+                if (w->body_gen_host.size() < w->body_type_host.size()) w->body_gen_host.resize(w->body_type_host.size(), 0u);
+                w->body_shape_host[e] = sh;
+                w->body_gen_host[e] += 1u; // EnsureRigidBody re-creates the btRigidBody: its pairs and their manifolds are gone
+                w->obstacles_stale = true;
             }
         }
         collider_half_extents(sh, sz, he + 3 * i);
@@ -1331,7 +1389,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
             }
             p.bp_partial = w->bp_partials.as<float4>();
         }
-        if (phys && w->ground_plane) {
+        if (phys && (w->ground_plane || w->static_contacts)) {
             // Ground plane on.  Bullet's order inside PhysicsSystem::Update: teleport dirty bodies (before stepSimulation), then per
             // sub-step collision detection + solver, then integrateTransforms — so k_ground_select re-poses them (once per
             // stepSimulation call) and picks the bodies at the ground, k_ground collides and solves those, and the tick kernel
@@ -1357,6 +1415,17 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
             gp.gz = gravity[2];
             gp.n_slots = n_slots;
             gp.want_aabb = (flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS)) ? 1u : 0u;
+            gp.plane = w->ground_plane ? 1u : 0u;
+            if (w->static_contacts) {
+                if (int rc = prepare_obstacles(w, n_slots)) return rc;
+                gp.obstacle_slots = w->obstacle_slots.as<uint32_t>();
+                gp.obstacle_gen = w->obstacle_gen.as<uint32_t>();
+                gp.obstacles = w->obstacles.as<bge::ObstacleRec>();
+                gp.n_obstacles = w->n_obstacles;
+                gp.entity_of_slot = w->entity_of_slot.as<uint32_t>();
+                gp.box_list = w->box_list.as<uint32_t>();
+                gp.box_count = w->box_count.as<uint32_t>();
+            }
             HIP_TRY(bge::launch_ground(w->stream, w->view, gp, (flags & BGE_TICK_BULLET_BASIS) != 0));
             p.no_repose = 1u;
             p.cinfo_in = w->cinfo.as<uint32_t>();
@@ -1555,6 +1624,98 @@ try {
     return BGE_OK;
 }
 BGE_CATCH_ALL("bge_world_set_ground_plane")
+
+int bge_world_set_static_contacts(bge_world* w, int enabled)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    const bool on = enabled != 0;
+    const uint64_t bytes = std::max<uint64_t>(w->flat.n_slots, bge::kTile) * bge::kBoxManifolds * bge::kBoxManifoldWords * 4;
+    if (on && w->has_topology && w->bmanifold.bytes < bytes) {
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        HIP_TRY(w->bmanifold.ensure(bytes));
+        HIP_TRY(hipMemsetAsync(w->bmanifold.p, 0xff, w->bmanifold.bytes, w->stream)); // every row free (bge::kBoxNone)
+        w->rebuild_view();
+    }
+    if (on && !w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
+    w->static_contacts = on;
+    w->obstacles_stale = true;
+    w->drop_graph();
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_set_static_contacts")
+
+static int upload_restitution_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const float* restitution)
+{
+    if (count == 0) return BGE_OK;
+    if (!restitution) return fail(BGE_ERR_INVALID, "restitution is NULL");
+    DeviceGuard guard(w->device);
+    const uint32_t* di = nullptr;
+    if (int rc = stage_index(w, count, index, &di)) return rc;
+    return upload_rows(w, first, count, 1, restitution, w->crestitution.p, 0, di);
+}
+
+int bge_world_upload_restitution(bge_world* w, uint64_t first, uint64_t count, const float* restitution)
+try {
+    if (int rc = check_range(w, first, count)) return rc;
+    return upload_restitution_impl(w, first, count, nullptr, restitution);
+}
+BGE_CATCH_ALL("bge_world_upload_restitution")
+
+int bge_world_upload_restitution_indexed(bge_world* w, uint64_t count, const uint32_t* entity_index, const float* restitution)
+try {
+    if (int rc = check_range(w, 0, 0)) return rc;
+    if (count && !entity_index) return fail(BGE_ERR_INVALID, "entity_index is NULL");
+    return upload_restitution_impl(w, 0, count, entity_index, restitution);
+}
+BGE_CATCH_ALL("bge_world_upload_restitution_indexed")
+
+int bge_world_download_box_contacts(bge_world* w, uint64_t first, uint64_t count, uint8_t* n_manifolds, uint32_t* header8, float* points192)
+try {
+    if (int rc = check_range(w, first, count)) return rc;
+    if (count == 0) return BGE_OK;
+    DeviceGuard guard(w->device);
+    std::vector<uint32_t> ci(count);
+    if (int rc = download_rows(w, first, count, 1, w->cinfo.p, ci.data())) return rc;
+    constexpr uint32_t kWords = bge::kBoxManifolds * bge::kBoxManifoldWords;
+    std::vector<uint32_t> rows;
+    if (w->bmanifold.p) {
+        rows.resize(count * kWords);
+        if (int rc = download_rows(w, first, count, kWords, w->bmanifold.p, rows.data())) return rc;
+    }
+    for (uint64_t i = 0; i < count; ++i) {
+        // the device keeps a body's rows in no particular order: ascending entity of the other box here
+        uint32_t order[bge::kBoxManifolds];
+        uint32_t n = 0;
+        if (w->bmanifold.p && (ci[i] & bge::kCiBoxes)) {
+            for (uint32_t e = 0; e < bge::kBoxManifolds; ++e) {
+                if (rows[i * kWords + e * bge::kBoxManifoldWords] != bge::kBoxNone) order[n++] = e;
+            }
+            std::sort(order, order + n, [&](uint32_t a, uint32_t b) {
+                return rows[i * kWords + a * bge::kBoxManifoldWords] < rows[i * kWords + b * bge::kBoxManifoldWords];
+            });
+        }
+        if (n_manifolds) n_manifolds[i] = static_cast<uint8_t>(n);
+        for (uint32_t k = 0; k < bge::kBoxManifolds; ++k) {
+            const uint32_t* src = k < n ? &rows[i * kWords + order[k] * bge::kBoxManifoldWords] : nullptr;
+            if (header8) {
+                header8[8 * i + 2 * k] = src ? src[0] : bge::kBoxNone;
+                header8[8 * i + 2 * k + 1] = src ? src[1] : 0u;
+            }
+            if (points192) {
+                float* dst = points192 + 192 * i + 48 * k;
+                if (src) {
+                    std::memcpy(dst, src + 4, 48 * 4);
+                    for (uint32_t j = src[1]; j < 4; ++j) std::memset(dst + 12 * j, 0, 48); // (points beyond the count: whatever the row held)
+                } else {
+                    std::memset(dst, 0, 48 * 4);
+                }
+            }
+        }
+    }
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_download_box_contacts")
 
 static int upload_friction_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const float* friction)
 {

@@ -112,6 +112,23 @@ class World:
         fr = _arr(friction, np.float32)
         check(lib().bge_world_upload_friction(self._h, first, len(fr), _p(fr)))
 
+    def set_static_contacts(self, enabled=True):
+        """Dynamic boxes collide with the Static / Kinematic box colliders of the scene (bge_world.h)."""
+        check(lib().bge_world_set_static_contacts(self._h, int(enabled)))
+
+    def upload_restitution(self, restitution, first=0):
+        r = _arr(restitution, np.float32)
+        check(lib().bge_world_upload_restitution(self._h, first, len(r), _p(r)))
+
+    def download_box_contacts(self, first=0, count=None):
+        """(n_manifolds[count], header[count, 4, 2] = (other entity, points), points[count, 4, 4, 12]) — ascending other entity."""
+        count = self.n - first if count is None else count
+        n = np.zeros(count, np.uint8)
+        hdr = np.zeros((count, 4, 2), np.uint32)
+        pts = np.zeros((count, 4, 4, 12), np.float32)
+        check(lib().bge_world_download_box_contacts(self._h, first, count, _p(n), _p(hdr), _p(pts)))
+        return n, hdr, pts
+
     def download_contacts(self, first=0, count=None):
         """(n, points): n[i] contact points of body i with the ground; points[i, k] = localA.xyz, appliedImpulse, localB.x, distance, localB.z, lateral."""
         count = self.n - first if count is None else count

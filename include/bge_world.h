@@ -274,6 +274,31 @@ BGE_API int bge_world_set_ground_plane(bge_world* world, int enabled);
 BGE_API int bge_world_upload_friction(bge_world* world, uint64_t first, uint64_t count, const float* friction);
 BGE_API int bge_world_upload_friction_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, const float* friction);
 BGE_API int bge_world_download_contacts(bge_world* world, uint64_t first, uint64_t count, uint8_t* n_points, float* points32);
+
+/*
+ * Dynamic boxes on the Static / Kinematic BOX colliders of the scene (round 3).  The reference
+ * creates every RigidBody — Static ones too — as a Bullet body with its btBoxShape / btCapsuleShape
+ * (src/physics/PhysicsSystem.cpp:421-474, CreateShape :686-707) and its default dispatcher collides Dynamic bodies with them
+ * (:122-128, 863): a body dropped over assets/scenes/demo.json:67-91's "Ground", a 50 x 1 x 50 box, rests on the box's top.
+ *   bge_world_set_static_contacts  0 (default) = off, as BASELINE's free bodies need; 1 = every Dynamic body with a BOX collider
+ *       collides with every Static / Kinematic body with a BOX collider whose fed AABB overlaps its own and whose layer / mask
+ *       pass both ways: Bullet's btBoxBoxDetector (15-axis separating-axis test, face clipping, the four-point cull) into a
+ *       4-point persistent manifold per pair, all of a body's manifolds (the plane's too) in ONE sequential-impulse island per
+ *       body — a static body merges no islands.  Combined friction = product of both frictions clamped to +-10, combined
+ *       restitution = product of both restitutions (btManifoldResult), so RigidBody::restitution (:438) is live here.
+ *       Not built: capsules against boxes (GJK / EPA), Dynamic against Dynamic.  A body holds at most 4 such manifolds (lowest
+ *       entity indices); the Dynamic body is always the pair's body A — Bullet orders a pair by proxy creation, which the
+ *       reference leaves to an unordered_map's iteration order (oracle/boxbox_ref.h states every such choice).
+ *   bge_world_upload_restitution   RigidBody::restitution per entity (default 0, src/ecs/PhysicsComponents.h:33).
+ *   bge_world_download_box_contacts  per queried entity: n_manifolds[i] in 0..4, header8 = 4 x (other entity index or
+ *       0xffffffff, points 0..4) in ascending entity index, points192 = 4 manifolds x 4 points x (localA.xyz, localB.xyz,
+ *       normalWorldOnB.xyz, distance, appliedImpulse, appliedImpulseLateral1).  Any of the three may be NULL.
+ */
+BGE_API int bge_world_set_static_contacts(bge_world* world, int enabled);
+BGE_API int bge_world_upload_restitution(bge_world* world, uint64_t first, uint64_t count, const float* restitution);
+BGE_API int bge_world_upload_restitution_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, const float* restitution);
+BGE_API int bge_world_download_box_contacts(bge_world* world, uint64_t first, uint64_t count, uint8_t* n_manifolds, uint32_t* header8,
+                                            float* points192);
 /* Scene::CountDirtyTransforms (src/ecs/Scene.cpp:435-446): a device-side wave-reduced count. */
 BGE_API int bge_world_dirty_count(bge_world* world, uint64_t* out);
 /* Overlapping pairs of the last BROADPHASE tick as (a, b) entity indices, a < b, unordered list.

@@ -981,6 +981,128 @@ def test_ground_plane_at_a_size_that_wraps_the_solver_work_list(basis):
     assert {1, 2} <= states, states       # awake and asleep bodies side by side at the end
 
 
+@pytest.mark.parametrize("basis,plane", [(False, True), (True, True), (False, False)])
+def test_dynamic_boxes_on_static_boxes_match_oracle_bitwise(basis, plane):
+    """SURVEY 8(f) rank 4 / VERDICT r02 item 4: Dynamic boxes collide with the Static / Kinematic box colliders of the scene through
+    Bullet's box-box narrowphase (bge_contact.hip k_contact_boxes against oracle/boxbox_ref.h).  A field of platforms — level,
+    tilted, stacked so that a body can touch two at once, one Kinematic wall — under 500 boxes and capsules of mixed size, mass,
+    friction and restitution dropped from 0.3 .. 3 m, the reference's plane below (or not).  They land face-, edge- and corner-first,
+    bounce where both restitutions are non-zero, slide down the tilted ones, come to rest on 1 .. 4 cached points per manifold, fall
+    asleep; capsules fall through boxes (not built) onto the plane.  On the way a platform is teleported away from under its
+    bodies, a Static box is re-created (a new pair: its manifolds start empty) and a resting Dynamic box is re-created.  Every
+    compared tick: position, rotationEuler, quaternion, both velocities, the plane manifold, every box manifold with its points
+    and impulses, activation state and timer — bit for bit."""
+    rng = np.random.default_rng(2024)
+    n_plat, n_dyn = 14, 500
+    n = n_plat + n_dyn
+    wl = synth.Workload("platforms", synth.FLAT, n, 31337)
+    body_type = np.ones(n, np.uint8)
+    shape = np.zeros(n, np.uint8)
+    size = np.zeros((n, 3), np.float32)
+    mass = np.ones(n, np.float32)
+    wl.scale[:] = 1.0
+    # platforms on a 4 x 3 grid, 8 m apart, tops around y = 1 .. 2; every third one tilted; two stacked pairs; one Kinematic wall
+    for k in range(12):
+        gx, gz = k % 4, k // 4
+        wl.pos[k] = (8.0 * gx - 12.0, 0.8 + 0.3 * (k % 3), 8.0 * gz - 8.0)
+        size[k] = (3.0, 0.4 + 0.1 * (k % 2), 3.0)
+        # (rotationEuler reaches Bullet as setEulerZYX(yaw = e.y, pitch = e.x, roll = e.z), PhysicsSystem.cpp:40-45: e.x turns about the
+        #  vertical, e.y and e.z tilt)
+        wl.euler[k] = (0.3 * k, 0.0, 0.0) if k % 3 else (0.0, 0.15, -0.1)
+        body_type[k] = 0
+    wl.pos[12] = (-12.0 + 2.0, 1.9, -8.0 + 1.0); size[12] = (0.8, 0.3, 0.8); wl.euler[12] = (0.5, 0.0, 0.0); body_type[12] = 0   # a step on platform 0
+    wl.pos[13] = (-4.0 + 2.4, 2.2, -8.0); size[13] = (0.3, 1.2, 3.0); wl.euler[13] = (0.0, 0.0, 0.0); body_type[13] = 2             # a Kinematic wall on platform 1
+    d = slice(n_plat, n)
+    cell = rng.integers(0, 12, n_dyn)
+    wl.pos[d, 0] = (8.0 * (cell % 4) - 12.0 + rng.uniform(-3.4, 3.4, n_dyn)).astype(np.float32)   # (some miss their platform's edge: the plane)
+    wl.pos[d, 2] = (8.0 * (cell // 4) - 8.0 + rng.uniform(-3.4, 3.4, n_dyn)).astype(np.float32)
+    wl.pos[d, 1] = rng.uniform(2.2, 5.0, n_dyn).astype(np.float32)
+    wl.euler[d] = rng.uniform(-1.2, 1.2, (n_dyn, 3)).astype(np.float32)
+    wl.euler[n_plat:n_plat + 60] = 0.0                                     # some land perfectly flat: four-point face contacts at once
+    shape[d] = rng.choice([0, 0, 0, 0, 1], n_dyn)
+    size[d] = rng.uniform(0.15, 0.7, (n_dyn, 3)).astype(np.float32)
+    mass[d] = rng.choice([0.3, 1.0, 5.0], n_dyn)
+    friction = rng.choice([0.05, 0.5, 1.0, 2.0], n).astype(np.float32)
+    restitution = rng.choice([0.0, 0.0, 0.5, 0.9], n).astype(np.float32)
+    layer = np.ones(n, np.uint32)
+    mask = np.full(n, 0xFFFFFFFF, np.uint32)
+    layer[n_plat:n_plat + 20] = 2
+    mask[3] = 0xFFFFFFFD                                                   # platform 3 ignores layer 2: those bodies fall through it
+    mode = po.ORIENT_BASIS if basis else po.ORIENT_IDEAL
+    wl.body_type = body_type
+    ref = build_oracle(wl, orient_mode=mode, shape=shape, size=size, mass=mass, layer=layer, mask=mask)
+    for i in range(n):
+        ref.SetFriction(i + 1, float(friction[i]))
+        ref.SetRestitution(i + 1, float(restitution[i]))
+    ref.SetGroundPlane(plane)
+    ref.SetStaticContacts(True)
+    flags = B.TICK_ALL | (B.TICK_BULLET_BASIS if basis else 0)
+    dyn = body_type == 1
+    seen_points, seen_two, slept, bounced = set(), False, 0, False
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(body_type, mass=mass, shape=shape, size=size, layer=layer, mask=mask)
+        w.upload_friction(friction)
+        w.upload_restitution(restitution)
+        w.set_ground_plane(plane)
+        w.set_static_contacts(True)
+        for tick in range(520):
+            if tick == 260:   # platform 5 goes away from under its bodies; platform 2 is re-created; a resting Dynamic box is re-created
+                away = np.array([[60.0, 1.0, 60.0]], np.float32)
+                ref.SetTRS(6, pos=away[0])
+                w.upload_trs(pos=away, first=5)
+                ref.MarkBodyDirty(3)
+                w.upload_bodies(body_type[2:3], mass=mass[2:3], shape=shape[2:3], size=size[2:3], layer=layer[2:3], mask=mask[2:3], first=2)
+                cnb, _, _ = w.download_box_contacts()
+                e = int(np.flatnonzero(dyn & (cnb > 0))[0])
+                ref.MarkBodyDirty(e + 1)
+                w.upload_bodies(body_type[e:e + 1], mass=mass[e:e + 1], shape=shape[e:e + 1], size=size[e:e + 1], layer=layer[e:e + 1], mask=mask[e:e + 1], first=e)
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, flags=flags)
+            if tick % 4 and tick > 8 and not (258 <= tick <= 264):
+                continue
+            rb, gb = ref.bulk_bodies(), w.download_bodies()
+            ex = rb["exists"]
+            pos, euler = w.download_pose()
+            rpos, reuler = ref.bulk_pose()
+            assert_bits_equal(pos, rpos, f"tick {tick}: position")
+            assert_bits_equal(gb["linvel"][dyn], rb["linvel"][dyn], f"tick {tick}: linear velocity")
+            assert_bits_equal(gb["angvel"][dyn], rb["angvel"][dyn], f"tick {tick}: angular velocity")
+            assert_bits_equal(gb["quat"][ex], rb["quat"][ex], f"tick {tick}: quaternion")
+            assert_bits_equal(euler, reuler, f"tick {tick}: rotationEuler")
+            nb, hdr, pts = w.download_box_contacts()
+            cn, cpts = w.download_contacts()
+            for e in np.flatnonzero(dyn)[:: 5 if tick % 40 else 1]:
+                want = ref.BoxContacts(int(e) + 1)
+                assert nb[e] == len(want), f"tick {tick}: body {e} has {nb[e]} box manifolds, oracle {len(want)}"
+                for k, (other, rows) in enumerate(want):
+                    assert hdr[e, k, 0] == other - 1 and hdr[e, k, 1] == len(rows), f"tick {tick}: body {e} manifold {k}: {hdr[e, k]} vs ({other - 1}, {len(rows)})"
+                    assert_bits_equal(pts[e, k, :len(rows)], rows, f"tick {tick}: body {e} manifold {k} points")
+                    seen_points.add(len(rows))
+                seen_two = seen_two or (len(want) >= 2 and all(len(r) for _, r in want))
+                if plane:
+                    rn, rpts = ref.GroundContacts(int(e) + 1)
+                    assert cn[e] == rn, f"tick {tick}: body {e} has {cn[e]} plane contacts, oracle {rn}"
+                    assert_bits_equal(cpts[e, :rn], rpts, f"tick {tick}: plane contact points of body {e}")
+            st, tm = w.download_activation()
+            rst, rtm = ref.bulk_activation()
+            assert np.array_equal(st[ex], rst[ex].astype(np.uint8)), f"tick {tick}: activation states"
+            assert_bits_equal(tm[ex & (rst == 1)], rtm[ex & (rst == 1)], f"tick {tick}: deactivation timers")
+            slept = int((st[dyn] == 2).sum())
+            bounced = bounced or bool((gb["linvel"][dyn, 1] > 1.0).any())
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world matrices at the end")
+        final_pos, _ = w.download_pose()
+    boxes_on_platforms = dyn & (shape == 0) & (final_pos[:, 1] > 0.9)
+    assert boxes_on_platforms.sum() > 150, boxes_on_platforms.sum()          # many boxes stayed up on their platforms
+    if plane:
+        assert (final_pos[dyn & (shape == 1), 1] < 1.5).all()               # capsules fall through boxes (not built) onto the plane
+    assert {1, 2, 4} <= seen_points, seen_points                            # corner, edge and face contacts
+    assert seen_two and bounced                                             # a body on two boxes at once; restitution is live
+    assert slept > 100, slept
+
+
 def test_ground_plane_switched_off_then_scene_grows_then_on_again():
     """the contact manifold store follows the slot layout whether the plane is on or off.  Bodies land and rest
     on the plane, the plane goes off (they fall on), the scene grows across several tile boundaries (bge_world_set_topology
