@@ -915,7 +915,7 @@ try {
         HIP_TRY(hipMemsetAsync(w->manifold.p, 0, w->manifold.bytes, w->stream));
     }
     HIP_TRY(w->crestitution.ensure(S * 4)); // (k_init_slots writes the default, the carry below the surviving values)
-    if (w->bmanifold.p) { // (exists from the first bge_world_set_static_contacts(1) on and follows every layout, like the plane's store)
+    if (w->static_contacts || w->bmanifold.p) { // (exists from the first bge_world_set_static_contacts(1) on and follows every layout, like the plane's store)
         HIP_TRY(w->bmanifold.ensure(S * bge::kBoxManifolds * bge::kBoxManifoldWords * 4));
         HIP_TRY(hipMemsetAsync(w->bmanifold.p, 0xff, w->bmanifold.bytes, w->stream));
     }
@@ -1637,7 +1637,6 @@ try {
         HIP_TRY(hipMemsetAsync(w->bmanifold.p, 0xff, w->bmanifold.bytes, w->stream)); // every row free (bge::kBoxNone)
         w->rebuild_view();
     }
-    if (on && !w->has_topology) return fail(BGE_ERR_STATE, "bge_world_set_topology has not been called");
     w->static_contacts = on;
     w->obstacles_stale = true;
     w->drop_graph();

@@ -80,6 +80,9 @@ public:
         if (bge_world_create(&d, &world_) != BGE_OK) Log("bge_world_create");
         // every world of the reference has the static plane y = 0 (PhysicsSystem::EnsureGround, PhysicsSystem.cpp:149-166)
         else if (bge_world_set_ground_plane(world_, 1) != BGE_OK) Log("bge_world_set_ground_plane");
+        // ... and its dispatcher collides Dynamic bodies with the Static / Kinematic ones (PhysicsSystem.cpp:122-128): box against box
+        // here (Bullet's btBoxBoxDetector, include/bge_world.h) — what carries a body on demo.json's "Ground"
+        else if (bge_world_set_static_contacts(world_, 1) != BGE_OK) Log("bge_world_set_static_contacts");
     }
     ~GpuSceneMirror() { bge_world_destroy(world_); }
     GpuSceneMirror(const GpuSceneMirror&) = delete;
@@ -96,6 +99,11 @@ public:
     void SetGroundPlane(bool on)
     {
         if (ok() && bge_world_set_ground_plane(world_, on ? 1 : 0) != BGE_OK) Log("bge_world_set_ground_plane");
+    }
+    // Contacts of Dynamic boxes with Static / Kinematic boxes (on by default, as in every reference world)
+    void SetStaticContacts(bool on)
+    {
+        if (ok() && bge_world_set_static_contacts(world_, on ? 1 : 0) != BGE_OK) Log("bge_world_set_static_contacts");
     }
 
     // Resident mode: the world matrices stay on the device after TransformSystem::Update; only the host `dirty` flags
@@ -518,7 +526,7 @@ private:
     bool UploadBodies(SceneT& scene)
     {
         index_list_.clear();
-        b_type_.clear(); b_mass_.clear(); b_shape_.clear(); b_size_.clear(); b_layer_.clear(); b_mask_.clear(); b_friction_.clear();
+        b_type_.clear(); b_mass_.clear(); b_shape_.clear(); b_size_.clear(); b_layer_.clear(); b_mask_.clear(); b_friction_.clear(); b_restitution_.clear();
         seen_.assign(ids_.size(), 0);
         for (auto& kv : scene.GetRigidBodies()) {
             auto it = index_of_.find(kv.first);
@@ -542,6 +550,7 @@ private:
             b_layer_.push_back(rb.layer);
             b_mask_.push_back(rb.mask);
             b_friction_.push_back(rb.friction); // info.m_friction = body.friction (PhysicsSystem.cpp:437)
+            b_restitution_.push_back(rb.restitution); // info.m_restitution = body.restitution (:438)
             body_[i].exists = true;
             rb.dirty = false;   // PhysicsSystem.cpp:476
             col->dirty = false; // PhysicsSystem.cpp:403
@@ -556,6 +565,7 @@ private:
                 b_layer_.push_back(1);
                 b_mask_.push_back(0xffffffffu);
                 b_friction_.push_back(0.5f);
+                b_restitution_.push_back(0.0f);
                 body_[i].exists = false;
                 RetireIfNothingLeft(i);
             }
@@ -567,6 +577,9 @@ private:
         }
         if (bge_world_upload_friction_indexed(world_, index_list_.size(), index_list_.data(), b_friction_.data()) != BGE_OK) {
             return Log("bge_world_upload_friction_indexed");
+        }
+        if (bge_world_upload_restitution_indexed(world_, index_list_.size(), index_list_.data(), b_restitution_.data()) != BGE_OK) {
+            return Log("bge_world_upload_restitution_indexed");
         }
         return true;
     }
@@ -612,7 +625,7 @@ private:
         float* data() { return p; }
     } down_;
     std::vector<uint8_t> b_type_, b_shape_;
-    std::vector<float> b_mass_, b_size_, b_friction_;
+    std::vector<float> b_mass_, b_size_, b_friction_, b_restitution_;
     std::vector<uint32_t> b_layer_, b_mask_;
     size_t live_ = 0;
     std::vector<uint32_t> t_entity_, t_layer_, t_mask_, t_signature_;

@@ -165,6 +165,7 @@ int main(int argc, char** argv)
     }
     Pair w;
     w.refPhysics.groundPlane = true; // the adapter's worlds have the reference's ground plane, as every PhysicsSystem world does
+    w.refPhysics.staticContacts = true; // ... and collide Dynamic boxes with Static / Kinematic ones, as its dispatcher does
     // Application::ReloadScene -> m_physics.ReloadConfigIfNeeded(m_scene); m_fixedDt = m_physics.GetFixedStep()
     // (src/core/Application.cpp:324-326) with the values of the reference's assets/config/physics.json
     CHECK(w.gpuPhysics.GetFixedStep() == static_cast<double>(1.0f / 120.0f) && w.gpuPhysics.GetConfig().gravity == -9.81f, "defaults (PhysicsSystem.h:85-95)");

@@ -108,6 +108,7 @@ static void RunCase(const std::string& text, const char* what, bool gpu)
     orc::RefPhysicsSystem refPhysics;
     refPhysics.computeAabbs = true; // the ghost overlaps come from the fed body AABBs
     refPhysics.groundPlane = true;  // every reference world has it; so has every world of the adapter
+    refPhysics.staticContacts = true; // ... and its dispatcher collides Dynamic boxes with the Static ones; so does the adapter's world
     bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
     const double dt = gpuPhysics.GetFixedStep(); // the reference drives its tick with m_physics.GetFixedStep() (Application.cpp:86, 326)
     for (int k = 0; k < 5; ++k) {
@@ -227,6 +228,7 @@ int main(int argc, char** argv)
         if (gpu) {
             orc::RefPhysicsSystem refPhysics;
             refPhysics.groundPlane = true;
+            refPhysics.staticContacts = true;
             bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
             const double dt = gpuPhysics.GetFixedStep();
             for (int k = 0; k < 560; ++k) {
@@ -258,6 +260,66 @@ int main(int argc, char** argv)
             }
             CHECK(asleep == 2 && awake == 1 && none == 1, "device activation states: %d asleep, %d awake, %d without a body", asleep, awake, none);
             std::printf("ground drop: crate at y = %.6f, capsule at y = %.6f, both asleep after %d ticks\n", crate->position.y, barrel->position.y, 560);
+        }
+    }
+    {
+        // the reference's own scene with a Dynamic crate dropped over it (demo_crate_scene.json beside the demo
+        // fixture: demo.json's three entities + a crate above the Checkpoint volume, a bouncy box above a Kinematic pad).  In the
+        // reference the crate lands on Ground's TOP (y = 0.99: a Static 50 x 1 x 50 box centred at y = -0.01), not on the plane
+        // y = 0 inside it; on its way down it enters the Checkpoint volume, which already lists Ground.  Product store + GPU
+        // adapter against oracle store + oracle physics (boxbox_ref.h), every Transform and every trigger event, every tick.
+        std::string path = argv[1];
+        const size_t slash = path.find_last_of('/');
+        path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "demo_crate_scene.json";
+        std::ifstream gf(path);
+        std::stringstream gs;
+        gs << gf.rdbuf();
+        CHECK(!gs.str().empty(), "cannot read %s", path.c_str());
+        orc::RefScene ref;
+        bge::Scene scene;
+        std::string err;
+        std::unordered_map<std::string, uint32_t> keys;
+        CHECK(bge::LoadSceneFromJsonText(gs.str(), ref, &err), "demo + crate, oracle store: %s", err.c_str());
+        CHECK(bge::LoadSceneFromJsonText(gs.str(), scene, &err, &keys), "demo + crate, product store: %s", err.c_str());
+        CompareStores(ref, scene, "demo + crate", false);
+        CHECK(scene.GetRigidBody(keys["crate"]) && scene.GetRigidBody(keys["crate"])->restitution == 0.3f, "restitution ingested");
+        if (gpu) {
+            orc::RefPhysicsSystem refPhysics;
+            refPhysics.computeAabbs = true;
+            refPhysics.groundPlane = true;
+            refPhysics.staticContacts = true;
+            bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
+            const double dt = gpuPhysics.GetFixedStep();
+            bool entered = false;
+            float ball_apex_after_bounce = 0.0f;
+            bool ball_hit = false;
+            for (int k = 0; k < 640; ++k) {
+                refPhysics.Update(ref, dt);
+                gpuPhysics.Update(scene, dt);
+                std::vector<std::array<uint32_t, 3>> a, b;
+                for (const auto& e : refPhysics.LastTriggerEvents()) a.push_back({static_cast<uint32_t>(e.type), e.trigger, e.other});
+                for (const auto& e : gpuPhysics.TriggerEvents(scene)) b.push_back({static_cast<uint32_t>(e.type), e.trigger, e.other});
+                std::sort(a.begin(), a.end());
+                std::sort(b.begin(), b.end());
+                CHECK(a == b, "demo + crate: trigger events of tick %d differ (%zu vs %zu)", k, a.size(), b.size());
+                for (const auto& e : b) entered = entered || (e[0] == 0u && e[1] == keys["checkpoint"] && e[2] == keys["crate"]);
+                orc::RefTransformSystemUpdate(ref);
+                bge::GpuTransformSystem<bge::Scene>::Update(scene);
+                CompareStores(ref, scene, "demo + crate", true);
+                const float by = scene.GetTransform(keys["ball"])->position.y;
+                if (by < 1.9f) ball_hit = true;
+                if (ball_hit) ball_apex_after_bounce = std::max(ball_apex_after_bounce, by);
+                if (g_failures) break;
+            }
+            const auto* crate = scene.GetTransform(keys["crate"]);
+            CHECK(crate && crate->position.y > 1.48f && crate->position.y < 1.50f, "the crate rests on Ground's top, y = 0.99 + 0.5 (y = %g)", crate ? crate->position.y : 0.0f);
+            CHECK(entered, "the crate entered the Checkpoint volume on its way down");
+            CHECK(ball_apex_after_bounce > 2.0f, "restitution 0.9 x 0.8: the bouncy box leaves the pad again (apex %g)", ball_apex_after_bounce);
+            const auto& rt = refPhysics.Runtimes().at(keys["crate"]);
+            CHECK(rt.activation == orc::kIslandSleeping, "the crate is asleep in the oracle (state %d)", rt.activation);
+            CHECK(rt.boxes.size() == 1 && rt.boxes[0].other == keys["ground"] && rt.boxes[0].n == 4 && rt.ground.n == 0,
+                  "the crate's only manifold is the one with Ground, four points (%zu manifolds)", rt.boxes.size());
+            std::printf("demo + crate: crate at y = %.6f on Ground's top, asleep; bouncy box apex %.3f after the pad\n", crate->position.y, ball_apex_after_bounce);
         }
     }
     if (g_failures == 0) std::printf("scene json: all checks passed%s\n", gpu ? " (with GPU ticks)" : "");
