@@ -112,7 +112,7 @@ __device__ inline void cull_points2(int n, const float p[], int m, int i0, int i
         }
         q = p[n * 2 - 2] * p[1] - p[0] * p[n * 2 - 1];
         if (__builtin_fabsf(a + q) > dev::kBtEpsilon) {
-            a = 1.0f / (3.0f * (a + q));
+            a = 0.3333333432674408f / (a + q); // (1.f / (3 * (a + q)) in the source: the reference's compiled code — MSVC /fp:fast — divides the constant 0x3eaaaaab)
         } else {
             a = 1.0e18f;
         }
@@ -184,6 +184,8 @@ __device__ inline int box_box(const F3& p1v, const M3& basis1, const F3& half1, 
     s = -3.402823466e+38f;
     invert_normal = 0;
     code = 0;
+// (the four-term sums of expr2 are written (t0 + t1) + (t2 + t3): the association of the reference's COMPILED dBoxBox2 — Bullet is
+    //  built with MSVC /fp:fast — read off the exe by oracle/tools/check_boxbox_order.py for all fifteen axes)
 #define BGE_TST(expr1, expr2, norm, cc)        \
     s2 = __builtin_fabsf(expr1) - (expr2);     \
     if (s2 > 0) return 0;                      \
@@ -193,25 +195,28 @@ __device__ inline int box_box(const F3& p1v, const M3& basis1, const F3& half1, 
         invert_normal = ((expr1) < 0);         \
         code = (cc);                           \
     }
-    BGE_TST(pp[0], (A[0] + B[0] * Q11 + B[1] * Q12 + B[2] * Q13), R1 + 0, 1);
-    BGE_TST(pp[1], (A[1] + B[0] * Q21 + B[1] * Q22 + B[2] * Q23), R1 + 1, 2);
-    BGE_TST(pp[2], (A[2] + B[0] * Q31 + B[1] * Q32 + B[2] * Q33), R1 + 2, 3);
-    BGE_TST(dotpq(R2 + 0, 4, p, 1), (A[0] * Q11 + A[1] * Q21 + A[2] * Q31 + B[0]), R2 + 0, 4);
-    BGE_TST(dotpq(R2 + 1, 4, p, 1), (A[0] * Q12 + A[1] * Q22 + A[2] * Q32 + B[1]), R2 + 1, 5);
-    BGE_TST(dotpq(R2 + 2, 4, p, 1), (A[0] * Q13 + A[1] * Q23 + A[2] * Q33 + B[2]), R2 + 2, 6);
+    BGE_TST(pp[0], ((A[0] + B[0] * Q11) + (B[1] * Q12 + B[2] * Q13)), R1 + 0, 1);
+    BGE_TST(pp[1], ((A[1] + B[0] * Q21) + (B[1] * Q22 + B[2] * Q23)), R1 + 1, 2);
+    BGE_TST(pp[2], ((A[2] + B[0] * Q31) + (B[1] * Q32 + B[2] * Q33)), R1 + 2, 3);
+    BGE_TST(dotpq(R2 + 0, 4, p, 1), ((A[0] * Q11 + A[1] * Q21) + (A[2] * Q31 + B[0])), R2 + 0, 4);
+    BGE_TST(dotpq(R2 + 1, 4, p, 1), ((A[0] * Q12 + A[1] * Q22) + (A[2] * Q32 + B[1])), R2 + 1, 5);
+    BGE_TST(dotpq(R2 + 2, 4, p, 1), ((A[0] * Q13 + A[1] * Q23) + (A[2] * Q33 + B[2])), R2 + 2, 6);
 #undef BGE_TST
+// (edge axes: the reference's compiled code — MSVC /fp:fast — forms ONE reciprocal 1 / l and multiplies: s2 * (1 / l), n * (1 / l), with
+//  (-1 / l) * r for the negated component, which is the same bits; oracle/tools/check_boxbox_order.py reads it off the exe)
 #define BGE_TST(expr1, expr2, n1, n2, n3, cc)                            \
-    s2 = __builtin_fabsf(expr1) - (expr2);                               \
-    if (s2 > dev::kBtEpsilon) return 0;                                  \
-    l = __builtin_sqrtf((n1) * (n1) + (n2) * (n2) + (n3) * (n3));        \
-    if (l > dev::kBtEpsilon) {                                           \
-        s2 /= l;                                                         \
+    s2 = __builtin_fabsf(expr1) - (expr2);                                          \
+    if (s2 > dev::kBtEpsilon) return 0;                                              \
+    l = __builtin_sqrtf((n1) * (n1) + (n2) * (n2) + (n3) * (n3));                   \
+    if (l > dev::kBtEpsilon) {                                                       \
+        const float il = 1.0f / l;                                       \
+        s2 *= il;                                                        \
         if (s2 * fudge_factor > s) {                                     \
             s = s2;                                                      \
             normalR = nullptr;                                           \
-            normalC[0] = (n1) / l;                                       \
-            normalC[1] = (n2) / l;                                       \
-            normalC[2] = (n3) / l;                                       \
+            normalC[0] = (n1) * il;                                      \
+            normalC[1] = (n2) * il;                                      \
+            normalC[2] = (n3) * il;                                      \
             invert_normal = ((expr1) < 0);                               \
             code = (cc);                                                 \
         }                                                                \
@@ -226,15 +231,15 @@ __device__ inline int box_box(const F3& p1v, const M3& basis1, const F3& half1, 
     Q31 += fudge2;
     Q32 += fudge2;
     Q33 += fudge2;
-    BGE_TST(pp[2] * R21 - pp[1] * R31, (A[1] * Q31 + A[2] * Q21 + B[1] * Q13 + B[2] * Q12), 0.0f, -R31, R21, 7);
-    BGE_TST(pp[2] * R22 - pp[1] * R32, (A[1] * Q32 + A[2] * Q22 + B[0] * Q13 + B[2] * Q11), 0.0f, -R32, R22, 8);
-    BGE_TST(pp[2] * R23 - pp[1] * R33, (A[1] * Q33 + A[2] * Q23 + B[0] * Q12 + B[1] * Q11), 0.0f, -R33, R23, 9);
-    BGE_TST(pp[0] * R31 - pp[2] * R11, (A[0] * Q31 + A[2] * Q11 + B[1] * Q23 + B[2] * Q22), R31, 0.0f, -R11, 10);
-    BGE_TST(pp[0] * R32 - pp[2] * R12, (A[0] * Q32 + A[2] * Q12 + B[0] * Q23 + B[2] * Q21), R32, 0.0f, -R12, 11);
-    BGE_TST(pp[0] * R33 - pp[2] * R13, (A[0] * Q33 + A[2] * Q13 + B[0] * Q22 + B[1] * Q21), R33, 0.0f, -R13, 12);
-    BGE_TST(pp[1] * R11 - pp[0] * R21, (A[0] * Q21 + A[1] * Q11 + B[1] * Q33 + B[2] * Q32), -R21, R11, 0.0f, 13);
-    BGE_TST(pp[1] * R12 - pp[0] * R22, (A[0] * Q22 + A[1] * Q12 + B[0] * Q33 + B[2] * Q31), -R22, R12, 0.0f, 14);
-    BGE_TST(pp[1] * R13 - pp[0] * R23, (A[0] * Q23 + A[1] * Q13 + B[0] * Q32 + B[1] * Q31), -R23, R13, 0.0f, 15);
+    BGE_TST(pp[2] * R21 - pp[1] * R31, ((A[1] * Q31 + A[2] * Q21) + (B[1] * Q13 + B[2] * Q12)), 0.0f, -R31, R21, 7);
+    BGE_TST(pp[2] * R22 - pp[1] * R32, ((A[1] * Q32 + A[2] * Q22) + (B[0] * Q13 + B[2] * Q11)), 0.0f, -R32, R22, 8);
+    BGE_TST(pp[2] * R23 - pp[1] * R33, ((A[1] * Q33 + A[2] * Q23) + (B[0] * Q12 + B[1] * Q11)), 0.0f, -R33, R23, 9);
+    BGE_TST(pp[0] * R31 - pp[2] * R11, ((A[0] * Q31 + A[2] * Q11) + (B[1] * Q23 + B[2] * Q22)), R31, 0.0f, -R11, 10);
+    BGE_TST(pp[0] * R32 - pp[2] * R12, ((A[0] * Q32 + A[2] * Q12) + (B[0] * Q23 + B[2] * Q21)), R32, 0.0f, -R12, 11);
+    BGE_TST(pp[0] * R33 - pp[2] * R13, ((A[0] * Q33 + A[2] * Q13) + (B[0] * Q22 + B[1] * Q21)), R33, 0.0f, -R13, 12);
+    BGE_TST(pp[1] * R11 - pp[0] * R21, ((A[0] * Q21 + A[1] * Q11) + (B[1] * Q33 + B[2] * Q32)), -R21, R11, 0.0f, 13);
+    BGE_TST(pp[1] * R12 - pp[0] * R22, ((A[0] * Q22 + A[1] * Q12) + (B[0] * Q33 + B[2] * Q31)), -R22, R12, 0.0f, 14);
+    BGE_TST(pp[1] * R13 - pp[0] * R23, ((A[0] * Q23 + A[1] * Q13) + (B[0] * Q32 + B[1] * Q31)), -R23, R13, 0.0f, 15);
 #undef BGE_TST
     if (!code) return 0;
 

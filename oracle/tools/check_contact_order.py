@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""What the contact path of oracle/contact_ref.h and oracle/boxbox_ref.h assumes about Bullet, read off the reference's exe.
+
+TEST INFRASTRUCTURE (oracle/): reads /root/reference/build/bin/RelWithDebInfo/SandboxCity.exe as bytes through objdump;
+nothing in it is loaded or run.  VERDICT r02 item 5.  Facts pinned here:
+
+  1. btContactSolverInfo as btDiscreteDynamicsWorld's constructor fills it (the block of immediate stores that starts with
+     m_tau = 0.6 at +0x98 of the world): every solver parameter the restatement hard-codes — numIterations 10, erp2 0.2,
+     globalCfm 0, splitImpulse on with penetration threshold -0.04 and turn erp 0.1, linearSlop 0, warmstartingFactor 0.85,
+     sor 1, solverMode = SOLVER_USE_WARMSTARTING | SOLVER_SIMD (no second friction direction, no randomised order, no
+     interleaving of contact and friction rows, velocity-dependent friction direction enabled), and
+     m_restitutionVelocityThreshold 0.2 (the field exists: bullet3 >= 2.88, so restitutionCurve has its dead band).
+  2. dBoxBox2 (btBoxBoxDetector.cpp), found as the only function that reads the float 1.05 (fudge_factor): it also reads the
+     1e-5 of fudge2, takes exactly nine square roots (the nine edge-edge axes), calls two helpers (intersectRectQuad2,
+     cullPoints2) and makes three virtual calls to Result::addContactPoint (+0x18): the edge-edge case and the two face loops.
+     Its separating-axis phase is executed SYMBOLICALLY (scalar SSE, no FMA, as everywhere outside the two row solvers): the
+     value compared at each of the fifteen tests is, as an expression tree over the inputs, what oracle/boxbox_ref.h's BoxBox2
+     computes — |pp_i| - ((A_i + B_0 Q_i1) + (B_1 Q_i2 + B_2 Q_i3)), ... with Q = |R| (+ 1e-5 for the edge axes), R_ij = column i
+     of R1 . column j of R2 summed (x + y) + z.  The four-term sums are associated pairwise and the edge axes scale by ONE
+     reciprocal 1 / l — what MSVC /fp:fast (Bullet's CMake default, USE_MSVC_FAST_FLOATINGPOINT) made of the source's
+     left-to-right sums and three divisions; the restatement and the device code were changed to the compiled form.
+  3. cullPoints2: calls atan2f once per point in a loop and compares against the float 3.14159265 (M__PI of the file, not
+     SIMD_PI) and its double 6.2831853, reads the 1e9 of maxdiff — and divides the constant 0x3eaaaaab by (a + q) where the
+     source says 1.f / (3 * (a + q)): Bullet is built with MSVC /fp:fast, the restatement follows the compiled form.
+
+Prints one line per fact and "RESULT: ..." at the end; exit code 1 on any mismatch, 2 when the reference is absent.
+"""
+import os
+import re
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def f32(bits):
+    return struct.unpack("<f", struct.pack("<I", bits & 0xFFFFFFFF))[0]
+
+
+def disassemble():
+    import subprocess
+    from check_bx_order import EXE
+    text = subprocess.run(["objdump", "-d", "--no-show-raw-insn", EXE], capture_output=True, text=True, check=True).stdout
+    ins = []
+    for line in text.splitlines():
+        m = re.match(r"\s*([0-9a-f]+):\s+(\S+)\s*(.*)$", line)
+        if m:
+            ins.append((int(m.group(1), 16), m.group(2), m.group(3).split("#")[0].strip()))
+    return ins
+
+
+def check_solver_info(ins):
+    """The constructor's block of stores: movl $0x3f19999a,0x98(%reg) starts it."""
+    starts = [i for i, (_, mn, ops) in enumerate(ins) if mn == "movl" and ops.startswith("$0x3f19999a,0x98(")]
+    ok = len(starts) >= 1
+    fields = {}
+    if ok:
+        i = starts[0]
+        base = ins[i][2].split("(")[1].rstrip(")")
+        for _, mn, ops in ins[i: i + 40]:
+            m = re.match(r"\$0x([0-9a-f]+),0x([0-9a-f]+)\(" + re.escape(base) + r"\)", ops)
+            if m and mn in ("movl", "movq"):
+                off = int(m.group(2), 16)
+                val = int(m.group(1), 16)
+                fields[off] = val & 0xFFFFFFFF
+                if mn == "movq":
+                    fields[off + 4] = (val >> 32) & 0xFFFFFFFF
+            m = re.match(r"%(e?bp|ebp|bp),0x([0-9a-f]+)\(" + re.escape(base) + r"\)", ops)   # (stores of a zeroed register)
+            if m and mn == "mov":
+                fields[int(m.group(2), 16)] = 0
+    want = {  # offset in the world -> (name, value)
+        0x98: ("m_tau", 0.6), 0x9c: ("m_damping", 1.0), 0xac: ("m_numIterations", 10), 0xb4: ("m_sor", 1.0), 0xb8: ("m_erp", 0.2),
+        0xbc: ("m_erp2", 0.2), 0xcc: ("m_globalCfm", 0.0), 0xd8: ("m_splitImpulse", 1), 0xdc: ("m_splitImpulsePenetrationThreshold", -0.04),
+        0xe0: ("m_splitImpulseTurnErp", 0.1), 0xe4: ("m_linearSlop", 0.0), 0xe8: ("m_warmstartingFactor", 0.85), 0xf0: ("m_solverMode", 0x104),
+        0x108: ("m_restitutionVelocityThreshold", 0.2),
+    }
+    bad = []
+    for off, (name, val) in want.items():
+        got = fields.get(off)
+        if got is None:
+            bad.append(f"{name}: no store found")
+        elif isinstance(val, int):
+            if got != val:
+                bad.append(f"{name} = {got:#x}, restated {val:#x}")
+        elif struct.pack("<f", val) != struct.pack("<I", got):
+            bad.append(f"{name} = {f32(got)!r}, restated {val!r}")
+    ok = ok and not bad
+    print(f"btContactSolverInfo in btDiscreteDynamicsWorld's constructor ({len(fields)} immediate stores read): "
+          + ("numIterations 10, sor 1, erp2 0.2, globalCfm 0, split impulse on below -0.04 with turn erp 0.1, linearSlop 0, "
+             "warm starting 0.85, solverMode 0x104 (warm starting | SIMD: one friction direction, rows in pool order), "
+             "restitutionVelocityThreshold 0.2: as restated" if ok else "MISMATCH: " + "; ".join(bad)))
+    return ok
+
+
+def main():
+    from check_bx_order import EXE
+    if not os.path.exists(EXE):
+        print("the reference build is not here; nothing checked")
+        return 2
+    ins = disassemble()
+    ok = check_solver_info(ins)
+    import check_boxbox_order
+    ok &= check_boxbox_order.check(ins)
+    print("RESULT: " + ("the contact path's parameters and the box-box detector's axis tests are compiled as restated" if ok else "MISMATCH"))
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
