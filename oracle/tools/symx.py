@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""A small symbolic executor for MSVC x64 scalar-SSE code, for the Bullet functions of the reference's exe that have branches,
+pointer arguments and 16-byte moves (check_solver_setup.py).  TEST INFRASTRUCTURE (oracle/): it interprets a disassembly
+listing; nothing of the reference is loaded or run.
+
+State: every xmm register is four lanes of expression trees; general registers hold symbolic pointers ("ptr", space, offset),
+integers ("int", v), raw float bits ("f32", tree) or None; memory is a map (space, byte offset) -> tree per 4-byte cell, with
+store forwarding, plus a map of 8-byte pointer cells.  A cell never written reads as the input ("in", space, offset).  The stack
+is the space "stk", offsets relative to %rsp at entry.  Control flow follows `decisions` {pc of a conditional jump: taken?};
+a conditional jump without a decision, an instruction that touches an xmm register and is not modelled, or a call without a hook
+raises — nothing is skipped silently.  Every float comparison executed is recorded in `self.compares`.
+"""
+import re
+import struct
+
+_ALIAS = {}
+for _r in ("ax", "bx", "cx", "dx", "si", "di", "bp", "sp"):
+    _ALIAS["%e" + _r] = "%r" + _r
+    _ALIAS["%" + _r] = "%r" + _r
+for _r, _l in (("ax", "al"), ("bx", "bl"), ("cx", "cl"), ("dx", "dl"), ("si", "sil"), ("di", "dil")):
+    _ALIAS["%" + _l] = "%r" + _r
+for _i in range(8, 16):
+    for _s in ("d", "w", "b"):
+        _ALIAS[f"%r{_i}{_s}"] = f"%r{_i}"
+
+CONDJ = {"je", "jne", "ja", "jae", "jb", "jbe", "jp", "jnp", "jg", "jge", "jl", "jle", "js", "jns"}
+ZERO = ("const", 0.0)
+
+
+def f32(bits):
+    return struct.unpack("<f", struct.pack("<I", bits & 0xFFFFFFFF))[0]
+
+
+def split_ops(ops):
+    return [p.strip() for p in re.split(r",(?![^(]*\))", ops)] if ops else []
+
+
+class Unmodelled(Exception):
+    pass
+
+
+class Machine:
+    def __init__(self, pe, ins, gpr=None, stack_ptrs=None, decisions=None, ptr_loads=None, hooks=None, pc_hooks=None):
+        self.pe, self.ins = pe, ins
+        self.index = {pc: i for i, (pc, _, _) in enumerate(ins)}
+        self.gpr = dict(gpr or {})
+        self.gpr["%rsp"] = ("ptr", "stk", 0)
+        self.xmm = {}
+        self.mem = {}
+        self.memp = {("stk", off): v for off, v in (stack_ptrs or {}).items()}
+        self.decisions = dict(decisions or {})
+        self.ptr_loads = dict(ptr_loads or {})
+        self.hooks = dict(hooks or {})
+        self.pc_hooks = dict(pc_hooks or {})
+        self.compares = []
+        self.trace = []
+        self.last_flags = None
+        self.decider = None
+
+    # ---------------------------------------------------------------- operands
+    def reg64(self, r):
+        return _ALIAS.get(r, r)
+
+    def is32(self, r):
+        return r.startswith("%e") or re.fullmatch(r"%r\d+d", r) is not None
+
+    def addr(self, op, pc_next):
+        m = re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+)\)", op)
+        if not m:
+            # base + index: modelled when one of the two holds the integer 0 (a pool base folded into the other's symbolic pointer)
+            mi = re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+),(%\w+),1\)", op)
+            if not mi:
+                raise Unmodelled(f"addressing {op}")
+            a, b = self.gpr.get(mi.group(2)), self.gpr.get(mi.group(3))
+            if b == ("int", 0):
+                return self.addr(f"{mi.group(1)}({mi.group(2)})", pc_next)
+            if a == ("int", 0):
+                return self.addr(f"{mi.group(1)}({mi.group(3)})", pc_next)
+            raise Unmodelled(f"addressing {op}: {a}, {b}")
+        d = int(m.group(1), 16) if m.group(1) else 0
+        r = m.group(2)
+        if r == "%rip":
+            return ("rip", pc_next + d)
+        v = self.gpr.get(r)
+        if not (isinstance(v, tuple) and v[0] == "ptr"):
+            raise Unmodelled(f"{op}: {r} holds {v}")
+        return (v[1], v[2] + d)
+
+    def const_at(self, va, lanes=1):
+        raw = self.pe.b[self.pe.r2f(va - self.pe.base): self.pe.r2f(va - self.pe.base) + 16]
+        out = []
+        for k in range(lanes):
+            w = raw[4 * k: 4 * k + 4]
+            out.append(("signmask",) if w == b"\x00\x00\x00\x80" else ("absmask",) if w == b"\xff\xff\xff\x7f" else ("const", struct.unpack("<f", w)[0]))
+        return out
+
+    def cell(self, key):
+        return self.mem.get(key, ("in", key[0], key[1]))
+
+    def load_lanes(self, op, pc_next, lanes):
+        if op.startswith("%xmm"):
+            return list(self.xmm.get(op, [("opaque", op + str(k)) for k in range(4)]))[:lanes] + [ZERO] * (4 - lanes)
+        a = self.addr(op, pc_next)
+        if a[0] == "rip":
+            return self.const_at(a[1], lanes) + [ZERO] * (4 - lanes)
+        return [self.cell((a[0], a[1] + 4 * k)) for k in range(lanes)] + [ZERO] * (4 - lanes)
+
+    def store_lanes(self, op, pc_next, vals):
+        a = self.addr(op, pc_next)
+        for k, v in enumerate(vals):
+            self.mem[(a[0], a[1] + 4 * k)] = v
+            self.memp.pop((a[0], a[1] + 4 * k), None)
+
+    def get(self, r):
+        return self.xmm.setdefault(r, [("opaque", r + str(k)) for k in range(4)])
+
+    # ---------------------------------------------------------------- run
+    def run(self, start=None, limit=20000):
+        i = 0 if start is None else self.index[start]
+        steps = 0
+        while True:
+            steps += 1
+            if steps > limit:
+                raise Unmodelled("step limit")
+            pc, mn, ops = self.ins[i]
+            pc_next = self.ins[i + 1][0] if i + 1 < len(self.ins) else pc + 8
+            if pc in self.pc_hooks:
+                self.pc_hooks[pc](self)
+            p = split_ops(ops)
+            self.trace.append(pc)
+            if mn == "ret":
+                return
+            if mn == "jmp":
+                i = self.index[int(p[0], 16)]
+                continue
+            if mn in CONDJ:
+                if pc not in self.decisions:
+                    d = self.decider(self, pc, mn, self.last_flags) if self.decider else None
+                    if d is None:
+                        raise Unmodelled(f"conditional jump without a decision at {pc:#x}: {mn} {ops} after {self.last_flags}")
+                    self.decisions[pc] = d
+                if self.decisions[pc]:
+                    i = self.index[int(p[0], 16)]
+                    continue
+                i += 1
+                continue
+            self.step(pc, mn, p, ops, pc_next)
+            i += 1
+
+    def step(self, pc, mn, p, ops, pc_next):
+        g = self.gpr
+        if mn in ("nop", "nopw", "nopl", "xchg", "data16", "cltq", "cdqe") or mn.startswith("nop"):
+            return
+        if mn == "push":
+            sp = g["%rsp"]
+            g["%rsp"] = ("ptr", "stk", sp[2] - 8)
+            return
+        if mn == "pop":
+            sp = g["%rsp"]
+            g["%rsp"] = ("ptr", "stk", sp[2] + 8)
+            g[self.reg64(p[0])] = None
+            return
+        if mn in ("sub", "add") and len(p) == 2 and p[1] == "%rsp" and p[0].startswith("$"):
+            sp = g["%rsp"]
+            k = int(p[0][1:], 16)
+            g["%rsp"] = ("ptr", "stk", sp[2] - k if mn == "sub" else sp[2] + k)
+            return
+        if mn in ("test", "cmp", "testb", "cmpl", "cmpq", "cmpb", "testl"):
+            self.last_flags = (pc, mn, ops)
+            return                       # (integer flags: the decisions say which way the jump goes)
+        if mn == "lea":
+            a = self.addr(p[0], pc_next)
+            g[self.reg64(p[1])] = ("ptr", a[0], a[1])
+            return
+        if mn in ("mov", "movl", "movq", "movslq", "movzbl", "movzwl", "movabs") and not any(x.startswith("%xmm") for x in p):
+            src, dst = p
+            if dst.startswith("%"):
+                d64 = self.reg64(dst)
+                if src.startswith("$"):
+                    g[d64] = ("int", int(src[1:], 16))
+                elif src.startswith("%"):
+                    g[d64] = g.get(self.reg64(src))
+                else:
+                    a = self.addr(src, pc_next)
+                    if a in self.memp:
+                        g[d64] = self.memp[a]
+                    elif a in self.ptr_loads:
+                        g[d64] = self.ptr_loads[a]
+                    elif self.is32(dst) and mn == "mov":
+                        g[d64] = ("f32", self.cell(a))
+                    else:
+                        g[d64] = None
+                return
+            a = self.addr(dst, pc_next)
+            wide = mn == "movq" or (mn == "mov" and src.startswith("%r") and not self.is32(src) and not src.endswith(("d", "w", "b")))
+            if src.startswith("$"):
+                v = int(src[1:], 16)
+                self.mem[a] = ("const", f32(v))
+                self.memp.pop(a, None)
+                if wide:
+                    self.mem[(a[0], a[1] + 4)] = ("const", f32(v >> 32))
+                return
+            v = g.get(self.reg64(src))
+            if isinstance(v, tuple) and v[0] == "ptr":
+                self.memp[a] = v
+                self.mem.pop(a, None)
+                self.mem.pop((a[0], a[1] + 4), None)
+            elif isinstance(v, tuple) and v[0] == "int":
+                self.memp.pop(a, None)
+                self.mem[a] = ("const", f32(v[1])) if v[1] else ZERO
+                if wide:
+                    self.mem[(a[0], a[1] + 4)] = ("const", f32(v[1] >> 32)) if v[1] >> 32 else ZERO
+            elif isinstance(v, tuple) and v[0] == "f32":
+                self.memp.pop(a, None)
+                self.mem[a] = v[1]
+            else:
+                self.memp[a] = None            # (a callee-saved register's unknown content going to its home slot)
+                self.mem[a] = ("opaque", f"gpr {src}@{pc:#x}")
+                if wide:
+                    self.mem[(a[0], a[1] + 4)] = ("opaque", f"gpr {src}@{pc:#x}+4")
+            return
+        if mn in ("xor",) and len(p) == 2 and p[0] == p[1]:
+            g[self.reg64(p[0])] = ("int", 0)
+            return
+        if mn in ("shl", "shr", "sar", "add", "sub", "and", "or", "inc", "dec", "imul", "neg", "not", "xor", "setne", "sete", "seta", "setb", "setbe", "setae",
+                  "cmovne", "cmove", "cmova", "cmovb", "cmovbe", "cmovae", "cmovg", "cmovl", "cmovge", "cmovle", "movsbl", "movswl") \
+                and not any(x.startswith("%xmm") for x in p):
+            if p and p[-1].startswith("%"):
+                g[self.reg64(p[-1])] = None
+            return
+        if mn == "call":
+            if ops in self.hooks:
+                self.hooks[ops](self)
+                return
+            raise Unmodelled(f"call {ops} at {pc:#x}")
+        # ---------------------------------------------------------------- SSE
+        if mn == "movss":
+            src, dst = p
+            if dst.startswith("%xmm"):
+                if src.startswith("%xmm"):
+                    d = list(self.get(dst))
+                    d[0] = self.get(src)[0]
+                    self.xmm[dst] = d
+                else:
+                    self.xmm[dst] = self.load_lanes(src, pc_next, 1)
+            else:
+                self.store_lanes(dst, pc_next, [self.get(src)[0]])
+            return
+        if mn in ("movaps", "movups", "movdqa", "movdqu"):
+            src, dst = p
+            if dst.startswith("%xmm"):
+                self.xmm[dst] = self.load_lanes(src, pc_next, 4)
+            else:
+                self.store_lanes(dst, pc_next, list(self.get(src)))
+            return
+        if mn == "movd" or (mn == "movq" and any(x.startswith("%xmm") for x in p)):
+            src, dst = p
+            if dst.startswith("%xmm") and src.startswith("%"):
+                v = g.get(self.reg64(src))
+                self.xmm[dst] = [v[1] if isinstance(v, tuple) and v[0] == "f32" else ZERO if v == ("int", 0) else ("opaque", f"movd@{pc:#x}"), ZERO, ZERO, ZERO]
+            elif src.startswith("%xmm") and dst.startswith("%"):
+                g[self.reg64(dst)] = ("f32", self.get(src)[0])
+            else:
+                raise Unmodelled(f"{mn} {ops}")
+            return
+        if mn in ("mulss", "addss", "subss", "divss", "maxss", "minss"):
+            src, dst = p
+            b = self.load_lanes(src, pc_next, 1)[0]
+            d = list(self.get(dst))
+            d[0] = ({"mulss": "mul", "addss": "add", "subss": "sub", "divss": "div", "maxss": "max", "minss": "min"}[mn], d[0], b)
+            self.xmm[dst] = d
+            return
+        if mn in ("mulps", "addps", "subps", "divps", "maxps", "minps"):
+            src, dst = p
+            b = self.load_lanes(src, pc_next, 4)
+            d = self.get(dst)
+            self.xmm[dst] = [(mn[:3], d[k], b[k]) for k in range(4)]
+            return
+        if mn == "sqrtss":
+            src, dst = p
+            d = list(self.get(dst))
+            d[0] = ("sqrtf", self.load_lanes(src, pc_next, 1)[0])
+            self.xmm[dst] = d
+            return
+        if mn in ("xorps", "pxor", "xorpd"):
+            src, dst = p
+            if src == dst:
+                self.xmm[dst] = [ZERO] * 4
+                return
+            m = self.load_lanes(src, pc_next, 4)
+            d = self.get(dst)
+            self.xmm[dst] = [("neg", d[k]) if m[k] == ("signmask",) else d[k] if m[k] == ZERO else ("opaque", f"xorps@{pc:#x}") for k in range(4)]
+            return
+        if mn in ("andps", "pand"):
+            src, dst = p
+            m = self.load_lanes(src, pc_next, 4)
+            d = self.get(dst)
+            self.xmm[dst] = [("abs", d[k]) if m[k] == ("absmask",) else ZERO if m[k] == ZERO else ("opaque", f"andps@{pc:#x}") for k in range(4)]
+            return
+        if mn == "shufps":
+            imm, src, dst = p
+            k = int(imm[1:], 16)
+            d = self.get(dst)
+            s = self.load_lanes(src, pc_next, 4)
+            self.xmm[dst] = [d[k & 3], d[(k >> 2) & 3], s[(k >> 4) & 3], s[(k >> 6) & 3]]
+            return
+        if mn in ("unpcklps",):
+            src, dst = p
+            d = self.get(dst)
+            s = self.load_lanes(src, pc_next, 4)
+            self.xmm[dst] = [d[0], s[0], d[1], s[1]]
+            return
+        if mn in ("comiss", "ucomiss"):
+            src, dst = p
+            self.compares.append((pc, self.get(dst)[0], self.load_lanes(src, pc_next, 1)[0]))
+            self.last_flags = (pc, mn, ops)
+            return
+        raise Unmodelled(f"{pc:#x}: {mn} {ops}")
+
+
+def function_listing(pe, va, size=0x2000):
+    """The instructions of the function at `va`, up to the first int3 after its last ret."""
+    from check_bullet_order import _disasm
+    ins = _disasm(pe, va, size, multi_ret=True)
+    return ins
+
+
+def show(t, names=None, leaf=None):
+    """Compact infix text of a (normalised) tree.  names: {tree: label} for sub-trees to print by name; leaf: fn(space, off) -> text."""
+    if names and t in names:
+        return names[t]
+    op = t[0]
+    if op == "in":
+        return leaf(t[1], t[2]) if leaf else f"{t[1]}[{t[2]:#x}]"
+    if op == "const":
+        return repr(t[1])
+    if op == "opaque":
+        return f"<{t[1]}>"
+    if op in ("neg",):
+        return "-" + show(t[1], names, leaf)
+    if op in ("abs", "sqrtf", "floor", "trunc"):
+        return f"{op}({show(t[1], names, leaf)})"
+    if op in ("max", "min", "atan2f"):
+        return f"{op}({show(t[1], names, leaf)}, {show(t[2], names, leaf)})"
+    sym = {"add": " + ", "sub": " - ", "mul": "*", "div": " / "}[op]
+    return "(" + show(t[1], names, leaf) + sym + show(t[2], names, leaf) + ")"
