@@ -47,6 +47,20 @@ __device__ __forceinline__ F3 mat_t_vec(const M3& m, const F3& v)
               m.m[0][2] * v.x + m.m[1][2] * v.y + m.m[2][2] * v.z};
 }
 
+// ---- associations of the reference's compiled code (MSVC /fp:fast; oracle/contact_ref.h, oracle/tools/check_solver_setup.py)
+__device__ __forceinline__ float dot_xzy(const F3& a, const F3& b) { return (a.x * b.x + a.z * b.z) + a.y * b.y; }
+__device__ __forceinline__ float inv_mass_plus_dot(float invMass, const F3& n, const F3& vec) { return (invMass + n.z * vec.z) + (n.x * vec.x + n.y * vec.y); }
+__device__ __forceinline__ F3 xform_point(const M3& b, const F3& o, const F3& l)
+{
+    return F3{(o.x + l.y * b.m[0][1]) + (l.x * b.m[0][0] + l.z * b.m[0][2]), (o.y + l.y * b.m[1][1]) + (l.x * b.m[1][0] + l.z * b.m[1][2]),
+              (o.z + l.y * b.m[2][1]) + (l.x * b.m[2][0] + l.z * b.m[2][2])};
+}
+__device__ __forceinline__ F3 xform_point_b(const M3& b, const F3& o, const F3& l)
+{
+    return F3{(o.x + l.z * b.m[0][2]) + (l.x * b.m[0][0] + l.y * b.m[0][1]), (o.y + l.y * b.m[1][1]) + (l.x * b.m[1][0] + l.z * b.m[1][2]),
+              (o.z + l.y * b.m[2][1]) + (l.x * b.m[2][0] + l.z * b.m[2][2])};
+}
+
 struct CtShape {
     bool capsule;
     F3 dims; // box: half extents with margin; capsule: (radius, half height, radius)
@@ -260,7 +274,7 @@ __device__ __forceinline__ void ct_collide(CtPoint (&p)[4], int& n, const CtShap
 #pragma unroll
     for (int i = 3; i >= 0; --i) {
         if (i < n) {
-            p[i].worldA = add3(mat_vec(basis, p[i].localA), origin);
+            p[i].worldA = xform_point(basis, origin, p[i].localA);
             p[i].worldB = p[i].localB;
             p[i].distance = dot3(sub3(p[i].worldA, p[i].worldB), F3{0.0f, 1.0f, 0.0f});
         }
@@ -321,32 +335,26 @@ __device__ __forceinline__ F3 ct_solve33(const M3& J, const F3& b)
     if (__builtin_fabsf(det) > kBtEpsilon) det = 1.0f / det;
     return F3{det * dot3(b, cross3(col2, col3)), det * dot3(col1, cross3(b, col3)), det * dot3(col1, cross3(col2, b))};
 }
-__device__ __forceinline__ M3 ct_skew(const F3& v)
+// computeGyroscopicImpulseImplicit_Body: idl = getLocalInertia() = 1 / m_invInertiaLocal; J with the exact zero products folded
+// away, as compiled (oracle/contact_ref.h GyroscopicImpulse)
+__device__ __forceinline__ F3 ct_gyroscopic_impulse(const F3& invInertiaLocal, const F3& omega1, const Q4& q, float step)
 {
-    M3 s;
-    s.m[0][0] = 0.0f; s.m[0][1] = -v.z; s.m[0][2] = v.y;
-    s.m[1][0] = v.z; s.m[1][1] = 0.0f; s.m[1][2] = -v.x;
-    s.m[2][0] = -v.y; s.m[2][1] = v.x; s.m[2][2] = 0.0f;
-    return s;
-}
-__device__ __forceinline__ F3 ct_gyroscopic_impulse(const F3& idl, const F3& omega1, const Q4& q, float step)
-{
+    const F3 idl = F3{invInertiaLocal.x != 0.0f ? 1.0f / invInertiaLocal.x : 0.0f, invInertiaLocal.y != 0.0f ? 1.0f / invInertiaLocal.y : 0.0f,
+                      invInertiaLocal.z != 0.0f ? 1.0f / invInertiaLocal.z : 0.0f};
     const Q4 qinv{-q.x, -q.y, -q.z, q.w};
     F3 omegab = ct_quat_rotate(qinv, omega1);
     const F3 ibo = F3{idl.x * omegab.x, idl.y * omegab.y, idl.z * omegab.z};
     const F3 f = scale3(cross3(omegab, ibo), step);
-    const M3 s0 = ct_skew(omegab), s1 = ct_skew(ibo);
-    const float il[3] = {idl.x, idl.y, idl.z};
     M3 J;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float s0Ib = s0.m[r][c] * il[c];
-            const float ib = r == c ? il[c] : 0.0f;
-            J.m[r][c] = ib + (s0Ib - s1.m[r][c]) * step;
-        }
-    }
+    J.m[0][0] = idl.x;
+    J.m[0][1] = (idl.z * omegab.z - idl.y * omegab.z) * step;
+    J.m[0][2] = (idl.z * omegab.y - idl.y * omegab.y) * step;
+    J.m[1][0] = (idl.x * omegab.z - idl.z * omegab.z) * step;
+    J.m[1][1] = idl.y;
+    J.m[1][2] = (idl.x * omegab.x - idl.z * omegab.x) * step;
+    J.m[2][0] = (idl.y * omegab.y - idl.x * omegab.y) * step;
+    J.m[2][1] = (idl.y * omegab.x - idl.x * omegab.x) * step;
+    J.m[2][2] = idl.z;
     const F3 omega_div = ct_solve33(J, f);
     omegab = sub3(omegab, omega_div);
     const F3 omega2 = ct_quat_rotate(q, omegab);
@@ -416,14 +424,14 @@ __device__ __forceinline__ CtRow ct_zero_row()
     return c;
 }
 
-// solveGroup for the island {body} (oracle/contact_ref.h SolveBodyAgainstGround)
+// solveGroup for the island {body} against the plane alone: oracle/boxbox_ref.h SolveBody with no box manifold
 // (inlined into its one caller: as a call its reference arguments — pose, velocities, the four points — lived in scratch memory.
 //  1 M resting bodies: 0.426 -> 0.355 ms per tick; with ct_point_select 0.234 and no scratch at all)
 #ifndef BGE_CT_SOLVE_INLINE
 #define BGE_CT_SOLVE_INLINE __forceinline__
 #endif
 __device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel, Q4& orn, M3& basis, CtPoint (&p)[4], int n, float invMassScalar,
-                                      const F3& invInertiaLocal, const F3& localInertia, float friction, const F3& force, float dt)
+                                      const F3& invInertiaLocal, float friction, const F3& force, float dt)
 {
     constexpr int kIterations = 10;
     constexpr float kErp2 = 0.2f, kSplitThreshold = -0.04f, kSplitTurnErp = 0.1f, kWarmstart = 0.85f, kSor = 1.0f;
@@ -436,7 +444,7 @@ __device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel,
     sb.angVel = angVel;
     sb.extForce = scale3(scale3(force, invMassScalar), dt);
     sb.extTorque = F3{0.0f, 0.0f, 0.0f};
-    sb.extTorque = add3(sb.extTorque, ct_gyroscopic_impulse(localInertia, angVel, orn, dt));
+    sb.extTorque = add3(sb.extTorque, ct_gyroscopic_impulse(invInertiaLocal, angVel, orn, dt));
 
     CtRow normalRow[4], frictionRow[4];
     const float invTimeStep = 1.0f / dt;
@@ -466,7 +474,7 @@ __device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel,
             c.angularComp = mat_vec(invI, torqueAxis0);
             {
                 const F3 vec = cross3(c.angularComp, rel_pos1);
-                const float denom0 = invMassScalar + dot3(nrm, vec);
+                const float denom0 = inv_mass_plus_dot(invMassScalar, nrm, vec);
                 const float cfm0 = 0.0f * invTimeStep;
                 c.jacDiagABInv = relaxation / (denom0 + 0.0f + cfm0);
             }
@@ -483,7 +491,7 @@ __device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel,
             }
             c.appliedPush = 0.0f;
             {
-                const float vel1Dotn = dot3(c.normal, add3(sb.linVel, sb.extForce)) + dot3(c.relposCrossN, add3(sb.angVel, sb.extTorque));
+                const float vel1Dotn = dot_xzy(c.normal, add3(sb.linVel, sb.extForce)) + dot_xzy(c.relposCrossN, add3(sb.angVel, sb.extTorque));
                 const float vel2Dotn = 0.0f + 0.0f;
                 const float rel_vel2 = vel1Dotn + vel2Dotn;
                 float positionalError = 0.0f;
@@ -521,11 +529,11 @@ __device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel,
             f.angularComp = mat_vec(invI, f.relposCrossN);
             {
                 const F3 vec = cross3(f.angularComp, rel_pos1);
-                const float denom0 = invMassScalar + dot3(dir, vec);
+                const float denom0 = inv_mass_plus_dot(invMassScalar, dir, vec);
                 f.jacDiagABInv = relaxation / (denom0 + 0.0f);
             }
             {
-                const float vel1Dotn = dot3(f.normal, add3(sb.linVel, sb.extForce)) + dot3(f.relposCrossN, sb.angVel);
+                const float vel1Dotn = dot_xzy(f.normal, add3(sb.linVel, sb.extForce)) + dot_xzy(f.relposCrossN, sb.angVel);
                 const float vel2Dotn = 0.0f + 0.0f;
                 const float rv = vel1Dotn + vel2Dotn;
                 const float velocityError = 0.0f - rv;
@@ -536,12 +544,7 @@ __device__ BGE_CT_SOLVE_INLINE bool ct_solve(F3& origin, F3& linVel, F3& angVel,
                 f.lower = -f.friction;
                 f.upper = f.friction;
             }
-            f.applied = p[j].appliedLateral * kWarmstart;
-            {
-                const F3 lin = scale3(f.normal, invMassScalar);
-                sb.dLin = add3(sb.dLin, scale3(lin, f.applied));
-                sb.dAng = add3(sb.dAng, scale3(f.angularComp, f.applied * 1.0f));
-            }
+            f.applied = 0.0f; // setFrictionConstraintImpulse of the reference's Bullet zeroes it: friction rows are not warm-started
         }
     }
 #pragma unroll 1
@@ -696,7 +699,7 @@ __device__ void ground_body(const WorldView& w, const GroundParams& g, uint32_t 
     const F3 localInertia = ct_local_inertia(shape, mass);
     const F3 invInertiaLocal = ct_inv_inertia_local(localInertia);
     Q4 orn = BASIS ? bt_quat_from_mat(basis) : q;
-    const bool moved = ct_solve(pos, v, av, orn, basis, p, n, inv_mass, invInertiaLocal, localInertia, w.cfriction[slot], force, g.dt);
+    const bool moved = ct_solve(pos, v, av, orn, basis, p, n, inv_mass, invInertiaLocal, w.cfriction[slot], force, g.dt);
     st3(w.vel, slot, v);
     st3(w.angvel, slot, av);
     if (moved) {
@@ -1012,8 +1015,8 @@ __device__ int bp_collide(float* pts, int n, float breaking, const F3& originA, 
     // refreshContactPoints(body0 transform, body1 transform)
     for (int i = n - 1; i >= 0; --i) {
         float* c = pts + 12 * i;
-        const F3 worldA = add3(mat_vec(basisA, bp_get3(c, 0)), originA);
-        const F3 worldB = add3(mat_vec(basisB, bp_get3(c, 3)), originB);
+        const F3 worldA = xform_point(basisA, originA, bp_get3(c, 0));
+        const F3 worldB = xform_point_b(basisB, originB, bp_get3(c, 3));
         c[9] = dot3(sub3(worldA, worldB), bp_get3(c, 6));
     }
     for (int i = n - 1; i >= 0; --i) {
@@ -1022,8 +1025,8 @@ __device__ int bp_collide(float* pts, int n, float breaking, const F3& originA, 
         bool remove = !(distance <= breaking);
         if (!remove) {
             const F3 nB = bp_get3(c, 6);
-            const F3 worldA = add3(mat_vec(basisA, bp_get3(c, 0)), originA);
-            const F3 worldB = add3(mat_vec(basisB, bp_get3(c, 3)), originB);
+            const F3 worldA = xform_point(basisA, originA, bp_get3(c, 0));
+            const F3 worldB = xform_point_b(basisB, originB, bp_get3(c, 3));
             const F3 projectedPoint = sub3(worldA, scale3(nB, distance));
             const F3 projectedDifference = sub3(worldB, projectedPoint);
             const float distance2d = dot3(projectedDifference, projectedDifference);
@@ -1073,7 +1076,7 @@ __device__ void ct_add_contact(CtBody& sb, CtRow* normalRow, CtRow* frictionRow,
     c.angularComp = mat_vec(invI, torqueAxis0);
     {
         const F3 vec = cross3(c.angularComp, rel_pos1);
-        const float denom0 = invMassScalar + dot3(n, vec);
+        const float denom0 = inv_mass_plus_dot(invMassScalar, n, vec);
         const float cfm0 = 0.0f * invTimeStep;
         c.jacDiagABInv = relaxation / (denom0 + 0.0f + cfm0);
     }
@@ -1096,7 +1099,7 @@ __device__ void ct_add_contact(CtBody& sb, CtRow* normalRow, CtRow* frictionRow,
     }
     c.appliedPush = 0.0f;
     {
-        const float vel1Dotn = dot3(c.normal, add3(sb.linVel, sb.extForce)) + dot3(c.relposCrossN, add3(sb.angVel, sb.extTorque));
+        const float vel1Dotn = dot_xzy(c.normal, add3(sb.linVel, sb.extForce)) + dot_xzy(c.relposCrossN, add3(sb.angVel, sb.extTorque));
         const float vel2Dotn = 0.0f + 0.0f;
         const float rel_vel2 = vel1Dotn + vel2Dotn;
         float positionalError = 0.0f;
@@ -1134,11 +1137,11 @@ __device__ void ct_add_contact(CtBody& sb, CtRow* normalRow, CtRow* frictionRow,
     fr.angularComp = mat_vec(invI, fr.relposCrossN);
     {
         const F3 vec = cross3(fr.angularComp, rel_pos1);
-        const float denom0 = invMassScalar + dot3(dir, vec);
+        const float denom0 = inv_mass_plus_dot(invMassScalar, dir, vec);
         fr.jacDiagABInv = relaxation / (denom0 + 0.0f);
     }
     {
-        const float vel1Dotn = dot3(fr.normal, add3(sb.linVel, sb.extForce)) + dot3(fr.relposCrossN, sb.angVel);
+        const float vel1Dotn = dot_xzy(fr.normal, add3(sb.linVel, sb.extForce)) + dot_xzy(fr.relposCrossN, sb.angVel);
         const float vel2Dotn = 0.0f + 0.0f;
         const float rv = vel1Dotn + vel2Dotn;
         const float velocityError = 0.0f - rv;
@@ -1149,12 +1152,7 @@ __device__ void ct_add_contact(CtBody& sb, CtRow* normalRow, CtRow* frictionRow,
         fr.lower = -fr.friction;
         fr.upper = fr.friction;
     }
-    fr.applied = lateralIn * kWarmstart;
-    {
-        const F3 lin = scale3(fr.normal, invMassScalar);
-        sb.dLin = add3(sb.dLin, scale3(lin, fr.applied));
-        sb.dAng = add3(sb.dAng, scale3(fr.angularComp, fr.applied * 1.0f));
-    }
+    fr.applied = 0.0f; // (not warm-started: see ct_solve)
     normalRow[j] = c;
     frictionRow[j] = fr;
 }
@@ -1331,7 +1329,7 @@ __device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t
     sb.angVel = av;
     sb.extForce = scale3(scale3(force, inv_mass), g.dt);
     sb.extTorque = F3{0.0f, 0.0f, 0.0f};
-    sb.extTorque = add3(sb.extTorque, ct_gyroscopic_impulse(localInertia, av, orn, g.dt));
+    sb.extTorque = add3(sb.extTorque, ct_gyroscopic_impulse(invInertiaLocal, av, orn, g.dt));
     CtRow normalRow[kMaxContactRows], frictionRow[kMaxContactRows];
     const float invTimeStep = 1.0f / g.dt;
     int n_rows = 0;
@@ -1355,7 +1353,7 @@ __device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t
         const int np = static_cast<int>(hdr[1]);
         for (int j = 0; j < np; ++j) {
             const float* c = pts + 12 * j;
-            const F3 worldA = add3(mat_vec(basis, bp_get3(c, 0)), pos); // what refreshContactPoints left in m_positionWorldOnA
+            const F3 worldA = xform_point(basis, pos, bp_get3(c, 0)); // what refreshContactPoints left in m_positionWorldOnA
             ct_add_contact(sb, normalRow, frictionRow, n_rows, pos, v, av, invI, inv_mass, invTimeStep, worldA, bp_get3(c, 6), c[9], combinedFriction,
                            combinedRestitution, c[10], c[11]);
             n_rows++;

@@ -618,8 +618,8 @@ inline void CollideBoxBox(BoxManifold& m, const BoxPose& a, const BoxPose& b)
     // refreshContactPoints(body0 transform, body1 transform)
     for (int i = m.n - 1; i >= 0; --i) {
         BoxPoint& c = m.p[i];
-        c.worldA = Add(MatVec(a.basis, c.localA), a.origin);
-        c.worldB = Add(MatVec(b.basis, c.localB), b.origin);
+        c.worldA = XformPoint(a.basis, a.origin, c.localA);
+        c.worldB = XformPointB(b.basis, b.origin, c.localB);
         c.distance = Dot(Sub(c.worldA, c.worldB), c.normalB);
     }
     for (int i = m.n - 1; i >= 0; --i) {
@@ -641,16 +641,16 @@ inline void CollideBoxBox(BoxManifold& m, const BoxPose& a, const BoxPose& b)
 }
 
 // solveGroup for the island {body}: its manifold with the ground plane (when the plane is on) followed by its manifolds with
-// Static / Kinematic boxes, in ascending entity id — contact_ref.h's SolveBodyAgainstGround with a normal per point.  The
+// Static / Kinematic boxes, in ascending entity id.  The
 // other body of every row is a fixed solver body (static and kinematic objects share the zero-velocity one: the reference
 // never gives a Kinematic body a velocity, it teleports it), so its side of every row contributes exactly zero.
 // Row order = Bullet's pool order for one island: every manifold's points in turn (convertContacts), all contact rows of an
-// iteration before all friction rows.  With no box manifold this IS SolveBodyAgainstGround, operation for operation
-// (tests/test_oracle_physics.py::test_general_solver_without_boxes_is_the_ground_solver_bit_for_bit).
+// iteration before all friction rows.  The row set-up follows the COMPILED setupContactConstraint / setupFrictionConstraint /
+// convertContact of the reference's exe (oracle/tools/check_solver_setup.py; contact_ref.h's header lists what that changed).
 // btContactSolverInfo as the reference's exe constructs it (VA 0x1401b8b5b: tau 0.6 ... m_restitutionVelocityThreshold 0.2 at
 // +0x108 of the world — the field exists, so the build is bullet3 >= 2.88).
 inline bool SolveBody(BodyState& b, Manifold* ground, BoxManifold* boxes, int nBoxes, float invMassScalar, const Vec3& invInertiaLocal,
-                      const Vec3& localInertia, float bodyFriction, const Vec3& force, float dt)
+                      float bodyFriction, const Vec3& force, float dt)
 {
     constexpr int kIterations = 10;
     constexpr float kErp2 = 0.2f;
@@ -668,7 +668,7 @@ inline bool SolveBody(BodyState& b, Manifold* ground, BoxManifold* boxes, int nB
     sb.angVel = b.angVel;
     sb.extForce = Scale(Scale(force, invMassScalar), dt);
     sb.extTorque = V(0.0f, 0.0f, 0.0f);
-    sb.extTorque = Add(sb.extTorque, GyroscopicImpulse(localInertia, b.angVel, b.orn, dt));
+    sb.extTorque = Add(sb.extTorque, GyroscopicImpulse(invInertiaLocal, b.angVel, b.orn, dt));
 
     struct Ref {
         Vec3 worldA, n;
@@ -708,7 +708,7 @@ inline bool SolveBody(BodyState& b, Manifold* ground, BoxManifold* boxes, int nB
         c.angularComp = MatVec(invI, torqueAxis0);
         {
             const Vec3 vec = Cross(c.angularComp, rel_pos1);
-            const float denom0 = invMassScalar + Dot(n, vec);
+            const float denom0 = InvMassPlusDot(invMassScalar, n, vec);
             const float cfm0 = 0.0f * invTimeStep;
             c.jacDiagABInv = relaxation / (denom0 + 0.0f + cfm0);
         }
@@ -732,7 +732,7 @@ inline bool SolveBody(BodyState& b, Manifold* ground, BoxManifold* boxes, int nB
         }
         c.appliedPush = 0.0f;
         {
-            const float vel1Dotn = Dot(c.normal, Add(sb.linVel, sb.extForce)) + Dot(c.relposCrossN, Add(sb.angVel, sb.extTorque));
+            const float vel1Dotn = DotXZY(c.normal, Add(sb.linVel, sb.extForce)) + DotXZY(c.relposCrossN, Add(sb.angVel, sb.extTorque));
             const float vel2Dotn = 0.0f + 0.0f;
             const float rel_vel2 = vel1Dotn + vel2Dotn;
             float positionalError = 0.0f;
@@ -771,11 +771,11 @@ inline bool SolveBody(BodyState& b, Manifold* ground, BoxManifold* boxes, int nB
         f.angularComp = MatVec(invI, f.relposCrossN);
         {
             const Vec3 vec = Cross(f.angularComp, rel_pos1);
-            const float denom0 = invMassScalar + Dot(dir, vec);
+            const float denom0 = InvMassPlusDot(invMassScalar, dir, vec);
             f.jacDiagABInv = relaxation / (denom0 + 0.0f);
         }
         {
-            const float vel1Dotn = Dot(f.normal, Add(sb.linVel, sb.extForce)) + Dot(f.relposCrossN, sb.angVel);
+            const float vel1Dotn = DotXZY(f.normal, Add(sb.linVel, sb.extForce)) + DotXZY(f.relposCrossN, sb.angVel);
             const float vel2Dotn = 0.0f + 0.0f;
             const float rv = vel1Dotn + vel2Dotn;
             const float velocityError = 0.0f - rv;
@@ -786,12 +786,7 @@ inline bool SolveBody(BodyState& b, Manifold* ground, BoxManifold* boxes, int nB
             f.lower = -f.friction;
             f.upper = f.friction;
         }
-        f.applied = *cp.appliedLat * kWarmstart;
-        {
-            const Vec3 lin = Scale(f.normal, invMassScalar);
-            sb.dLin = Add(sb.dLin, Scale(lin, f.applied));
-            sb.dAng = Add(sb.dAng, Scale(f.angularComp, f.applied * 1.0f));
-        }
+        f.applied = 0.0f; // setFrictionConstraintImpulse of this Bullet: frictionConstraint1.m_appliedImpulse = 0.f, no warm start
     }
     for (int it = 0; it < kIterations; ++it) {
         for (int j = 0; j < nRows; ++j) ResolveSplitPenetration(sb, normalRow[j]);

@@ -39,8 +39,23 @@
 //   * contraction: a scan of the whole exe's disassembly finds exactly 12 fused multiply-adds (vfmadd / vfnmadd), all
 //     inside those two _sse4_1_fma3 row solvers, and no other VEX-encoded arithmetic — every other float operation of the
 //     engine, glm and Bullet in that build is an unfused SSE mul/add/sub/div, which is what -ffp-contract=off restates.
-// Everything else is from the published source with scalar left-to-right arithmetic; the compiled operation order of
-// setupContactConstraint, the manifold functions and computeGyroscopicImpulseImplicit_Body has NOT been checked.
+//   * the rest of the path, executed symbolically by oracle/tools/check_solver_setup.py (expression trees of the COMPILED code
+//     against this file's, as for integrateTransform): setupContactConstraint (VA 0x1401cbb10), setupFrictionConstraint
+//     (0x1401cca80), convertContact's relative velocity and lateral direction (0x1401c58c0), computeGyroscopicImpulseImplicit_Body
+//     (0x1401ae380) with btMatrix3x3::solve33, btPersistentManifold::refreshContactPoints (0x1401fed20) / sortCachedPoints
+//     (0x1401ff840) / getCacheEntry (0x1401fe930), btManifoldResult::addContactPoint's local points (0x140204500),
+//     btConvexPlaneCollisionAlgorithm::processCollision's single contact (0x14021ba50), the capsule's support vertex,
+//     btRigidBody::updateInertiaTensor (0x1401b2b50) and the solver's write-back.  Bullet is built with MSVC /fp:fast in that
+//     exe (its CMake default), so sums are NOT always left to right; what the restatement took over from the compiled code:
+//       - denom0 of a row = (invMass + n.z vec.z) + (n.x vec.x + n.y vec.y)                       (InvMassPlusDot)
+//       - the velocity dot products of a row's right-hand side are summed (x + z) + y              (DotXZY)
+//       - refreshContactPoints: world point = (origin + l.y B[r][1]) + (l.x B[r][0] + l.z B[r][2]) (XformPoint; body B's x row
+//         pairs the origin with the z product: XformPointB)
+//       - friction rows are NOT warm-started: setFrictionConstraintImpulse of this Bullet zeroes m_appliedImpulse
+//       - getLocalInertia() is 1 / m_invInertiaLocal per component, not the inertia the shape computed
+//     and the sites that were already the compiled form: rel_pos, getVelocityInLocalPointNoDelta, rel_vel (x + y) + z, the
+//     lateral direction and its normalisation by one reciprocal, btPlaneSpace1, restitutionCurve and its dead band, the
+//     positional error -(pen erp) / dt, solve33, quatRotate, sortCachedPoints' areas, invXform, the support functions.
 //
 // Simplifications (stated, not hidden): the world inverse inertia tensor is rebuilt from the pose at solve time (Bullet
 // keeps the one of the last integrateTransforms: different only in the sub-step right after a teleport of a body that is
@@ -79,6 +94,24 @@ inline Vec3 MatTVec(const Mat3& m, const Vec3& v)
 {
     return V(m.m[0][0] * v.x + m.m[1][0] * v.y + m.m[2][0] * v.z, m.m[0][1] * v.x + m.m[1][1] * v.y + m.m[2][1] * v.z,
              m.m[0][2] * v.x + m.m[1][2] * v.y + m.m[2][2] * v.z);
+}
+
+// ---- associations of the reference's compiled code (MSVC /fp:fast; oracle/tools/check_solver_setup.py)
+// a row's velocity dot products (setupContactConstraint / setupFrictionConstraint): (x + z) + y
+inline float DotXZY(const Vec3& a, const Vec3& b) { return (a.x * b.x + a.z * b.z) + a.y * b.y; }
+// denom0 = rb0->getInvMass() + n.dot(vec) as compiled
+inline float InvMassPlusDot(float invMass, const Vec3& n, const Vec3& vec) { return (invMass + n.z * vec.z) + (n.x * vec.x + n.y * vec.y); }
+// refreshContactPoints: trA(localPointA), every row (origin + l.y B[r][1]) + (l.x B[r][0] + l.z B[r][2])
+inline Vec3 XformPoint(const Mat3& b, const Vec3& o, const Vec3& l)
+{
+    return V((o.x + l.y * b.m[0][1]) + (l.x * b.m[0][0] + l.z * b.m[0][2]), (o.y + l.y * b.m[1][1]) + (l.x * b.m[1][0] + l.z * b.m[1][2]),
+             (o.z + l.y * b.m[2][1]) + (l.x * b.m[2][0] + l.z * b.m[2][2]));
+}
+// refreshContactPoints: trB(localPointB): the x row pairs the origin with the z product
+inline Vec3 XformPointB(const Mat3& b, const Vec3& o, const Vec3& l)
+{
+    return V((o.x + l.z * b.m[0][2]) + (l.x * b.m[0][0] + l.y * b.m[0][1]), (o.y + l.y * b.m[1][1]) + (l.x * b.m[1][0] + l.z * b.m[1][2]),
+             (o.z + l.y * b.m[2][1]) + (l.x * b.m[2][0] + l.z * b.m[2][2]));
 }
 
 // What the reference's colliders are in Bullet (src/physics/PhysicsSystem.cpp:686-707): btBoxShape(halfExtents) with the
@@ -286,8 +319,8 @@ inline void CollideWithGround(Manifold& m, const Shape& shape, float breaking, c
     // refreshContactPoints(convex transform, plane transform)
     for (int i = m.n - 1; i >= 0; --i) {
         ContactPoint& c = m.p[i];
-        c.worldA = Add(MatVec(basis, c.localA), origin);
-        c.worldB = c.localB;
+        c.worldA = XformPoint(basis, origin, c.localA);
+        c.worldB = c.localB; // (the plane's transform is the identity: XformPointB gives the point itself)
         c.distance = Dot(Sub(c.worldA, c.worldB), V(0.0f, 1.0f, 0.0f));
     }
     for (int i = m.n - 1; i >= 0; --i) {
@@ -335,31 +368,27 @@ inline Vec3 Solve33(const Mat3& J, const Vec3& b)
 }
 
 // btRigidBody::computeGyroscopicImpulseImplicit_Body(step): one Newton step of the implicit gyroscopic term in the body
-// frame (BT_ENABLE_GYROSCOPIC_FORCE_IMPLICIT_BODY is a btRigidBody default flag)
-inline Vec3 GyroscopicImpulse(const Vec3& idl, const Vec3& omega1, const Quat& q, float step)
+// frame (BT_ENABLE_GYROSCOPIC_FORCE_IMPLICIT_BODY is a btRigidBody default flag).  idl = getLocalInertia() = 1 / m_invInertiaLocal
+// per component (0 where that is 0).  J = Ib + (skew0 * Ib - skew1) * step as compiled: the products with the zeros of the
+// diagonal Ib and of the skew matrices are folded away (they are exact), which leaves the entries below.
+inline Vec3 GyroscopicImpulse(const Vec3& invInertiaLocal, const Vec3& omega1, const Quat& q, float step)
 {
+    const Vec3 idl = V(invInertiaLocal.x != 0.0f ? 1.0f / invInertiaLocal.x : 0.0f, invInertiaLocal.y != 0.0f ? 1.0f / invInertiaLocal.y : 0.0f,
+                       invInertiaLocal.z != 0.0f ? 1.0f / invInertiaLocal.z : 0.0f);
     const Quat qinv{-q.x, -q.y, -q.z, q.w};
     Vec3 omegab = QuatRotate(qinv, omega1);
-    const Vec3 ibo = V(idl.x * omegab.x, idl.y * omegab.y, idl.z * omegab.z); // Ib * omegab, Ib diagonal (the zero products vanish)
+    const Vec3 ibo = V(idl.x * omegab.x, idl.y * omegab.y, idl.z * omegab.z); // Ib * omegab, Ib diagonal
     const Vec3 f = Scale(Cross(omegab, ibo), step);
-    // skew0 = [omegab]x, skew1 = [Ib omegab]x;  J = Ib + (skew0 * Ib - skew1) * step
-    auto skew = [](const Vec3& v) {
-        Mat3 s;
-        s.m[0][0] = 0.0f; s.m[0][1] = -v.z; s.m[0][2] = v.y;
-        s.m[1][0] = v.z; s.m[1][1] = 0.0f; s.m[1][2] = -v.x;
-        s.m[2][0] = -v.y; s.m[2][1] = v.x; s.m[2][2] = 0.0f;
-        return s;
-    };
-    const Mat3 s0 = skew(omegab), s1 = skew(ibo);
     Mat3 J;
-    const float il[3] = {idl.x, idl.y, idl.z};
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) {
-            const float s0Ib = s0.m[r][c] * il[c]; // (skew0 * Ib)(r,c): Ib is diagonal
-            const float ib = r == c ? il[c] : 0.0f;
-            J.m[r][c] = ib + (s0Ib - s1.m[r][c]) * step;
-        }
-    }
+    J.m[0][0] = idl.x;
+    J.m[0][1] = (idl.z * omegab.z - idl.y * omegab.z) * step;
+    J.m[0][2] = (idl.z * omegab.y - idl.y * omegab.y) * step;
+    J.m[1][0] = (idl.x * omegab.z - idl.z * omegab.z) * step;
+    J.m[1][1] = idl.y;
+    J.m[1][2] = (idl.x * omegab.x - idl.z * omegab.x) * step;
+    J.m[2][0] = (idl.y * omegab.y - idl.x * omegab.y) * step;
+    J.m[2][1] = (idl.y * omegab.x - idl.x * omegab.x) * step;
+    J.m[2][2] = idl.z;
     const Vec3 omega_div = Solve33(J, f);
     omegab = Sub(omegab, omega_div);
     const Vec3 omega2 = QuatRotate(q, omegab);
@@ -440,169 +469,6 @@ struct BodyState {
     Quat orn;   // what physics_ref.h's CurrentOrn() yields for the body
     Mat3 basis; // its matrix
 };
-
-// solveGroup for the island {body} with its ground manifold.  `force` = btRigidBody::m_totalForce after applyGravity.
-// Returns true when the split impulse moved the body (origin / orientation were changed).
-inline bool SolveBodyAgainstGround(BodyState& b, Manifold& m, const Shape& shape, float invMassScalar, const Vec3& invInertiaLocal,
-                                   const Vec3& localInertia, float friction, const Vec3& force, float dt)
-{
-    constexpr int kIterations = 10;               // btContactSolverInfo::m_numIterations
-    constexpr float kErp2 = 0.2f;                 // m_erp2
-    constexpr float kSplitThreshold = -0.04f;     // m_splitImpulsePenetrationThreshold
-    constexpr float kSplitTurnErp = 0.1f;         // m_splitImpulseTurnErp
-    constexpr float kWarmstart = 0.85f;           // m_warmstartingFactor
-    constexpr float kSor = 1.0f;                  // m_sor
-    (void)shape;
-    const Vec3 n = V(0.0f, 1.0f, 0.0f);
-    const Mat3 invI = InvInertiaWorld(b.basis, invInertiaLocal);
-
-    // convertBodies -> initSolverBody
-    SolverBody sb;
-    sb.invMass = V(invMassScalar, invMassScalar, invMassScalar); // invMass * linearFactor (1,1,1)
-    sb.linVel = b.linVel;
-    sb.angVel = b.angVel;
-    sb.extForce = Scale(Scale(force, invMassScalar), dt);          // getTotalForce() * getInvMass() * timeStep
-    sb.extTorque = Scale(MatVec(invI, V(0.0f, 0.0f, 0.0f)), dt);   // getTotalTorque() * invInertiaTensorWorld * timeStep: zero
-    sb.extTorque = V(0.0f, 0.0f, 0.0f);
-    sb.extTorque = Add(sb.extTorque, GyroscopicImpulse(localInertia, b.angVel, b.orn, dt));
-
-    // convertContact
-    SolverRow normalRow[4], frictionRow[4];
-    const float invTimeStep = 1.0f / dt;
-    const float combinedFriction = std::max(-10.0f, std::min(10.0f, friction * 1.0f)); // calculateCombinedFriction with the ground's 1.0
-    for (int j = 0; j < m.n; ++j) {
-        ContactPoint& cp = m.p[j];
-        SolverRow& c = normalRow[j];
-        c = SolverRow{};
-        const Vec3 rel_pos1 = Sub(cp.worldA, b.origin);
-        // getVelocityInLocalPointNoDelta
-        const Vec3 vel1 = Add(Add(sb.linVel, sb.extForce), Cross(Add(sb.angVel, sb.extTorque), rel_pos1));
-        const Vec3 vel = Sub(vel1, V(0.0f, 0.0f, 0.0f));
-        const float rel_vel = Dot(n, vel);
-        // setupContactConstraint
-        const float relaxation = kSor;
-        const Vec3 torqueAxis0 = Cross(rel_pos1, n);
-        c.angularComp = MatVec(invI, torqueAxis0); // * angularFactor (1,1,1)
-        {
-            const Vec3 vec = Cross(c.angularComp, rel_pos1);
-            const float denom0 = invMassScalar + Dot(n, vec);
-            const float cfm0 = 0.0f * invTimeStep;
-            c.jacDiagABInv = relaxation / (denom0 + 0.0f + cfm0);
-        }
-        c.normal = n;
-        c.relposCrossN = torqueAxis0;
-        const float penetration = cp.distance + 0.0f; // + m_linearSlop
-        c.friction = combinedFriction;
-        const float restitution = 0.0f; // combined restitution 0: restitutionCurve gives 0 or -0, clamped to 0
-        // warm starting
-        c.applied = cp.appliedImpulse * kWarmstart;
-        {
-            const Vec3 lin = V(c.normal.x * sb.invMass.x, c.normal.y * sb.invMass.y, c.normal.z * sb.invMass.z);
-            sb.dLin = Add(sb.dLin, Scale(lin, c.applied));               // internalApplyImpulse: += linearComponent * impulse * linearFactor
-            sb.dAng = Add(sb.dAng, Scale(c.angularComp, c.applied * 1.0f)); // += angularComponent * (impulse * angularFactor)
-        }
-        c.appliedPush = 0.0f;
-        {
-            const float vel1Dotn = Dot(c.normal, Add(sb.linVel, sb.extForce)) + Dot(c.relposCrossN, Add(sb.angVel, sb.extTorque));
-            const float vel2Dotn = 0.0f + 0.0f;
-            const float rel_vel2 = vel1Dotn + vel2Dotn;
-            float positionalError = 0.0f;
-            float velocityError = restitution - rel_vel2;
-            if (penetration > 0.0f) {
-                positionalError = 0.0f;
-                velocityError -= penetration * invTimeStep;
-            } else {
-                positionalError = -penetration * kErp2 * invTimeStep;
-            }
-            const float penetrationImpulse = positionalError * c.jacDiagABInv;
-            const float velocityImpulse = velocityError * c.jacDiagABInv;
-            if (penetration > kSplitThreshold) { // m_splitImpulse is on
-                c.rhs = penetrationImpulse + velocityImpulse;
-                c.rhsPenetration = 0.0f;
-            } else {
-                c.rhs = velocityImpulse;
-                c.rhsPenetration = penetrationImpulse;
-            }
-            c.cfm = 0.0f * c.jacDiagABInv;
-            c.lower = 0.0f;
-            c.upper = 1e10f;
-        }
-        // friction direction: the lateral relative velocity, or btPlaneSpace1's first tangent when it vanishes
-        Vec3 dir = Sub(vel, Scale(n, rel_vel));
-        const float lat_rel_vel = Dot(dir, dir);
-        if (lat_rel_vel > bt::kEpsilon) {
-            dir = Scale(dir, 1.0f / std::sqrt(lat_rel_vel));
-        } else {
-            dir = FallbackFrictionDir();
-        }
-        // setupFrictionConstraint
-        SolverRow& f = frictionRow[j];
-        f = SolverRow{};
-        f.friction = combinedFriction;
-        f.normal = dir;
-        f.relposCrossN = Cross(rel_pos1, dir);
-        f.angularComp = MatVec(invI, f.relposCrossN);
-        {
-            const Vec3 vec = Cross(f.angularComp, rel_pos1);
-            const float denom0 = invMassScalar + Dot(dir, vec);
-            f.jacDiagABInv = relaxation / (denom0 + 0.0f);
-        }
-        {
-            const float vel1Dotn = Dot(f.normal, Add(sb.linVel, sb.extForce)) + Dot(f.relposCrossN, sb.angVel);
-            const float vel2Dotn = 0.0f + 0.0f;
-            const float rv = vel1Dotn + vel2Dotn;
-            const float velocityError = 0.0f - rv;
-            const float velocityImpulse = velocityError * f.jacDiagABInv;
-            f.rhs = 0.0f + velocityImpulse;
-            f.rhsPenetration = 0.0f;
-            f.cfm = 0.0f;
-            f.lower = -f.friction;
-            f.upper = f.friction;
-        }
-        // setFrictionConstraintImpulse (warm starting)
-        f.applied = cp.appliedImpulseLateral1 * kWarmstart;
-        {
-            const Vec3 lin = Scale(f.normal, invMassScalar); // m_contactNormal1 * rb0->getInvMass()
-            sb.dLin = Add(sb.dLin, Scale(lin, f.applied));
-            sb.dAng = Add(sb.dAng, Scale(f.angularComp, f.applied * 1.0f));
-        }
-    }
-
-    // solveGroupCacheFriendlySplitImpulseIterations
-    for (int it = 0; it < kIterations; ++it) {
-        for (int j = 0; j < m.n; ++j) ResolveSplitPenetration(sb, normalRow[j]);
-    }
-    // velocity iterations: all contact rows, then all friction rows (no interleaving by default)
-    for (int it = 0; it < kIterations; ++it) {
-        for (int j = 0; j < m.n; ++j) ResolveRow(sb, normalRow[j], false);
-        for (int j = 0; j < m.n; ++j) {
-            const float totalImpulse = normalRow[j].applied;
-            if (totalImpulse > 0.0f) {
-                frictionRow[j].lower = -(frictionRow[j].friction * totalImpulse);
-                frictionRow[j].upper = frictionRow[j].friction * totalImpulse;
-                ResolveRow(sb, frictionRow[j], true);
-            }
-        }
-    }
-    // solveGroupCacheFriendlyFinish: impulses back into the manifold, velocities (and the pushed transform) into the body
-    for (int j = 0; j < m.n; ++j) {
-        m.p[j].appliedImpulse = normalRow[j].applied;
-        m.p[j].appliedImpulseLateral1 = frictionRow[j].applied;
-    }
-    sb.linVel = Add(sb.linVel, sb.dLin); // writebackVelocityAndTransform
-    sb.angVel = Add(sb.angVel, sb.dAng);
-    bool moved = false;
-    if (sb.push.x != 0.0f || sb.push.y != 0.0f || sb.push.z != 0.0f || sb.turn.x != 0.0f || sb.turn.y != 0.0f || sb.turn.z != 0.0f) {
-        // btTransformUtil::integrateTransform(worldTransform, pushVelocity, turnVelocity * splitImpulseTurnErp, timeStep)
-        b.origin = Add(b.origin, Scale(sb.push, dt));
-        b.orn = bt::IntegrateOrientation(b.orn, Scale(sb.turn, kSplitTurnErp), dt);
-        b.basis = bt::MatFromQuat(b.orn);
-        moved = true;
-    }
-    b.linVel = Add(sb.linVel, sb.extForce);
-    b.angVel = Add(sb.angVel, sb.extTorque);
-    return moved;
-}
 
 } // namespace ct
 } // namespace orc

@@ -214,7 +214,6 @@ int orc_get_ground_contacts(void* h, uint32_t id, float* out32)
 }
 // Dynamic boxes against the scene's Static / Kinematic box colliders (boxbox_ref.h)
 void orc_set_static_contacts(void* h, int enabled) { S(h)->physics.staticContacts = enabled != 0; }
-void orc_set_legacy_ground_solver(void* h, int enabled) { S(h)->physics.legacyGroundSolver = enabled != 0; }
 void orc_set_restitution(void* h, uint32_t id, float restitution)
 {
     if (RefRigidBody* b = S(h)->scene.GetRigidBody(id)) b->restitution = restitution;

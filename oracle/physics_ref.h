@@ -196,7 +196,6 @@ public:
     // what the reference's world does for every pair the dispatcher accepts (PhysicsSystem.cpp:122-128); capsules against boxes
     // (GJK / EPA) are not restated.  Off by default, like the plane: BASELINE's workloads are free bodies.
     bool staticContacts = false;
-    bool legacyGroundSolver = false; // tests only: plane-only bodies through round 2's SolveBodyAgainstGround (must give the same bits as SolveBody)
 
     std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
     std::unordered_map<EntityId, RefTriggerRuntime>& TriggerRuntimes() { return triggerRuntime_; }
@@ -424,10 +423,8 @@ private:
                 // the island {body} through the solver.  A body without a contact and without angular velocity takes the plain
                 // update below — the same arithmetic, (v + 0) + impulse.
                 ct::BodyState b{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
-                const bool moved = (legacyGroundSolver && withGround && rt.boxes.empty())
-                                       ? ct::SolveBodyAgainstGround(b, rt.ground, rt.shape, rt.invMass, rt.invInertiaLocal, rt.localInertia, rt.friction, force, dt)
-                                       : ct::SolveBody(b, withGround ? &rt.ground : nullptr, rt.boxes.data(), static_cast<int>(rt.boxes.size()), rt.invMass,
-                                                       rt.invInertiaLocal, rt.localInertia, rt.friction, force, dt);
+                const bool moved = ct::SolveBody(b, withGround ? &rt.ground : nullptr, rt.boxes.data(), static_cast<int>(rt.boxes.size()), rt.invMass,
+                                                 rt.invInertiaLocal, rt.friction, force, dt);
                 rt.linvel = b.linVel;
                 rt.angvel = b.angVel;
                 if (moved) { // the split impulse corrected the pose

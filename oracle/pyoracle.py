@@ -66,7 +66,6 @@ class _Lib:
         l.orc_set_friction.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
         l.orc_set_restitution.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
         l.orc_set_static_contacts.argtypes = [C.c_void_p, C.c_int]
-        l.orc_set_legacy_ground_solver.argtypes = [C.c_void_p, C.c_int]
         l.orc_get_box_contacts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         l.orc_get_box_contacts.restype = C.c_int
         l.orc_get_ground_contacts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
@@ -321,9 +320,6 @@ class RefScene:
     def SetStaticContacts(self, enabled=True):
         """Dynamic boxes collide with the Static / Kinematic box colliders of the scene (Bullet's btBoxBoxCollisionAlgorithm)."""
         lib().orc_set_static_contacts(self.h, int(enabled))
-
-    def SetLegacyGroundSolver(self, enabled=True):
-        lib().orc_set_legacy_ground_solver(self.h, int(enabled))
 
     def BoxContacts(self, eid):
         """[(other entity id, rows)]: rows[j] = localA.xyz, localB.xyz, normalWorldOnB.xyz, distance, appliedImpulse,

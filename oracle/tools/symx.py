@@ -68,10 +68,15 @@ class Machine:
         m = re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+)\)", op)
         if not m:
             # base + index: modelled when one of the two holds the integer 0 (a pool base folded into the other's symbolic pointer)
-            mi = re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+),(%\w+),1\)", op)
+            mi = re.fullmatch(r"(-?0x[0-9a-f]+|)\((%\w+),(%\w+),(\d)\)", op)
             if not mi:
                 raise Unmodelled(f"addressing {op}")
             a, b = self.gpr.get(mi.group(2)), self.gpr.get(mi.group(3))
+            if isinstance(b, tuple) and b[0] == "int" and isinstance(a, tuple) and a[0] == "ptr":   # a known integer index
+                d0 = int(mi.group(1), 16) if mi.group(1) else 0
+                return (a[1], a[2] + d0 + b[1] * int(mi.group(4)))
+            if mi.group(4) != "1":
+                raise Unmodelled(f"addressing {op}: {a}, {b}")
             if b == ("int", 0):
                 return self.addr(f"{mi.group(1)}({mi.group(2)})", pc_next)
             if a == ("int", 0):
@@ -147,10 +152,28 @@ class Machine:
             self.step(pc, mn, p, ops, pc_next)
             i += 1
 
+    def call_function(self, va):
+        """A direct call into code that is executed with the same state: the callee's instructions run on this machine's registers
+        and memory (its frame lies below the caller's in the one stack space), then the caller continues."""
+        saved = (self.ins, self.index)
+        sp = self.gpr["%rsp"]
+        self.gpr["%rsp"] = ("ptr", "stk", sp[2] - 8)
+        self.ins = function_listing(self.pe, va, 0x3000)
+        self.index = {pc: i for i, (pc, _, _) in enumerate(self.ins)}
+        self.depth = getattr(self, "depth", 0) + 1
+        if self.depth > 6:
+            raise Unmodelled("call depth")
+        self.run()
+        self.depth -= 1
+        self.ins, self.index = saved
+        self.gpr["%rsp"] = sp
+
     def step(self, pc, mn, p, ops, pc_next):
         g = self.gpr
         if mn in ("nop", "nopw", "nopl", "xchg", "data16", "cltq", "cdqe") or mn.startswith("nop"):
             return
+        if mn == "rex" and ops.startswith("push"):
+            mn, p = "push", split_ops(ops.split(None, 1)[1])
         if mn == "push":
             sp = g["%rsp"]
             g["%rsp"] = ("ptr", "stk", sp[2] - 8)
@@ -169,8 +192,11 @@ class Machine:
             self.last_flags = (pc, mn, ops)
             return                       # (integer flags: the decisions say which way the jump goes)
         if mn == "lea":
-            a = self.addr(p[0], pc_next)
-            g[self.reg64(p[1])] = ("ptr", a[0], a[1])
+            try:
+                a = self.addr(p[0], pc_next)
+                g[self.reg64(p[1])] = ("ptr", a[0], a[1])
+            except Unmodelled:
+                g[self.reg64(p[1])] = None          # (integer arithmetic through lea)
             return
         if mn in ("mov", "movl", "movq", "movslq", "movzbl", "movzwl", "movabs") and not any(x.startswith("%xmm") for x in p):
             src, dst = p
@@ -222,6 +248,19 @@ class Machine:
         if mn in ("xor",) and len(p) == 2 and p[0] == p[1]:
             g[self.reg64(p[0])] = ("int", 0)
             return
+        if mn in ("incl", "decl", "incq", "decq", "addl", "subl", "addq", "subq", "andl", "orl") and not p[-1].startswith("%"):
+            a = self.addr(p[-1], pc_next)
+            self.mem[a] = ("opaque", f"int@{pc:#x}")
+            return
+        if mn.startswith("cmov") and len(p) == 2 and p[1].startswith("%") and self.decider is not None:
+            d = self.decisions.get(pc)
+            if d is None:
+                d = self.decider(self, pc, mn, self.last_flags)
+            if d is not None:
+                self.decisions[pc] = d
+                if d:
+                    g[self.reg64(p[1])] = g.get(self.reg64(p[0])) if p[0].startswith("%") else self.memp.get(self.addr(p[0], pc_next))
+                return
         if mn in ("shl", "shr", "sar", "add", "sub", "and", "or", "inc", "dec", "imul", "neg", "not", "xor", "setne", "sete", "seta", "setb", "setbe", "setae",
                   "cmovne", "cmove", "cmova", "cmovb", "cmovbe", "cmovae", "cmovg", "cmovl", "cmovge", "cmovle", "movsbl", "movswl") \
                 and not any(x.startswith("%xmm") for x in p):
@@ -231,6 +270,14 @@ class Machine:
         if mn == "call":
             if ops in self.hooks:
                 self.hooks[ops](self)
+                return
+            if re.fullmatch(r"0x[0-9a-f]+", ops):
+                from check_bullet_order import _resolve
+                target = _resolve(self.pe, int(ops, 16))
+                if target in self.hooks:
+                    self.hooks[target](self)
+                    return
+                self.call_function(target)
                 return
             raise Unmodelled(f"call {ops} at {pc:#x}")
         # ---------------------------------------------------------------- SSE
@@ -344,3 +391,22 @@ def show(t, names=None, leaf=None):
         return f"{op}({show(t[1], names, leaf)}, {show(t[2], names, leaf)})"
     sym = {"add": " + ", "sub": " - ", "mul": "*", "div": " / "}[op]
     return "(" + show(t[1], names, leaf) + sym + show(t[2], names, leaf) + ")"
+
+
+def norm2(t):
+    """check_bx_order.norm, then a + (-b) -> a - b and a - (-b) -> a + b (exact identities in IEEE-754), re-normalised."""
+    from check_bx_order import norm
+
+    def fix(e):
+        if not isinstance(e, tuple) or e[0] in ("in", "const", "opaque"):
+            return e
+        e = (e[0],) + tuple(fix(x) if isinstance(x, tuple) else x for x in e[1:])
+        if e[0] == "add":
+            if e[2][0] == "neg":
+                return ("sub", e[1], e[2][1])
+            if e[1][0] == "neg":
+                return ("sub", e[2], e[1][1])
+        if e[0] == "sub" and e[2][0] == "neg":
+            return ("add", e[1], e[2][1])
+        return e
+    return norm(fix(norm(t)))

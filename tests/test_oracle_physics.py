@@ -491,54 +491,3 @@ def test_a_box_leans_on_a_wall_and_the_floor_at_once_and_a_moved_wall_lets_go():
     ref.PhysicsSystemUpdate(1 / 120)
     ref.TransformSystemUpdate()
     assert [o for o, _ in ref.BoxContacts(box)] == [ground]
-
-
-def test_general_solver_without_boxes_is_the_ground_solver_bit_for_bit():
-    """ct::SolveBody with no box manifold must be ct::SolveBodyAgainstGround operation for operation: the plane scenes of round 2
-    (and the GPU's plane kernel, which is checked against them) went through the old function.  1,000 boxes and capsules of mixed
-    size, mass, friction and orientation dropped on the plane, two oracles in lockstep — one through each function — every pose,
-    velocity and contact point compared bit for bit every tenth tick while they land, tumble, rest and fall asleep."""
-    n = 1000
-    rng = np.random.default_rng(5)
-    wl = synth.Workload("ground", synth.FLAT, n, 77)
-    wl.pos[:, 0] = rng.uniform(-40, 40, n).astype(np.float32)
-    wl.pos[:, 2] = rng.uniform(-40, 40, n).astype(np.float32)
-    wl.pos[:, 1] = rng.uniform(0.2, 2.0, n).astype(np.float32)
-    wl.body_type[:] = 1
-    shape = rng.choice([0, 0, 1], n).astype(np.uint8)
-    size = rng.uniform(0.15, 0.9, (n, 3)).astype(np.float32)
-    mass = rng.choice([0.3, 1.0, 40.0], n).astype(np.float32)
-    refs = []
-    for legacy in (False, True):
-        ref = build_oracle(wl, shape=shape, size=size, mass=mass)
-        for i in range(n):
-            ref.SetFriction(i + 1, float(rng.choice([0.05, 0.5, 3.0])) if not legacy else refs[0]._fr[i])
-        if not legacy:
-            ref._fr = [0.0] * n
-        ref.SetGroundPlane(True)
-        ref.SetLegacyGroundSolver(legacy)
-        refs.append(ref)
-    # (same frictions in both: set them again from one draw)
-    fr = np.random.default_rng(6).choice([0.05, 0.5, 3.0], n)
-    refs = []
-    for legacy in (False, True):
-        ref = build_oracle(wl, shape=shape, size=size, mass=mass)
-        for i in range(n):
-            ref.SetFriction(i + 1, float(fr[i]))
-        ref.SetGroundPlane(True)
-        ref.SetLegacyGroundSolver(legacy)
-        refs.append(ref)
-    for tick in range(420):
-        for ref in refs:
-            ref.PhysicsSystemUpdate(1 / 120)
-            ref.TransformSystemUpdate()
-        if tick % 10:
-            continue
-        a, b = refs[0].bulk_bodies(), refs[1].bulk_bodies()
-        for key in ("origin", "quat", "linvel", "angvel"):
-            assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), (tick, key)
-        for e in range(1, n + 1, 9):
-            (na, pa), (nb, pb) = refs[0].GroundContacts(e), refs[1].GroundContacts(e)
-            assert na == nb and np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), (tick, e)
-    st, _ = refs[0].bulk_activation()
-    assert (st == 2).sum() > 0.5 * n
