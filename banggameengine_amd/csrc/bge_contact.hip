@@ -77,7 +77,8 @@ __device__ __forceinline__ F3 ct_local_inertia(const CtShape& s, float mass)
         return F3{scaledmass * (y2 + z2), scaledmass * (x2 + z2), scaledmass * (x2 + y2)};
     }
     const float lx = 2.0f * s.dims.x, ly = 2.0f * s.dims.y, lz = 2.0f * s.dims.z;
-    return F3{mass / 12.0f * (ly * ly + lz * lz), mass / 12.0f * (lx * lx + lz * lz), mass / 12.0f * (lx * lx + ly * ly)};
+    const float m12 = mass * 0.0833333358168602f; // (mass / 12 as the reference's compiled code has it: times 0x3daaaaab)
+    return F3{m12 * (ly * ly + lz * lz), m12 * (lx * lx + lz * lz), m12 * (lx * lx + ly * ly)};
 }
 __device__ __forceinline__ F3 ct_inv_inertia_local(const F3& i)
 {

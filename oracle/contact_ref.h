@@ -133,7 +133,9 @@ inline Vec3 LocalInertia(const Shape& s, float mass)
         return V(scaledmass * (y2 + z2), scaledmass * (x2 + z2), scaledmass * (x2 + y2));
     }
     const float lx = 2.0f * s.dims.x, ly = 2.0f * s.dims.y, lz = 2.0f * s.dims.z;
-    return V(mass / 12.0f * (ly * ly + lz * lz), mass / 12.0f * (lx * lx + lz * lz), mass / 12.0f * (lx * lx + ly * ly));
+    // (mass / 12 in the source; the reference's compiled code — MSVC /fp:fast — multiplies by the constant 0x3daaaaab instead)
+    const float m12 = mass * 0.0833333358168602f;
+    return V(m12 * (ly * ly + lz * lz), m12 * (lx * lx + lz * lz), m12 * (lx * lx + ly * ly));
 }
 
 // btRigidBody::setMassProps: m_invInertiaLocal

@@ -628,6 +628,57 @@ def check_inertia(pe, all_ins):
     return False
 
 
+
+def shape_vtable(pe, ctor_prefix):
+    import check_bullet_order as cb
+    _, code, rel = cb.coff_section(cb.OBJ, "?CreateShape@PhysicsSystem@@AEBA")
+    sites = sorted(off for off, name in rel.items() if name.startswith(ctor_prefix))
+    targets = set()
+    for off in sites:
+        pat = code[off - 13: off]
+        for mm in re.finditer(re.escape(pat), pe.b):
+            targets.add(pe.call_target(mm.start() + 12))
+    ins = cb._disasm(pe, pe.base + targets.pop())
+    lea = [x[0] for x in ins if x[1] == "lea" and "(%rip)" in x[2]][-1]
+    vt = lea + 7 + struct.unpack("<i", pe.bytes_at_va(lea, 7)[3:])[0]
+    return [cb._resolve(pe, struct.unpack("<Q", pe.bytes_at_va(vt + 8 * k, 8))[0]) for k in range(20)]
+
+
+def check_local_inertia(pe):
+    """calculateLocalInertia (vtable slot 7) of btBoxShape and btCapsuleShape.  The box's `mass / 12` is compiled as a product with
+    0x3daaaaab (MSVC /fp:fast); the capsule's source already multiplies by the literal 0.08333333 (0x3daaaaaa)."""
+    ok = True
+    box, caps = shape_vtable(pe, "??0btBoxShape@@"), shape_vtable(pe, "??0btCapsuleShape@@")
+    for name, slots in (("btBoxShape", box), ("btCapsuleShape", caps)):
+        ins = function_listing(pe, slots[7], 0x400)
+        if name == "btCapsuleShape":
+            # m_upAxis is 1 (the constructor stores it: check_bullet_order.py): (upAxis + 2) % 3 = 0 through the 0x55555556 multiply
+            k = next(i for i, (pc, mn, ops) in enumerate(ins) if mn == "movslq" and ops == "%r9d,%rax")
+            hooks = {ins[k + 1][0]: lambda m: m.gpr.__setitem__("%rax", ("int", 0))}
+        else:
+            hooks = {}
+        m = Machine(pe, ins, gpr={"%rcx": P("shape"), "%r8": P("out")}, ptr_loads={("shape", 0): P("vt"), ("shape", 0x50): ("int", 1)},
+                    hooks={"*0x58(%rax)": lambda m, f=slots[11]: m.call_function(f), COOKIE: lambda m: None}, pc_hooks=hooks)
+        m.xmm["%xmm1"] = [("in", "mass", 0)] + [("const", 0.0)] * 3
+        m.decider = lambda m, pc, mn, lf: None
+        m.run()
+        mass = I("mass", 0)
+        if name == "btBoxShape":
+            h = [I("shape", 0x30 + 4 * k) + I("shape", 0x40) for k in range(3)]       # getHalfExtentsWithMargin
+            l = [x + x for x in h]                                                      # 2 * h, compiled as h + h: the same float
+            m12 = mass * C(struct.unpack("<f", struct.pack("<I", 0x3DAAAAAB))[0])
+            want = [m12 * (l[1] * l[1] + l[2] * l[2]), m12 * (l[0] * l[0] + l[2] * l[2]), m12 * (l[0] * l[0] + l[1] * l[1])]
+        else:
+            r, hh = I("shape", 0x30), I("shape", 0x34)
+            h = [r, r + hh, r]
+            l = [x * 2.0 for x in h]
+            sm = mass * C(struct.unpack("<f", struct.pack("<I", 0x3DAAAAAA))[0])
+            x2, y2, z2 = [x * x for x in l]
+            want = [sm * (y2 + z2), sm * (x2 + z2), sm * (x2 + y2)]
+        ok &= report(f"{name}::calculateLocalInertia at VA {slots[7]:#x}", [(f"inertia.{c}", m.mem.get(("out", 4 * k), ("missing",)), w) for k, (c, w) in enumerate(zip("xyz", want))])
+    return ok
+
+
 def capsule_vtable(pe):
     import check_bullet_order as cb
     _, code, rel = cb.coff_section(cb.OBJ, "?CreateShape@PhysicsSystem@@AEBA")
@@ -852,6 +903,7 @@ def main():
         ok &= check_manifold(pe, refresh_va, sort_va, cache_va)
         ok &= check_add_contact_point(pe, add_cp, cache_va)
     ok &= check_inertia(pe, all_ins)
+    ok &= check_local_inertia(pe)
     ok &= check_capsule_support(pe)
     ok &= check_convex_plane(pe)
     print("RESULT: " + ("setup rows, gyroscopic term, manifold refresh / sort / cache and the plane contact are compiled as restated" if ok else "MISMATCH"))
