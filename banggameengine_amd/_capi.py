@@ -82,6 +82,8 @@ SYMBOLS = {
     "bge_world_trigger_events": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "bge_world_trigger_active": (C.c_int, [_vp, _u64, _vp, _vp]),
     "bge_world_trigger_query_stats": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
+    "bge_world_set_trigger_stay_events": (C.c_int, [_vp, C.c_int]),
+    "bge_world_trigger_diff_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bge_world_pack_roots": (C.c_int, [_vp, _vp]),
     "bge_world_device_array": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "bge_world_get_info": (C.c_int, [_vp, C.POINTER(WorldInfo)]),

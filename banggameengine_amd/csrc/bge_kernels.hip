@@ -950,15 +950,17 @@ __global__ void __launch_bounds__(256) k_trigger_pairs(uint64_t n_slots, uint32_
 }
 
 // every ghost against every other ghost: both are registered collision objects, so the pair cache lists each in the other
-// (btGhostPairCallback::addOverlappingPair serves both proxies).  One thread per ghost i, the j boxes pass through LDS in
-// tiles of 256; a hit is (i | kGhostHit, j) — trigger INDICES, the host maps j to its entity and knows whether j is still
-// in the world when i is processed (a one-shot ghost that fired earlier in ProcessTriggerEvents' loop is not).  An inactive
-// ghost carries an empty box and overlaps nothing.  n_triggers^2 / 2 box tests x 2: thousands of ghosts are microseconds.
+// (btGhostPairCallback::addOverlappingPair serves both proxies).  Workgroup (x, y): the 256 ghosts i of tile x, one per thread,
+// against the 64 ghosts j of tile y, which pass through LDS (one thread per i looping over ALL j took 352 us at 1000 ghosts: four
+// workgroups, a thousand dependent trips each); a hit is (i | kGhostHit, j) — trigger INDICES, the host maps j to its entity and
+// knows whether j is still in the world when i is processed (a one-shot ghost that fired earlier in ProcessTriggerEvents' loop is
+// not).  An inactive ghost carries an empty box and overlaps nothing.
+constexpr uint32_t kGhostTileJ = 64;
 __global__ void __launch_bounds__(256) k_trigger_ghost_pairs(uint32_t n_triggers, TriggerView t, uint32_t* __restrict__ count,
                                                              uint2* __restrict__ out, uint32_t cap)
 {
-    __shared__ float s_box[256][6];
-    __shared__ uint32_t s_group[256], s_mask[256];
+    __shared__ float s_box[kGhostTileJ][6];
+    __shared__ uint32_t s_group[kGhostTileJ], s_mask[kGhostTileJ];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -969,34 +971,32 @@ __global__ void __launch_bounds__(256) k_trigger_ghost_pairs(uint32_t n_triggers
         grp = t.group[i];
         msk = t.mask[i];
     }
-    for (uint32_t j0 = 0; j0 < n_triggers; j0 += 256u) { // uniform trip count: the ballots need every lane
-        __syncthreads();
-        const uint32_t jl = j0 + threadIdx.x;
-        if (jl < n_triggers) {
+    const uint32_t j0 = blockIdx.y * kGhostTileJ;
+    const uint32_t jl = j0 + threadIdx.x;
+    if (threadIdx.x < kGhostTileJ && jl < n_triggers) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a) s_box[threadIdx.x][a] = t.aabb[6ull * jl + a];
-            s_group[threadIdx.x] = t.group[jl];
-            s_mask[threadIdx.x] = t.mask[jl];
+        for (int a = 0; a < 6; ++a) s_box[threadIdx.x][a] = t.aabb[6ull * jl + a];
+        s_group[threadIdx.x] = t.group[jl];
+        s_mask[threadIdx.x] = t.mask[jl];
+    }
+    __syncthreads();
+    const uint32_t nj = min(kGhostTileJ, n_triggers - j0); // (uniform trip count: the ballots need every lane)
+    for (uint32_t k = 0; k < nj; ++k) {
+        const uint32_t j = j0 + k;
+        bool hit = i < n_triggers && j != i && (grp & s_mask[k]) != 0u && (s_group[k] & msk) != 0u;
+        if (hit) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) hit = hit && b[a] <= s_box[k][3 + a] && b[3 + a] >= s_box[k][a];
         }
-        __syncthreads();
-        const uint32_t nj = min(256u, n_triggers - j0);
-        for (uint32_t k = 0; k < nj; ++k) {
-            const uint32_t j = j0 + k;
-            bool hit = i < n_triggers && j != i && (grp & s_mask[k]) != 0u && (s_group[k] & msk) != 0u;
-            if (hit) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) hit = hit && b[a] <= s_box[k][3 + a] && b[3 + a] >= s_box[k][a];
-            }
-            const unsigned long long m = __ballot(hit);
-            if (m == 0) continue;
-            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(count, static_cast<uint32_t>(__popcll(m)));
-            base = __shfl(base, static_cast<int>(leader), 64);
-            if (hit) {
-                const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-                if (at < cap) out[at] = make_uint2(i | kGhostHit, j);
-            }
+        const unsigned long long m = __ballot(hit);
+        if (m == 0) continue;
+        const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(count, static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, static_cast<int>(leader), 64);
+        if (hit) {
+            const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+            if (at < cap) out[at] = make_uint2(i | kGhostHit, j);
         }
     }
 }
@@ -1119,12 +1119,128 @@ hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n
     return hipGetLastError();
 }
 
+// ---- trigger overlap diff (bge_kernels.hpp TriggerDiff)
+namespace {
+constexpr uint32_t kTrigProbeLimit = 4096;
+
+__device__ __forceinline__ uint32_t trig_hash(uint64_t key, uint32_t log2_cap)
+{
+    return static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ull) >> (64u - log2_cap));
+}
+
+// 0 = was there already, 1 = inserted, 2 = no room within the probe limit
+__device__ __forceinline__ int trig_insert(uint64_t* table, uint32_t log2_cap, uint64_t key)
+{
+    const uint32_t mask = (1u << log2_cap) - 1u;
+    uint32_t h = trig_hash(key, log2_cap);
+    for (uint32_t probe = 0; probe < kTrigProbeLimit; ++probe) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(table + h), static_cast<unsigned long long>(kTrigKeyEmpty),
+                                                 static_cast<unsigned long long>(key));
+        if (old == kTrigKeyEmpty) return 1;
+        if (old == key) return 0;
+        h = (h + 1u) & mask;
+    }
+    return 2;
+}
+
+__device__ __forceinline__ bool trig_contains(const uint64_t* table, uint32_t log2_cap, uint64_t key)
+{
+    const uint32_t mask = (1u << log2_cap) - 1u;
+    uint32_t h = trig_hash(key, log2_cap);
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const uint64_t k = table[h];
+        if (k == key) return true;
+        if (k == kTrigKeyEmpty) return false;
+        h = (h + 1u) & mask;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void trig_append(const TriggerDiff& d, bool mine, uint64_t record)
+{
+    const unsigned long long m = __ballot(mine);
+    if (m == 0ull) return;
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    uint32_t base = 0;
+    if (lane == __ffsll(static_cast<long long>(m)) - 1) base = atomicAdd(d.header + 0, static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1);
+    if (mine) {
+        const uint32_t at = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+        if (at < d.delta_cap) d.deltas[at] = record;
+    }
+}
+
+// this tick's hits into the current table; the ones last tick's table does not hold are Enters
+__global__ void __launch_bounds__(256) k_trigger_diff_cur(TriggerDiff d)
+{
+    const uint32_t hits = d.count[0];
+    const uint32_t n = hits < d.pair_cap ? hits : d.pair_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.header[3] = hits;
+        d.header[4] = d.count[1];
+        d.header[5] = d.count[2];
+    }
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1u) / stride; // every lane of a wave makes the same number of trips (ballots inside)
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t k = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool fresh = false, enter = false;
+        uint64_t key = 0;
+        if (k < n) {
+            const uint2 hit = d.pairs[k];
+            key = (static_cast<uint64_t>(hit.x & ~kGhostHit) << 33) | ((hit.x & kGhostHit) ? (1ull << 32) : 0ull) | hit.y;
+            const int how = trig_insert(d.cur, d.log2_cap, key);
+            if (how == 2) d.header[2] = 1u;
+            fresh = how == 1;
+            enter = fresh && !trig_contains(d.prev, d.log2_cap, key);
+        }
+        const unsigned long long f = __ballot(fresh);
+        if ((threadIdx.x & 63u) == 0u && f) atomicAdd(d.header + 1, static_cast<uint32_t>(__popcll(f)));
+        trig_append(d, enter, key);
+    }
+}
+
+// last tick's keys that this tick's table does not hold are Exits
+__global__ void __launch_bounds__(256) k_trigger_diff_prev(TriggerDiff d)
+{
+    const uint32_t cap = 1u << d.log2_cap;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = 0; base < cap; base += stride) {
+        const uint32_t slot = base + blockIdx.x * blockDim.x + threadIdx.x;
+        uint64_t key = kTrigKeyEmpty;
+        if (slot < cap) key = d.prev[slot];
+        const bool gone = key != kTrigKeyEmpty && !trig_contains(d.cur, d.log2_cap, key);
+        trig_append(d, gone, key | kTrigKeyExit);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_trigger_table_build(uint64_t* table, uint32_t log2_cap, const uint64_t* keys, uint32_t n, uint32_t* header)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && trig_insert(table, log2_cap, keys[k]) == 2) header[2] = 1u;
+}
+} // namespace
+
+hipError_t launch_trigger_diff(hipStream_t stream, const TriggerDiff& d)
+{
+    hipLaunchKernelGGL(k_trigger_diff_cur, dim3(256), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(k_trigger_diff_prev, dim3(256), dim3(256), 0, stream, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_trigger_table_build(hipStream_t stream, uint64_t* table, uint32_t log2_cap, const uint64_t* keys, uint32_t n, uint32_t* header)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trigger_table_build, grid_for(n, 256), dim3(256), 0, stream, table, log2_cap, keys, n, header);
+    return hipGetLastError();
+}
+
 hipError_t launch_trigger_ghost_pairs(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, uint32_t* count, void* out_pairs,
                                       uint32_t cap)
 {
     if (n_triggers < 2) return hipSuccess;
-    hipLaunchKernelGGL(k_trigger_ghost_pairs, grid_for(n_triggers, 256), dim3(256), 0, stream, n_triggers, t, count,
-                       static_cast<uint2*>(out_pairs), cap);
+    hipLaunchKernelGGL(k_trigger_ghost_pairs, dim3((n_triggers + 255u) / 256u, (n_triggers + kGhostTileJ - 1u) / kGhostTileJ), dim3(256), 0, stream,
+                       n_triggers, t, count, static_cast<uint2*>(out_pairs), cap);
     return hipGetLastError();
 }
 

@@ -165,6 +165,29 @@ hipError_t launch_trigger_pairs(hipStream_t stream, uint64_t n_slots, uint32_t n
 constexpr uint32_t kGhostHit = 0x80000000u;
 hipError_t launch_trigger_ghost_pairs(hipStream_t stream, uint32_t n_triggers, const TriggerView& t, uint32_t* count, void* out_pairs,
                                       uint32_t cap);
+
+// ---- Enter / Exit of the trigger overlaps on the device.  The hit list of a tick is turned into keys
+//   (trigger index << 33) | (kGhostHit ? 1 << 32 : 0) | (body entity or other trigger's index)
+// and put into an open-addressing table; a key that is not in LAST tick's table is an Enter, a key of last tick's table that is
+// not in this one an Exit.  Only those — as keys, Exit marked by bit 63 — and five counters travel to the host, which owns the
+// overlap sets (bge_world.cpp apply_trigger_deltas) and rebuilds the mirror table whenever it changed them itself.
+constexpr uint64_t kTrigKeyEmpty = ~0ull;
+constexpr uint64_t kTrigKeyExit = 1ull << 63;
+struct TriggerDiff {
+    uint64_t* cur;        // [1 << log2_cap] filled with kTrigKeyEmpty before the launch
+    uint64_t* prev;       // last tick's table
+    uint32_t log2_cap;
+    uint32_t* header;     // [0] deltas appended, [1] distinct keys this tick, [2] a table overflowed, [3] hits, [4] [5] query counters
+    uint64_t* deltas;     // behind the header in one buffer, so that one copy fetches both
+    uint32_t delta_cap;
+    const uint2* pairs;
+    const uint32_t* count; // the hit list's counters ([0] hits, [1] [2] how the ghosts were split)
+    uint32_t pair_cap;
+};
+hipError_t launch_trigger_diff(hipStream_t stream, const TriggerDiff& d);
+// inserts `n` keys into a table (mirror rebuild from the host's sets); header[2] reports an overflow
+hipError_t launch_trigger_table_build(hipStream_t stream, uint64_t* table, uint32_t log2_cap, const uint64_t* keys, uint32_t n, uint32_t* header);
+
 // compact: 12 floats per root (4x3, the constant fourth column dropped) instead of 16
 hipError_t launch_pack_roots(hipStream_t stream, uint64_t n_roots, const uint32_t* root_slots, const float* world, float* dst,
                              bool compact = false);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -252,6 +253,23 @@ struct bge_world {
     bool trig_list_on_device = false; // the device arrays are indexed like `triggers` (false between an upload of the list and the next sync)
     DevBuf trig_slot, trig_entity, trig_he, trig_group, trig_mask, trig_active, trig_aabb, trig_pairs, trig_count, trig_lists;
     uint32_t trigger_grid_min = 64;       // more ghosts than this: the broadphase grid answers for the small ones
+    // Enter / Exit taken on the device (bge_kernels.hpp TriggerDiff): two key tables (this tick's, last tick's), header + deltas in
+    // one device buffer with a page-locked copy.  The overlap sets above stay the truth; `trig_mirror_valid` says that last tick's
+    // table holds exactly them — it is rebuilt from them after every tick that went the long way or changed them on the host.
+    DevBuf trig_tab[2], trig_delta_dev, trig_keys_dev;
+    uint32_t trig_tab_log2 = 0;
+    void* trig_delta_host = nullptr;      // hipHostMalloc
+    bool trig_mirror_valid = false;
+    bool trig_device_diff = true;         // BGE_TRIGGER_DEVICE_DIFF=0 keeps every tick on the host's path (A/B, tests)
+    bool trig_stay_events = true;         // bge_world_set_trigger_stay_events
+    uint64_t trig_stay_suppressed = 0;    // Stay events not materialised since the last bge_world_trigger_events
+    uint64_t trig_fast_ticks = 0, trig_slow_ticks = 0;
+    double trig_wait_ms = 0.0, trig_apply_ms = 0.0; // BGE_TRIGGER_PROFILE=1: time until the deltas are on the host / spent applying them
+    uint64_t trig_deltas_seen = 0;
+    std::vector<uint64_t> trig_keys_host;
+    std::vector<uint32_t> trig_exits, trig_touched;
+    std::vector<uint8_t> trig_was;
+    uint64_t trig_total_overlaps = 0;     // sum of the sets' sizes over the volumes in the world (kept by the short way, recounted by the long one)
     uint32_t trig_through_grid = 0, trig_against_all = 0; // how the last tick split them
     bge::TriggerView trigger_view() const
     {
@@ -325,9 +343,12 @@ struct bge_world {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
                           &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &crestitution, &bmanifold, &obstacle_slots, &obstacle_gen, &obstacles, &box_list, &box_count, &frozen, &trig_slot, &trig_entity, &trig_he, &trig_group,
-                          &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists, &ground_list, &ground_count}) {
+                          &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists, &ground_list, &ground_count, &trig_tab[0], &trig_tab[1],
+                          &trig_delta_dev, &trig_keys_dev}) {
             b->release();
         }
+        if (trig_delta_host) (void)hipHostFree(trig_delta_host);
+        trig_delta_host = nullptr;
         broadphase.release();
         slab_broadphase.release();
         router.release();
@@ -499,6 +520,7 @@ void ensure_triggers(bge_world* w)
             t.posed = false;
             t.clear_overlaps();
             w->triggers_device_stale = true;
+            w->trig_mirror_valid = false;
         }
     }
 }
@@ -525,6 +547,10 @@ void diff_and_commit_trigger(bge_world* w, bge_world::Trigger& t, std::vector<ui
     for (uint32_t other : cur) {
         while (at < prev.size() && prev[at] < other) ++at;
         const bool was = at < prev.size() && prev[at] == other;
+        if (was && !w->trig_stay_events) {
+            ++w->trig_stay_suppressed;
+            continue;
+        }
         w->trigger_events.push_back(bge_trigger_event{was ? 1u : 0u, t.entity, other});
     }
     at = 0;
@@ -587,11 +613,192 @@ int process_trigger_pairs(bge_world* w)
     return BGE_OK;
 }
 
+// ---- the short way: Enter / Exit come from the device (bge_kernels.hpp TriggerDiff), the sets are updated by them
+constexpr uint32_t kTrigDeltaCap = 1u << 16;       // deltas fetched with the header in one copy; more than that in a tick: the long way
+constexpr uint32_t kTrigHeaderWords = 8;
+
+inline void sorted_insert(std::vector<uint32_t>& v, uint32_t e)
+{
+    auto it = std::lower_bound(v.begin(), v.end(), e);
+    if (it == v.end() || *it != e) v.insert(it, e);
+}
+inline void sorted_erase(std::vector<uint32_t>& v, uint32_t e)
+{
+    auto it = std::lower_bound(v.begin(), v.end(), e);
+    if (it != v.end() && *it == e) v.erase(it);
+}
+inline bool sorted_has(const std::vector<uint32_t>& v, uint32_t e) { return std::binary_search(v.begin(), v.end(), e); }
+
+// (Re)build last tick's table from the host's sets: after a tick on the long way, an upload of the trigger list, a (de)activation
+int rebuild_trigger_mirror(bge_world* w)
+{
+    std::vector<uint64_t>& keys = w->trig_keys_host;
+    keys.clear();
+    w->trig_total_overlaps = 0;
+    for (size_t i = 0; i < w->triggers.size(); ++i) {
+        const bge_world::Trigger& t = w->triggers[i];
+        if (!t.runtime_active) continue;
+        w->trig_total_overlaps += t.overlaps.size();
+        for (uint32_t e : t.overlap_bodies) keys.push_back((static_cast<uint64_t>(i) << 33) | e);
+        for (uint32_t e : t.overlap_ghosts) {
+            auto it = w->trig_index_of_entity.find(e);
+            if (it != w->trig_index_of_entity.end()) keys.push_back((static_cast<uint64_t>(i) << 33) | (1ull << 32) | it->second);
+        }
+    }
+    uint32_t log2 = 12;
+    while ((1ull << log2) < 4 * std::max<uint64_t>(keys.size(), w->trig_pairs_host.size() / 2)) ++log2;
+    if (log2 > 26) return fail(BGE_ERR_OOM, "%llu remembered trigger overlaps", (unsigned long long)keys.size());
+    if (log2 > w->trig_tab_log2) w->trig_tab_log2 = log2;
+    const size_t bytes = sizeof(uint64_t) << w->trig_tab_log2;
+    for (DevBuf& b : w->trig_tab) HIP_TRY(b.ensure(bytes));
+    HIP_TRY(w->trig_delta_dev.ensure(kTrigHeaderWords * 4 + static_cast<size_t>(kTrigDeltaCap) * 8));
+    if (!w->trig_delta_host) HIP_TRY(hipHostMalloc(&w->trig_delta_host, kTrigHeaderWords * 4 + static_cast<size_t>(kTrigDeltaCap) * 8, hipHostMallocDefault));
+    HIP_TRY(hipMemsetAsync(w->trig_tab[0].p, 0xff, bytes, w->stream)); // this tick's table for the next diff
+    HIP_TRY(hipMemsetAsync(w->trig_tab[1].p, 0xff, bytes, w->stream)); // last tick's
+    HIP_TRY(hipMemsetAsync(w->trig_delta_dev.p, 0, kTrigHeaderWords * 4, w->stream));
+    if (!keys.empty()) {
+        HIP_TRY(w->trig_keys_dev.ensure(keys.size() * 8));
+        HIP_TRY(hipMemcpyAsync(w->trig_keys_dev.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(bge::launch_trigger_table_build(w->stream, w->trig_tab[1].as<uint64_t>(), w->trig_tab_log2, w->trig_keys_dev.as<uint64_t>(),
+                                                static_cast<uint32_t>(keys.size()), w->trig_delta_dev.as<uint32_t>()));
+        uint32_t overflow = 0;
+        HIP_TRY(hipMemcpyAsync(&overflow, w->trig_delta_dev.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream)); // (`keys` is read by the copy above)
+        if (overflow) return fail(BGE_ERR_HIP, "trigger mirror table overflowed at %llu keys", (unsigned long long)keys.size());
+    }
+    w->trig_mirror_valid = true;
+    return BGE_OK;
+}
+
+// One tick's trigger events from the device's deltas.  Returns 1 when the tick has to go the long way after all (too many changes,
+// a table overflow), 0 when done, a negative error otherwise.
+int process_trigger_pairs_fast(bge_world* w)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    bge::TriggerDiff d{};
+    d.cur = w->trig_tab[0].as<uint64_t>();
+    d.prev = w->trig_tab[1].as<uint64_t>();
+    d.log2_cap = w->trig_tab_log2;
+    d.header = w->trig_delta_dev.as<uint32_t>();
+    d.deltas = reinterpret_cast<uint64_t*>(w->trig_delta_dev.as<uint32_t>() + kTrigHeaderWords);
+    d.delta_cap = kTrigDeltaCap;
+    d.pairs = static_cast<const uint2*>(w->trig_pairs.p);
+    d.count = w->trig_count.as<uint32_t>();
+    d.pair_cap = kTriggerPairCap;
+    HIP_TRY(hipMemsetAsync(d.header, 0, kTrigHeaderWords * 4, w->stream));
+    HIP_TRY(bge::launch_trigger_diff(w->stream, d));
+    // the header and the first 1,024 deltas in one copy; a tick with more changes fetches the rest in a second one
+    constexpr uint32_t kFirst = 1024;
+    uint32_t* host = static_cast<uint32_t*>(w->trig_delta_host);
+    HIP_TRY(hipMemcpyAsync(host, w->trig_delta_dev.p, kTrigHeaderWords * 4 + kFirst * 8, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    const uint32_t n_delta = host[0], n_pairs = host[3];
+    w->trig_against_all = host[4];
+    w->trig_through_grid = host[5];
+    if (n_pairs > kTriggerPairCap) return fail(BGE_ERR_OOM, "%u trigger overlaps in one tick exceed the buffer of %u", n_pairs, kTriggerPairCap);
+    if (host[2] || n_delta > kTrigDeltaCap || (static_cast<uint64_t>(host[1]) << 1) > (1ull << w->trig_tab_log2)) {
+        w->trig_mirror_valid = false; // (both tables are rebuilt, larger, after the long way)
+        if (w->trig_pairs_host.size() < 2 * static_cast<size_t>(n_pairs)) w->trig_pairs_host.resize(2 * static_cast<size_t>(n_pairs));
+        return 1;
+    }
+    if (n_delta > kFirst) {
+        HIP_TRY(hipMemcpyAsync(host + kTrigHeaderWords + 2 * kFirst, reinterpret_cast<const uint64_t*>(w->trig_delta_dev.as<uint32_t>() + kTrigHeaderWords) + kFirst,
+                               static_cast<size_t>(n_delta - kFirst) * 8, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    // this tick's table becomes last tick's; the other one is cleared for the next diff (in stream order, behind the kernels)
+    std::swap(w->trig_tab[0], w->trig_tab[1]);
+    HIP_TRY(hipMemsetAsync(w->trig_tab[0].p, 0xff, sizeof(uint64_t) << w->trig_tab_log2, w->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    uint64_t* deltas = reinterpret_cast<uint64_t*>(host + kTrigHeaderWords);
+    std::sort(deltas, deltas + n_delta, [](uint64_t a, uint64_t b) { return (a & ~bge::kTrigKeyExit) < (b & ~bge::kTrigKeyExit); });
+    const size_t n_trig = w->triggers.size();
+    std::vector<uint32_t>& enters = w->trig_union; // (scratch: the entities that entered the trigger at hand, ascending)
+    std::vector<uint32_t>& exits = w->trig_exits;
+    std::vector<uint32_t>& touched = w->trig_touched;
+    std::vector<uint8_t>& was = w->trig_was;
+    uint32_t at = 0;
+    uint64_t all_enters = 0;
+    // with Stay records every volume in the world is reported; without them only the volumes the deltas name are visited
+    for (size_t i = 0; i < n_trig; ++i) {
+        if (!w->trig_stay_events) {
+            if (at >= n_delta) break;
+            i = static_cast<size_t>((deltas[at] & ~bge::kTrigKeyExit) >> 33);
+            if (i >= n_trig) break;
+        }
+        bge_world::Trigger& t = w->triggers[i];
+        enters.clear();
+        exits.clear();
+        touched.clear();
+        const uint32_t first = at;
+        while (at < n_delta && ((deltas[at] & ~bge::kTrigKeyExit) >> 33) == i) ++at;
+        if (!t.runtime_active) continue; // (the device skips a ghost that is not in the world: nothing can be listed for it)
+        if (at > first) {
+            // the entities whose membership may change, and whether they are members now
+            for (uint32_t k = first; k < at; ++k) {
+                const uint64_t key = deltas[k] & ~bge::kTrigKeyExit;
+                const uint32_t other = static_cast<uint32_t>(key);
+                const bool ghost = (key >> 32) & 1ull;
+                if (ghost && other >= n_trig) continue;
+                touched.push_back(ghost ? w->triggers[other].entity : other);
+            }
+            std::sort(touched.begin(), touched.end());
+            touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+            was.resize(touched.size());
+            for (size_t k = 0; k < touched.size(); ++k) was[k] = sorted_has(t.overlaps, touched[k]);
+            for (uint32_t k = first; k < at; ++k) {
+                const bool exit = (deltas[k] & bge::kTrigKeyExit) != 0;
+                const uint64_t key = deltas[k] & ~bge::kTrigKeyExit;
+                const uint32_t other = static_cast<uint32_t>(key);
+                const bool ghost = (key >> 32) & 1ull;
+                if (ghost && other >= n_trig) continue;
+                std::vector<uint32_t>& set = ghost ? t.overlap_ghosts : t.overlap_bodies;
+                const uint32_t e = ghost ? w->triggers[other].entity : other;
+                if (exit) sorted_erase(set, e);
+                else sorted_insert(set, e);
+            }
+            for (size_t k = 0; k < touched.size(); ++k) {
+                const uint32_t e = touched[k];
+                const bool is = sorted_has(t.overlap_bodies, e) || sorted_has(t.overlap_ghosts, e); // (met both ways counts once)
+                if (is && !was[k]) {
+                    sorted_insert(t.overlaps, e);
+                    enters.push_back(e);
+                } else if (!is && was[k]) {
+                    sorted_erase(t.overlaps, e);
+                    exits.push_back(e);
+                }
+            }
+            w->trig_total_overlaps += enters.size();
+            w->trig_total_overlaps -= exits.size();
+            all_enters += enters.size();
+        }
+        // ProcessTriggerEvents' report for this trigger: Enter / Stay over the current set in ascending entity order, then Exit
+        if (w->trig_stay_events) {
+            size_t en = 0;
+            for (uint32_t e : t.overlaps) {
+                const bool entered = en < enters.size() && enters[en] == e;
+                if (entered) ++en;
+                w->trigger_events.push_back(bge_trigger_event{entered ? 0u : 1u, t.entity, e});
+            }
+        } else {
+            for (uint32_t e : enters) w->trigger_events.push_back(bge_trigger_event{0u, t.entity, e});
+        }
+        for (uint32_t e : exits) w->trigger_events.push_back(bge_trigger_event{2u, t.entity, e});
+    }
+    if (!w->trig_stay_events) w->trig_stay_suppressed += w->trig_total_overlaps - all_enters;
+    ++w->trig_fast_ticks;
+    w->trig_wait_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    w->trig_apply_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    w->trig_deltas_seen += n_delta;
+    return 0;
+}
+
 // ... and in a call that simulates nothing: no collision detection ran, every ghost's list is last call's — minus the ghosts
 // that are no longer in the world (deactivated by EnsureTrigger since, or fired as one-shot earlier in this loop); a volume
 // that was made one-shot since fires on what it remembers (PhysicsSystem.cpp:1062-1072)
 void process_triggers_without_a_step(bge_world* w)
 {
+    w->trig_mirror_valid = false; // (a ghost that left the world drops out of the others' lists here, on the host)
     std::vector<uint32_t> bodies, ghosts;
     for (bge_world::Trigger& t : w->triggers) {
         if (!t.runtime_active) continue;
@@ -686,6 +893,7 @@ try {
     if (!w) return fail(BGE_ERR_OOM, "host allocation failed");
     w->device = device;
     if (const char* e = std::getenv("BGE_TRIGGER_GRID_MIN")) w->trigger_grid_min = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+    if (const char* e = std::getenv("BGE_TRIGGER_DEVICE_DIFF")) w->trig_device_diff = std::strtoul(e, nullptr, 10) != 0;
     DeviceGuard guard(device);
     if (desc && desc->stream) {
         w->stream = static_cast<hipStream_t>(desc->stream);
@@ -708,6 +916,10 @@ void bge_world_destroy(bge_world* w)
     if (!w) return;
     DeviceGuard guard(w->device);
     (void)hipStreamSynchronize(w->stream);
+    if (w->trig_fast_ticks && std::getenv("BGE_TRIGGER_PROFILE"))
+        std::fprintf(stderr, "[bge] trigger diff on the device: %llu ticks, %.3f ms per tick until the deltas were on the host, %.3f ms applying %.0f of them\n",
+                     (unsigned long long)w->trig_fast_ticks, w->trig_wait_ms / w->trig_fast_ticks, w->trig_apply_ms / w->trig_fast_ticks,
+                     double(w->trig_deltas_seen) / w->trig_fast_ticks);
     w->release_all();
     if (w->own_stream) (void)hipStreamDestroy(w->stream);
     delete w;
@@ -1509,7 +1721,26 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
                                                   big_list ? w->trig_count.as<uint32_t>() + 1 : nullptr));
                 HIP_TRY(bge::launch_trigger_ghost_pairs(w->stream, n_trig, w->trigger_view(), w->trig_count.as<uint32_t>(), w->trig_pairs.p,
                                                         kTriggerPairCap));
-                if (int rc2 = process_trigger_pairs(w)) return rc2;
+                // The short way needs last tick's table to hold exactly the host's sets and no one-shot volume in the world (one that
+                // fires leaves the world in the middle of ProcessTriggerEvents' loop and takes itself out of the later ghosts' lists:
+                // that order dependence stays on the host)
+                bool short_way = w->trig_device_diff && w->trig_mirror_valid;
+                for (const bge_world::Trigger& t : w->triggers) short_way = short_way && !(t.one_shot && t.runtime_active);
+                int how = 1;
+                if (short_way) {
+                    how = process_trigger_pairs_fast(w);
+                    if (how < 0) return how;
+                }
+                if (how == 1) {
+                    if (int rc2 = process_trigger_pairs(w)) return rc2;
+                    ++w->trig_slow_ticks;
+                    w->trig_mirror_valid = false;
+                    bool one_shot = false;
+                    for (const bge_world::Trigger& t : w->triggers) one_shot = one_shot || (t.one_shot && t.runtime_active);
+                    if (w->trig_device_diff && !one_shot) {
+                        if (int rc2 = rebuild_trigger_mirror(w)) return rc2;
+                    }
+                }
             }
         }
         w->maybe_dirty = phys && !xform;
@@ -2256,6 +2487,7 @@ try {
     for (size_t i = 0; i < w->triggers.size(); ++i) w->trig_index_of_entity[w->triggers[i].entity] = static_cast<uint32_t>(i);
     w->triggers_device_stale = true;
     w->trig_list_on_device = false;
+    w->trig_mirror_valid = false; // (the keys carry trigger indices)
     return BGE_OK;
 }
 BGE_CATCH_ALL("bge_world_upload_triggers")
@@ -2272,6 +2504,24 @@ try {
     return BGE_OK;
 }
 BGE_CATCH_ALL("bge_world_trigger_events")
+
+int bge_world_set_trigger_stay_events(bge_world* w, int enabled)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "NULL world");
+    w->trig_stay_events = enabled != 0;
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_set_trigger_stay_events")
+
+int bge_world_trigger_diff_stats(bge_world* w, uint64_t* device_ticks, uint64_t* host_ticks, uint64_t* stay_suppressed)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "NULL world");
+    if (device_ticks) *device_ticks = w->trig_fast_ticks;
+    if (host_ticks) *host_ticks = w->trig_slow_ticks;
+    if (stay_suppressed) *stay_suppressed = w->trig_stay_suppressed;
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_trigger_diff_stats")
 
 int bge_world_trigger_active(bge_world* w, uint64_t count, const uint32_t* entity_index, uint8_t* active)
 try {

@@ -276,6 +276,16 @@ class World:
         check(lib().bge_world_trigger_active(self._h, len(e), _p(e), _p(out)))
         return out.astype(bool)
 
+    def set_trigger_stay_events(self, enabled=True):
+        """Stay records in trigger_events() (the reference's behaviour, the default) or Enter / Exit only (bge_world.h)."""
+        check(lib().bge_world_set_trigger_stay_events(self._h, int(bool(enabled))))
+
+    def trigger_diff_stats(self):
+        """(ticks whose Enter / Exit difference was taken on the device, ticks that took it on the host, Stay events left out)."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().bge_world_trigger_diff_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
     def trigger_query_stats(self):
         """(ghosts that walked the broadphase grid, ghosts tested against every body) in the last tick."""
         a, b = C.c_uint32(0), C.c_uint32(0)

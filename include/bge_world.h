@@ -318,7 +318,8 @@ BGE_API int bge_world_pairs(bge_world* world, uint32_t* pairs2, uint64_t cap, ui
  *       of two overlapping ghosts then reports the other) — with the filter (groupT & maskO) && (groupO & maskT): the
  *       content of Bullet's pair cache for the ghost (btGhostPairCallback, PhysicsSystem.cpp:132-133; the reference gives
  *       Bullet custom groups, :473,577, so no static-static exclusion applies; the ghost's own entity is skipped, :1033),
- *       (c) diffs the overlap set with the previous tick's on the host: Enter (0) / Stay (1) / Exit (2).  A one-shot trigger
+ *       (c) diffs the overlap set with the previous tick's — on the device, see bge_world_set_trigger_stay_events below; the host
+ *       keeps the sets and takes over whenever it changed them itself —: Enter (0) / Stay (1) / Exit (2).  A one-shot trigger
  *       turns inactive after its first non-empty set, forgets it, and leaves the world at once: triggers processed AFTER
  *       it in the same tick no longer list it (:1062-1072).  The triggers are processed IN THE ORDER OF THE UPLOADED ARRAY
  *       (the reference walks a std::unordered_map — an order the language leaves open; the C++ adapter and the oracle use
@@ -339,6 +340,17 @@ BGE_API int bge_world_upload_triggers(bge_world* world, uint64_t count, const ui
                                       const float* size3, const uint32_t* layer, const uint32_t* mask,
                                       const uint8_t* one_shot, const uint8_t* active);
 BGE_API int bge_world_trigger_events(bge_world* world, bge_trigger_event* out, uint64_t cap, uint64_t* total);
+/* Stay events.  PhysicsSystem::ProcessTriggerEvents (src/physics/PhysicsSystem.cpp:1017-1074) reports Stay for every remembered
+ * overlap on every tick, and so does bge_world_trigger_events by default.  With many volumes that list is the cost of the trigger
+ * pass (92,000 records a tick at 4 M bodies x 1000 volumes): the Enter / Exit difference itself is taken on the device (a table of
+ * last tick's overlaps stays there; only the changes travel).  enabled = 0 leaves the Stay records out — Enter and Exit still come,
+ * in the same order — and bge_world_trigger_diff_stats counts what was left out.
+ * device_ticks / host_ticks: how many ticks took their difference on the device / on the host (the first tick after the volumes or
+ * their activation changed, ticks with a one-shot volume in the world, a tick with more than 65,536 changes; BGE_TRIGGER_DEVICE_DIFF=0
+ * in the environment keeps every tick on the host). */
+BGE_API int bge_world_set_trigger_stay_events(bge_world* world, int enabled);
+BGE_API int bge_world_trigger_diff_stats(bge_world* world, uint64_t* device_ticks, uint64_t* host_ticks, uint64_t* stay_suppressed);
+
 BGE_API int bge_world_trigger_active(bge_world* world, uint64_t count, const uint32_t* entity_index, uint8_t* active);
 BGE_API int bge_world_trigger_query_stats(bge_world* world, uint32_t* through_grid, uint32_t* against_all_bodies);
 

@@ -749,6 +749,73 @@ def test_many_triggers_through_the_grid_match_oracle():
     assert seen_types == {0, 1, 2} and total > 5000
 
 
+def test_trigger_difference_taken_on_the_device_matches_oracle():
+    """without one-shot volumes the Enter / Exit difference is taken on the device (a table of last tick's
+    overlap keys; only the changes and five counters travel) and the host applies it to its sets.  500 ghosts over 40 k moving
+    bodies of all three types, ghost-ghost overlaps included; every tick's events equal the oracle's, with Stay records and —
+    in a second world — without (then exactly the Enter / Exit records remain); half-way the volume list is uploaded again with
+    some volumes switched off (the mirror table is rebuilt from the host's sets), and the statistics say that all other ticks
+    really went through the device."""
+    n = 40000
+    wl = synth.Workload("cube", synth.FLAT, n, 17, pos_box=synth.CUBE)
+    wl.pos = (wl.pos * np.float32(50.0 / 262.0)).astype(np.float32)
+    rng = np.random.default_rng(8)
+    wl.body_type = rng.choice([0, 1, 1, 1, 2], n).astype(np.uint8)
+    layer = rng.choice([1, 2, 4], n).astype(np.uint32)
+    mask = rng.choice([0xFFFFFFFF, 0xFFFFFFFB, 3], n).astype(np.uint32)
+    n_trig = 500
+    trig_entities = np.sort(rng.choice(n, n_trig, replace=False)).astype(np.uint32)
+    t_shape = rng.choice([0, 0, 1], n_trig).astype(np.uint8)
+    t_size = np.exp(rng.uniform(np.log(0.3), np.log(6.0), (n_trig, 3))).astype(np.float32)
+    t_layer = rng.choice([0, 4, 2], n_trig).astype(np.uint32)
+    t_mask = rng.choice([0xFFFFFFFF, 1, 6], n_trig).astype(np.uint32)
+    t_oneshot = np.zeros(n_trig, np.uint8)
+    t_active = (rng.random(n_trig) < 0.95).astype(np.uint8)
+    ref = build_oracle(wl, aabbs=True, layer=layer, mask=mask)
+    for k in range(n_trig):
+        ref.AddTriggerVolume(int(trig_entities[k]) + 1, int(t_shape[k]), t_size[k], int(t_layer[k]), int(t_mask[k]), False, bool(t_active[k]))
+    flags = B.TICK_ALL | B.TICK_BROADPHASE
+    seen_types, total = set(), 0
+    with B.World(pair_capacity=64 * n) as w, B.World(pair_capacity=64 * n) as lean:
+        for x in (w, lean):
+            x.set_topology(wl.parent)
+            x.upload_trs(wl.pos, wl.euler, wl.scale)
+            x.upload_bodies(wl.body_type, layer=layer, mask=mask)
+            x.upload_triggers(trig_entities, t_shape, t_size, t_layer, t_mask, t_oneshot, t_active)
+        lean.set_trigger_stay_events(False)
+        stays = 0
+        for tick in range(16):
+            if tick == 8:
+                t_active = t_active.copy()
+                t_active[::7] = 0
+                for k in range(0, n_trig, 7):      # (AddTriggerVolume on an entity that has one returns it: the fields are set again)
+                    ref.AddTriggerVolume(int(trig_entities[k]) + 1, int(t_shape[k]), t_size[k], int(t_layer[k]), int(t_mask[k]), False, False)
+                for x in (w, lean):
+                    x.upload_triggers(trig_entities, t_shape, t_size, t_layer, t_mask, t_oneshot, t_active)
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            for x in (w, lean):
+                x.tick(dt=DT, flags=flags)
+            if tick == 0:
+                ref.bulk_set_velocity(wl.vel * np.float32(8.0))
+                for x in (w, lean):
+                    x.set_velocities(wl.vel * np.float32(8.0))
+            want = ref.TriggerEvents()
+            want[:, 1:] -= 1
+            got = w.trigger_events()
+            assert np.array_equal(got, want), f"tick {tick}: {len(got)} vs {len(want)} events"
+            assert np.array_equal(lean.trigger_events(), want[want[:, 0] != 1]), f"tick {tick}: Enter / Exit without the Stay records"
+            stays += int((want[:, 0] == 1).sum())
+            seen_types |= set(got[:, 0].tolist())
+            total += len(got)
+        device, host, left_out = w.trigger_diff_stats()
+        assert host == 2 and device == 14, (device, host)       # the first tick and the one after the second upload
+        assert left_out == 0
+        device, host, left_out = lean.trigger_diff_stats()
+        assert host == 2 and device == 14 and left_out > 0, (device, host, left_out)
+    assert seen_types == {0, 1, 2} and total > 3000
+
+
 @pytest.mark.parametrize("basis", [False, True])
 def test_step_simulation_clock_matches_oracle(basis):
     """bge_world_step_simulation = Bullet's stepSimulation(dt, 4, fixedStep) around the ticks (PhysicsSystem.cpp:855-863;
