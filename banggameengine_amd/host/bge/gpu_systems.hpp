@@ -99,6 +99,7 @@ public:
     void SetGroundPlane(bool on)
     {
         if (ok() && bge_world_set_ground_plane(world_, on ? 1 : 0) != BGE_OK) Log("bge_world_set_ground_plane");
+        ground_plane_state = on ? 1 : 0;
     }
     // Contacts of Dynamic boxes with Static / Kinematic boxes (on by default, as in every reference world)
     void SetStaticContacts(bool on)
@@ -216,12 +217,13 @@ public:
         return true;
     }
 
-    // what LogStats prints as "bodies": the collision objects of the world (rigid bodies + active trigger ghosts)
+    // what LogStats prints as "bodies": m_world->getNumCollisionObjects() (PhysicsSystem.cpp:1332) — rigid bodies, active trigger
+    // ghosts and, while it is in the world, the ground plane's object (:149-166)
     int CollisionObjectCount()
     {
         bge_world_info info{};
         if (!ok() || bge_world_get_info(world_, &info) != BGE_OK) return 0;
-        int n = static_cast<int>(info.n_bodies);
+        int n = static_cast<int>(info.n_bodies) + (ground_plane_state ? 1 : 0);
         for (uint8_t a : t_active_) n += a ? 1 : 0;
         return n;
     }
