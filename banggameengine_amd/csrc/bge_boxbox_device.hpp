@@ -287,9 +287,10 @@ __device__ inline int box_box(const F3& p1v, const M3& basis1, const F3& half1, 
                 alpha = 0.0f;
                 beta = 0.0f;
             } else {
-                d = 1.0f / d;
-                alpha = (q1 + uaub * q2) * d;
-                beta = (uaub * q1 + q2) * d;
+                // (d = 1 / d and two products in the source: the reference's compiled code — MSVC /fp:fast — divides by d once,
+                //  oracle/boxbox_ref.h LineClosestApproach)
+                alpha = (q1 + uaub * q2) / d;
+                beta = (uaub * q1 + q2) / d;
             }
         }
         for (int i = 0; i < 3; ++i) pa[i] += ua[i] * alpha;

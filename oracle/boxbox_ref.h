@@ -118,9 +118,10 @@ inline void LineClosestApproach(const Vec3& pa, const Vec3& ua, const Vec3& pb, 
         *alpha = 0.0f;
         *beta = 0.0f;
     } else {
-        d = 1.0f / d;
-        *alpha = (q1 + uaub * q2) * d;
-        *beta = (uaub * q1 + q2) * d;
+        // (d = 1 / d and two products in the source; only beta reaches the contact point, and the reference's compiled code —
+        //  MSVC /fp:fast, read off the exe by oracle/tools/check_boxbox_order.py — divides by d once instead)
+        *alpha = (q1 + uaub * q2) / d;
+        *beta = (uaub * q1 + q2) / d;
     }
 }
 

@@ -22,6 +22,10 @@ nothing in it is loaded or run.  VERDICT r02 item 5.  Facts pinned here:
   3. cullPoints2: calls atan2f once per point in a loop and compares against the float 3.14159265 (M__PI of the file, not
      SIMD_PI) and its double 6.2831853, reads the 1e9 of maxdiff — and divides the constant 0x3eaaaaab by (a + q) where the
      source says 1.f / (3 * (a + q)): Bullet is built with MSVC /fp:fast, the restatement follows the compiled form.
+  4. dBoxBox2's contact generation (check_boxbox_contacts.py): face contacts for every code / incident axis / sign, edge contacts
+     (dLineClosestApproach: beta by ONE division, the compiled form), a clipped corner through intersectRectQuad2 and the cull,
+     and cullPoints2 on its own for 5..8 points — with concrete integers and symbolic floats, every value handed to
+     Result::addContactPoint identical to boxbox_ref.h's as an expression tree.
 
 Prints one line per fact and "RESULT: ..." at the end; exit code 1 on any mismatch, 2 when the reference is absent.
 """
@@ -101,7 +105,12 @@ def main():
     ok = check_solver_info(ins)
     import check_boxbox_order
     ok &= check_boxbox_order.check(ins)
-    print("RESULT: " + ("the contact path's parameters and the box-box detector's axis tests are compiled as restated" if ok else "MISMATCH"))
+    import check_boxbox_contacts
+    from check_bx_order import Pe
+    pe = Pe(EXE)
+    fn, cull = check_boxbox_contacts.locate(pe)
+    ok &= cull is not None and check_boxbox_contacts.check(pe, fn, cull)
+    print("RESULT: " + ("the contact path's parameters, the box-box detector's axis tests and its contact generation are compiled as restated" if ok else "MISMATCH"))
     return 0 if ok else 1
 
 
