@@ -6,7 +6,8 @@
 // btDefaultCollisionConfiguration / btCollisionDispatcher (:122-128), whose algorithm for two boxes is
 // btBoxBoxCollisionAlgorithm; assets/scenes/demo.json:67-91's "Ground" is such a box.
 //
-// Bullet's source is not under /root/reference; restated from its PUBLISHED source, function by function, scalar left to right:
+// Bullet's source is not under /root/reference; restated from its PUBLISHED source, function by function, and then corrected to
+// the COMPILED code of the reference's exe wherever MSVC /fp:fast made something else of it (PARITY STATUS below):
 //   BulletCollision/CollisionDispatch/btBoxBoxDetector.cpp   dBoxBox2 (15-axis separating-axis test, reference / incident face,
 //                                                            intersectRectQuad2, the four-point cull cullPoints2),
 //                                                            dLineClosestApproach, btBoxBoxDetector::getClosestPoints
@@ -20,7 +21,15 @@
 //                                                            for the plane, with a normal per point and a moving frame for B
 //   LinearMath/btVector3.h                                   btPlaneSpace1 (the friction direction when nothing slides)
 //
-// PARITY STATUS: "parity unpinned": none of this was read from the reference's exe yet (dBoxBox2 is in there, without a symbol).
+// PARITY STATUS: "parity unpinned" in the strict sense (Bullet is a third-party dependency whose version is not pinned and the
+// reference holds no fixtures), but every function here is compared, as expression trees, with the reference's compiled code:
+// dBoxBox2's separating-axis phase (oracle/tools/check_boxbox_order.py), its contact generation — face contacts for every code /
+// incident axis / sign, intersectRectQuad2's clipping, the cull, dLineClosestApproach — and cullPoints2
+// (check_boxbox_contacts.py: integers concrete, floats symbolic), addContactPoint / getCacheEntry / sortCachedPoints /
+// refreshContactPoints and the solver's row set-up (check_solver_setup.py), the solver's parameters (check_contact_order.py).
+// What the compiled code does differently from the source, and this file follows: pairwise four-term sums and ONE reciprocal per
+// edge axis in the SAT, 0x3eaaaaab / (a + q) in cullPoints2, beta by one division in dLineClosestApproach, DotXZY /
+// InvMassPlusDot / XformPoint / XformPointB and no friction warm start in the rows (contact_ref.h's header).
 // Specification choices where Bullet's behaviour depends on history the reference leaves open (stated, not hidden):
 //   * which body is "A": Bullet orders a pair by broadphase proxy id = creation order, which in the reference follows the
 //     iteration order of a std::unordered_map and every re-creation; here the DYNAMIC body is always A (the manifold's body0);
