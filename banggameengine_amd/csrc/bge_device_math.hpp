@@ -299,12 +299,54 @@ __device__ __forceinline__ Q4 bt_quat_from_mat(const M3& a)
     return Q4{(a.m[0][2] + a.m[2][0]) * s, (a.m[1][2] + a.m[2][1]) * s, ti, (a.m[1][0] - a.m[0][1]) * s};
 }
 
+// The same function without branches, for BGE_TICK_BULLET_BASIS's queue (one wave per workgroup over bodies of mixed cases).
+// (Used THERE only.  Substituted everywhere it made one case of the random-edit campaign differ by a few ulps in rotationEuler — seed 6, the
+//  AABB variant's inline step — although the two functions agree bit for bit on 8 M matrices in a kernel of their own and over six
+//  iterated steps of 2 M bodies: something in that context, not found yet)
+__device__ __forceinline__ Q4 bt_quat_from_mat_sel(const M3& a)
+{
+    // btMatrix3x3::getRotation has four cases (trace > 0; the largest diagonal element otherwise), each with one square root and
+    // one division.  As four branches a wave of mixed bodies ran all four one after the other — two thirds of this function's
+    // instructions, and the function runs twice per queued body in BGE_TICK_BULLET_BASIS.  Here every lane SELECTS its case's
+    // radicand and numerators and the wave shares one square root and one division: the same operations on the same operands per
+    // lane, so the same bits (tests/test_gpu_parity.py's BASIS cases, the fuzz campaign).
+    const float m00 = a.m[0][0], m11 = a.m[1][1], m22 = a.m[2][2];
+    const float trace = m00 + m11 + m22;
+    const bool t = trace > 0.0f;
+    const int i = m00 < m11 ? (m11 < m22 ? 2 : 1) : (m00 < m22 ? 2 : 0);
+    const float r_t = trace + 1.0f;
+    const float r_0 = m00 - m11 - m22 + 1.0f;
+    const float r_1 = m11 - m22 - m00 + 1.0f;
+    const float r_2 = m22 - m00 - m11 + 1.0f;
+    float s = __builtin_sqrtf(t ? r_t : (i == 0 ? r_0 : (i == 1 ? r_1 : r_2)));
+    const float half = s * 0.5f;
+    s = 0.5f / s;
+    const float da = a.m[2][1] - a.m[1][2], db = a.m[0][2] - a.m[2][0], dc = a.m[1][0] - a.m[0][1];
+    const float sa = a.m[2][1] + a.m[1][2], sb = a.m[2][0] + a.m[0][2], sc = a.m[1][0] + a.m[0][1];
+    //          x    y    z    w
+    // trace    da   db   dc   half
+    // i = 0    half sc   sb   da
+    // i = 1    sc   half sa   db
+    // i = 2    sb   sa   half dc        (the sums are commutative: (m[1][0] + m[0][1]) and (m[0][1] + m[1][0]) are one float)
+    const float nx = t ? da : (i == 1 ? sc : sb);
+    const float ny = t ? db : (i == 0 ? sc : sa);
+    const float nz = t ? dc : (i == 0 ? sb : sa);
+    const float nw = i == 0 ? da : (i == 1 ? db : dc);
+    Q4 q{nx * s, ny * s, nz * s, nw * s};
+    if (t) q.w = half;
+    else if (i == 0) q.x = half;
+    else if (i == 1) q.y = half;
+    else q.z = half;
+    return q;
+}
+
 // Transform::rotationEuler written by SyncRigidBodiesFromPhysics: {pitch, yaw, roll} of getEulerZYX
 // (the reference reads worldTransform.getRotation() and builds btMatrix3x3(rotation) before getEulerZYX: the basis takes a
 //  getRotation -> setRotation round trip first, oracle/bullet_math.h TransformEulerFromMat)
+template <bool SEL = false>
 __device__ __forceinline__ F3 bt_transform_euler_from_mat(const M3& basis)
 {
-    const M3 a = bt_mat_from_quat(bt_quat_from_mat(basis));
+    const M3 a = bt_mat_from_quat(SEL ? bt_quat_from_mat_sel(basis) : bt_quat_from_mat(basis));
     float yaw, pitch, roll;
     if (__builtin_fabsf(a.m[2][0]) >= 1.0f) {
         yaw = 0.0f;
@@ -329,26 +371,36 @@ __device__ __forceinline__ F3 bt_transform_euler_from_mat(const M3& basis)
 }
 
 // rotation part of btTransformUtil::integrateTransform
+// (A body that does not turn — w = +-0 — and whose quaternion has no zero component: dorn = (+-0, +-0, +-0, cos 0 = 1), and
+//  dorn * orn0 is orn0 BIT FOR BIT: 1 * c plus or minus signed zeros is c for c != 0.  With a zero component the signed zeros decide
+//  its sign, so those take the general path.  A wave all of whose lanes are in the first case skips the exponential map and the
+//  quaternion product — ~90 of the step's instructions; in BGE_TICK_BULLET_BASIS's steady state that is every queued wave.
+//  Checked on the CPU against oracle/bullet_math.h's IntegrateOrientation over 5.4 M random quaternions: 0 differences.)
 __device__ __forceinline__ Q4 bt_integrate_orientation(const Q4& orn0, const F3& w, float dt)
 {
-    const float fAngle2 = w.x * w.x + w.y * w.y + w.z * w.z;
-    float fAngle = 0.0f;
-    if (fAngle2 > kBtEpsilon) fAngle = __builtin_sqrtf(fAngle2);
-    if (fAngle * dt > kBtAngularMotionThreshold) fAngle = kBtAngularMotionThreshold / dt;
-    float k;
-    if (fAngle < 0.001f) {
-        // association as compiled in the reference's build: (dt*dt) * (dt * 1/48), oracle/tools/check_bullet_order.py
-        k = 0.5f * dt - ((dt * dt) * (dt * 0.020833333333f)) * fAngle * fAngle;
-    } else {
-        k = bge_det_sinf(0.5f * fAngle * dt) / fAngle;
+    const bool still = w.x == 0.0f && w.y == 0.0f && w.z == 0.0f && orn0.x != 0.0f && orn0.y != 0.0f && orn0.z != 0.0f && orn0.w != 0.0f;
+    Q4 r = orn0;
+    if (__builtin_amdgcn_ballot_w64(!still) != 0ull) {
+        const float fAngle2 = w.x * w.x + w.y * w.y + w.z * w.z;
+        float fAngle = 0.0f;
+        if (fAngle2 > kBtEpsilon) fAngle = __builtin_sqrtf(fAngle2);
+        if (fAngle * dt > kBtAngularMotionThreshold) fAngle = kBtAngularMotionThreshold / dt;
+        float k;
+        if (fAngle < 0.001f) {
+            // association as compiled in the reference's build: (dt*dt) * (dt * 1/48), oracle/tools/check_bullet_order.py
+            k = 0.5f * dt - ((dt * dt) * (dt * 0.020833333333f)) * fAngle * fAngle;
+        } else {
+            k = bge_det_sinf(0.5f * fAngle * dt) / fAngle;
+        }
+        const Q4 a{w.x * k, w.y * k, w.z * k, bge_det_cosf(fAngle * dt * 0.5f)};
+        const Q4& b = orn0;
+        Q4 g;
+        g.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+        g.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+        g.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+        g.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+        if (!still) r = g;
     }
-    const Q4 a{w.x * k, w.y * k, w.z * k, bge_det_cosf(fAngle * dt * 0.5f)};
-    const Q4& b = orn0;
-    Q4 r;
-    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
-    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
-    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
-    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
     // safeNormalize's length2 is summed pairwise in the compiled integrateTransform: (x^2 + y^2) + (z^2 + w^2)
     const float l2 = (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
     if (l2 > kBtEpsilon) {

@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
             Q4 q{qq.x, qq.y, qq.z, qq.w};
             uint32_t out = (in & kEqForce) ? kEqStoreEuler : 0u;
             if ((in & kEqIntegrate) && BGE_EXPERIMENT_BASIS == 0) {
-                const Q4 qn = bt_integrate_orientation(bt_quat_from_mat(bt_mat_from_quat(q)), F3{aa.x, aa.y, aa.z}, p.dt);
+                const Q4 qn = bt_integrate_orientation(bt_quat_from_mat_sel(bt_mat_from_quat(q)), F3{aa.x, aa.y, aa.z}, p.dt);
                 const bool same = !(in & kEqForce) && __float_as_uint(qn.x) == __float_as_uint(q.x) && __float_as_uint(qn.y) == __float_as_uint(q.y) &&
                                   __float_as_uint(qn.z) == __float_as_uint(q.z) && __float_as_uint(qn.w) == __float_as_uint(q.w);
                 // (a re-posed or corrected body stores what the step made of its quaternion even when the bits did not move:
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 q = qn;
             }
             F3 e{0.0f, 0.0f, 0.0f};
-            if ((out & kEqStoreEuler) && BGE_EXPERIMENT_BASIS < 2) e = bt_transform_euler_from_mat(bt_mat_from_quat(q));
+            if ((out & kEqStoreEuler) && BGE_EXPERIMENT_BASIS < 2) e = bt_transform_euler_from_mat<true>(bt_mat_from_quat(q));
             eq_quat[et] = make_float4(q.x, q.y, q.z, q.w);
             eq_av[et] = make_float4(e.x, e.y, e.z, __uint_as_float(out));
         }

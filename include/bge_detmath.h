@@ -150,7 +150,13 @@ BGE_HD float bge_det_atanf(float x)
 }
 
 /* atan2 with the quadrant rules of the C library, except that signed zeros are
- * not distinguished (atan2(-0,-1) = +pi here). */
+ * not distinguished (atan2(-0,-1) = +pi here).  The quotient and the range
+ * reduction of the arctangent share ONE division: |y| / |x| is compared with
+ * tan(pi/8), tan(3 pi/8) as |y| against those multiples of |x|, and the reduced
+ * argument is -|x| / |y|, (|y| - |x|) / (|y| + |x|) or |y| / |x| (round 3: it was
+ * y / x followed by -1 / t or (t - 1) / (t + 1), three IEEE divisions in a
+ * predicated instruction stream; the values move by an ulp here and there, which
+ * no libm pins). */
 BGE_HD float bge_det_atan2f(float y, float x)
 {
     if (x == 0.0f) {
@@ -165,7 +171,28 @@ BGE_HD float bge_det_atan2f(float y, float x)
     if (x < 0.0f) {
         w = y < 0.0f ? -BGE_PI_F : BGE_PI_F;
     }
-    return w + bge_det_atanf(y / x);
+    const float ax = x < 0.0f ? -x : x;
+    const float ay = y < 0.0f ? -y : y;
+    float base, num, den;
+    if (ay > 2.414213562373095f * ax) { /* tan(3pi/8) */
+        base = BGE_HALF_PI_F;
+        num = -ax;
+        den = ay;
+    } else if (ay > 0.4142135623730950f * ax) { /* tan(pi/8) */
+        base = BGE_QUARTER_PI_F;
+        num = ay - ax;
+        den = ay + ax;
+    } else {
+        base = 0.0f;
+        num = ay;
+        den = ax;
+    }
+    const float t = num / den;
+    const float z = t * t;
+    const float r = base + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z
+                             - 3.33329491539e-1f) * z * t + t);
+    const int neg = (y < 0.0f) != (x < 0.0f);
+    return w + (neg ? -r : r);
 }
 
 #endif /* BGE_DETMATH_H */

@@ -379,8 +379,14 @@ def test_random_scene_and_edit_script_match_oracle_every_tick(seed, monkeypatch)
                                                f"history {history.get(int(badp[0]))}; parent's history {history.get(int(parent[badp[0]])) if parent[badp[0]] != 0xFFFFFFFF else None}]")
             if os.environ.get("BGE_FUZZ_TRACE_ENTITY"):
                 te_ = int(os.environ["BGE_FUZZ_TRACE_ENTITY"])
+                bade_ = np.flatnonzero((euler.view(np.uint32) != reuler.view(np.uint32)).any(axis=1) & tf)
+                if te_ < 0 and len(bade_):
+                    te_ = int(bade_[0])          # (-1: the first entity whose rotationEuler differs)
+                te_ = max(te_, 0)
                 print(f"tick {tick} after {what}: sub-steps {got_n}: entity {te_}: here {pos[te_].tolist()} v {w.download_bodies()['linvel'][te_].tolist()} | oracle {rpos[te_].tolist()} "
-                      f"v {ref.bulk_bodies()['linvel'][te_].tolist()} | type {wl.body_type[te_]} Transform {has_transform[te_]} parent {parent[te_]} history {history.get(te_)}")
+                      f"v {ref.bulk_bodies()['linvel'][te_].tolist()} | type {wl.body_type[te_]} Transform {has_transform[te_]} parent {parent[te_]} history {history.get(te_)}"
+                      f" | euler here {euler[te_].view(np.uint32).tolist()} oracle {reuler[te_].view(np.uint32).tolist()} | quat here {w.download_bodies()['quat'][te_].view(np.uint32).tolist()} "
+                      f"oracle {ref.bulk_bodies()['quat'][te_].view(np.uint32).tolist()} | flags {flags:#x}")
             assert_bits_equal(pos[tf], rpos[tf], f"{tag}: position{detail}")
             assert_bits_equal(euler[tf], reuler[tf], f"{tag}: rotationEuler")
             want_world, want_dirty = ref.bulk_world()

@@ -121,5 +121,33 @@ def main():
     print(json.dumps(traffic, indent=1)[:3000])
 
 
+def ground(rnd):
+    """profiles/<round>/pmc_ground.md: k_ground on 1 M resting bodies — duration from the kernel trace, SQ counters of the same
+    launches (the 60 timed ticks = dispatches 150..210 of the kernel in tools/measure_ground.py's resting phase)."""
+    src = os.path.join(ROOT, "gpurun_out", rnd + "prof")
+    dst = os.path.join(ROOT, "profiles", rnd)
+    trace = newest(os.path.join(src, "stats_ground", "**", "*kernel_trace.csv"))
+    pmc = newest(os.path.join(src, "pmc_ground", "**", "*counter_collection.csv"))
+    if not trace or not pmc:
+        return
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace)) if "k_ground<" in r["Kernel_Name"]]
+    rows = {}
+    for r in csv.DictReader(open(pmc)):
+        if "k_ground<" in r["Kernel_Name"]:
+            rows.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    ids = sorted(rows)[150:210]
+    med = {c: statistics.median(rows[i][c] for i in ids if c in rows[i]) for c in rows[ids[0]]} if len(ids) == 60 else {}
+    with open(os.path.join(dst, "pmc_ground.md"), "w") as f:
+        f.write("# `k_ground` on 1 M bodies resting on the plane: SQ counters (round's profiling run, `tools/profile_round.sh`)\n\n")
+        f.write(f"kernel trace: {len(dur)} launches, the 60 timed ones average {sum(dur[150:210]) / 60e3:.1f} us\n\n| counter | median per launch |\n|---|---|\n")
+        for c, v in sorted(med.items()):
+            f.write(f"| {c} | {v:.4g} |\n")
+        if med.get("SQ_WAVES") and med.get("SQ_INSTS_VALU"):
+            f.write(f"\nVALU instructions per wave: {med['SQ_INSTS_VALU'] / med['SQ_WAVES']:.0f}\n")
+        if med.get("SQ_BUSY_CYCLES") and med.get("SQ_ACTIVE_INST_VALU"):
+            f.write(f"SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = {med['SQ_ACTIVE_INST_VALU'] / med['SQ_BUSY_CYCLES']:.3f}\n")
+
+
 if __name__ == "__main__":
     main()
+    ground(sys.argv[1] if len(sys.argv) > 1 else "r02")

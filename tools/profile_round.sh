@@ -41,4 +41,10 @@ for wl in flat1m chains4 subtree64; do
 done
 pmc sq1_cube4m "$SQ1" --workload cube4m --steps 4 --warmup 2
 pmc sq2_cube4m "$SQ2" --workload cube4m --steps 4 --warmup 2
+# the ground plane's solver kernel on 1 M resting bodies: kernel trace, then the SQ counters of the same script
+export BGE_GROUND_PHASE=resting
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ground -- python3 $R/tools/measure_ground.py > $OUT/stats_ground.txt 2> $OUT/stats_ground.err || echo "stats ground failed"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_ground -- python3 $R/tools/measure_ground.py > /dev/null 2> $OUT/pmc_ground.err || echo "pmc ground failed"
+unset BGE_GROUND_PHASE
+echo "ground done"
 echo "profiles done"
