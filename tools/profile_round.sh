@@ -5,6 +5,7 @@
 # WRITE_SIZE in separate passes (TCC slots), as MI355X_MICROARCH.md prescribes.
 set -o pipefail
 ROUND=${1:-r02}
+PART=${2:-all}   # "a": kernel statistics + FETCH / WRITE passes, "b": SQ passes + the ground plane, "all": both (more than one 20-minute gpurun call)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${ROUND}prof
 mkdir -p $OUT
@@ -19,6 +20,7 @@ pmc() { # name, counters (quoted), then bench.py arguments
     rocprofv3 --pmc $counters --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --no-cpu --no-configs "$@" > /dev/null 2> $OUT/pmc_$name.err || echo "pmc $name failed"
     echo "pmc $name done"
 }
+if [ $PART != b ]; then
 run flat1m
 run chains4 --workload chains4 --steps 600 --warmup 50
 run subtree64 --workload subtree64 --steps 300 --warmup 30
@@ -33,6 +35,8 @@ for wl in flat1m chains4 subtree64 cube4m; do
 done
 pmc fetch_flat1m_basis FETCH_SIZE --bullet-basis --steps 20 --warmup 5
 pmc write_flat1m_basis WRITE_SIZE --bullet-basis --steps 20 --warmup 5
+fi
+if [ $PART != a ]; then
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
 SQ2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_BUSY_CYCLES"
 for wl in flat1m chains4 subtree64; do
@@ -47,4 +51,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ground -- pyt
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_ground -- python3 $R/tools/measure_ground.py > /dev/null 2> $OUT/pmc_ground.err || echo "pmc ground failed"
 unset BGE_GROUND_PHASE
 echo "ground done"
+fi
 echo "profiles done"
