@@ -738,6 +738,162 @@ __device__ void ground_body(const WorldView& w, const GroundParams& g, uint32_t 
     if (f != f0) w.flags[slot] = f;
 }
 
+// ---- the obstacles' grid (GroundParams::obstacle_grid)
+__device__ __forceinline__ int obs_cell(float x, float mn, float per_unit, int n)
+{
+    // monotone in x, clamped: two intervals that overlap map to index ranges that overlap, whatever the rounding
+    const float c = (x - mn) * per_unit;
+    int i = c > 0.0f ? (c < static_cast<float>(n) ? static_cast<int>(c) : n - 1) : 0;
+    return i < n ? i : n - 1;
+}
+
+// One workgroup builds the whole index: bounds, counts per cell (LDS), scan, fill.  A few thousand obstacles are microseconds.
+__global__ void __launch_bounds__(1024) k_obstacle_grid(GroundParams g)
+{
+    __shared__ uint32_t s_cnt[kObstacleGridAxis * kObstacleGridAxis];
+    __shared__ uint32_t s_scan[1024];
+    __shared__ float s_red[4][16];
+    __shared__ uint32_t s_wide, s_bad;
+    const uint32_t tid = threadIdx.x, K = g.n_obstacles;
+    uint32_t* hdr = g.obstacle_grid;
+    float mnx = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxz = -INFINITY;
+    for (uint32_t k = tid; k < K; k += 1024u) {
+        const ObstacleRec& o = g.obstacles[k];
+        if (!o.live || !(o.aabb[0] <= o.aabb[3]) || !(o.aabb[2] <= o.aabb[5])) continue;
+        mnx = fminf(mnx, o.aabb[0]);
+        mxx = fmaxf(mxx, o.aabb[3]);
+        mnz = fminf(mnz, o.aabb[2]);
+        mxz = fmaxf(mxz, o.aabb[5]);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        mnx = fminf(mnx, __shfl_down(mnx, d));
+        mnz = fminf(mnz, __shfl_down(mnz, d));
+        mxx = fmaxf(mxx, __shfl_down(mxx, d));
+        mxz = fmaxf(mxz, __shfl_down(mxz, d));
+    }
+    if ((tid & 63u) == 0u) {
+        s_red[0][tid >> 6] = mnx;
+        s_red[1][tid >> 6] = mnz;
+        s_red[2][tid >> 6] = mxx;
+        s_red[3][tid >> 6] = mxz;
+    }
+    if (tid == 0) s_wide = s_bad = 0u;
+    for (uint32_t c = tid; c < kObstacleGridAxis * kObstacleGridAxis; c += 1024u) s_cnt[c] = 0u;
+    __syncthreads();
+    mnx = mnz = INFINITY;
+    mxx = mxz = -INFINITY;
+    for (int k = 0; k < 16; ++k) {
+        mnx = fminf(mnx, s_red[0][k]);
+        mnz = fminf(mnz, s_red[1][k]);
+        mxx = fmaxf(mxx, s_red[2][k]);
+        mxz = fmaxf(mxz, s_red[3][k]);
+    }
+    int n = 1;
+    while (n < static_cast<int>(kObstacleGridAxis) && static_cast<uint32_t>(n * n) < K) n *= 2;
+    const bool any = mnx <= mxx && mnz <= mxz && mxx - mnx < INFINITY && mxz - mnz < INFINITY;
+    const float ux = any && mxx > mnx ? static_cast<float>(n) / (mxx - mnx) : 0.0f, uz = any && mxz > mnz ? static_cast<float>(n) / (mxz - mnz) : 0.0f;
+    // pass 1: counts (an obstacle that covers more than 64 cells goes on the wide list instead)
+    for (uint32_t k = tid; k < K; k += 1024u) {
+        const ObstacleRec& o = g.obstacles[k];
+        if (!any || !o.live || !(o.aabb[0] <= o.aabb[3]) || !(o.aabb[2] <= o.aabb[5])) continue;
+        const int x0 = obs_cell(o.aabb[0], mnx, ux, n), x1 = obs_cell(o.aabb[3], mnx, ux, n), z0 = obs_cell(o.aabb[2], mnz, uz, n), z1 = obs_cell(o.aabb[5], mnz, uz, n);
+        if ((x1 - x0 + 1) * (z1 - z0 + 1) > 64) {
+            const uint32_t at = atomicAdd(&s_wide, 1u);
+            if (at < kObstacleGridWide) hdr[8 + at] = k;
+            else s_bad = 1u;
+            continue;
+        }
+        for (int z = z0; z <= z1; ++z) {
+            for (int x = x0; x <= x1; ++x) atomicAdd(&s_cnt[z * n + x], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the n * n counts: four cells per thread, then the 1024 partial sums
+    const uint32_t cells = static_cast<uint32_t>(n * n);
+    uint32_t mine[4], sum = 0;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t c = tid * 4u + j;
+        mine[j] = c < cells ? s_cnt[c] : 0u;
+        sum += mine[j];
+    }
+    s_scan[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = tid >= d ? s_scan[tid - d] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_scan[tid] - sum;
+    const uint32_t total = s_scan[1023];
+    uint32_t* start = hdr + kObstacleGridStart;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t c = tid * 4u + j;
+        if (c < cells) {
+            start[c] = run;
+            s_cnt[c] = run; // (from here on: the cell's write cursor)
+        }
+        run += mine[j];
+    }
+    if (tid == 0) start[cells] = total;
+    __syncthreads();
+    const bool fits = total <= g.obstacle_grid_cap && !s_bad;
+    if (fits) {
+        uint32_t* items = hdr + kObstacleGridItems;
+        for (uint32_t k = tid; k < K; k += 1024u) {
+            const ObstacleRec& o = g.obstacles[k];
+            if (!any || !o.live || !(o.aabb[0] <= o.aabb[3]) || !(o.aabb[2] <= o.aabb[5])) continue;
+            const int x0 = obs_cell(o.aabb[0], mnx, ux, n), x1 = obs_cell(o.aabb[3], mnx, ux, n), z0 = obs_cell(o.aabb[2], mnz, uz, n), z1 = obs_cell(o.aabb[5], mnz, uz, n);
+            if ((x1 - x0 + 1) * (z1 - z0 + 1) > 64) continue;
+            for (int z = z0; z <= z1; ++z) {
+                for (int x = x0; x <= x1; ++x) items[atomicAdd(&s_cnt[z * n + x], 1u)] = k;
+            }
+        }
+    }
+    if (tid == 0) {
+        hdr[0] = fits ? 1u : 0u;
+        hdr[1] = static_cast<uint32_t>(n);
+        hdr[2] = s_wide < kObstacleGridWide ? s_wide : kObstacleGridWide;
+        hdr[4] = __float_as_uint(mnx);
+        hdr[5] = __float_as_uint(mnz);
+        hdr[6] = __float_as_uint(ux);
+        hdr[7] = __float_as_uint(uz);
+    }
+}
+
+// fn(k) for every obstacle number whose fed AABB may overlap the box [x0, x1] x [z0, z1] in x and z — possibly more than once and in
+// no particular order; through the grid when it is valid and the box covers few cells, otherwise all of them.  fn returns true to stop.
+template <class Fn>
+__device__ __forceinline__ void for_each_obstacle_near(const GroundParams& g, float x0, float x1, float z0, float z1, Fn fn)
+{
+    const uint32_t* hdr = g.obstacle_grid;
+    if (hdr && hdr[0]) {
+        const int n = static_cast<int>(hdr[1]);
+        const float mnx = __uint_as_float(hdr[4]), mnz = __uint_as_float(hdr[5]), ux = __uint_as_float(hdr[6]), uz = __uint_as_float(hdr[7]);
+        const int cx0 = obs_cell(x0, mnx, ux, n), cx1 = obs_cell(x1, mnx, ux, n), cz0 = obs_cell(z0, mnz, uz, n), cz1 = obs_cell(z1, mnz, uz, n);
+        if (x0 <= x1 && z0 <= z1 && (cx1 - cx0 + 1) * (cz1 - cz0 + 1) <= 64) {
+            const uint32_t n_wide = hdr[2];
+            for (uint32_t j = 0; j < n_wide; ++j) {
+                if (fn(hdr[8 + j])) return;
+            }
+            const uint32_t* start = hdr + kObstacleGridStart;
+            const uint32_t* items = hdr + kObstacleGridItems;
+            for (int z = cz0; z <= cz1; ++z) {
+                for (int x = cx0; x <= cx1; ++x) {
+                    const uint32_t b = start[z * n + x], e = start[z * n + x + 1];
+                    for (uint32_t at = b; at < e; ++at) {
+                        if (fn(items[at])) return;
+                    }
+                }
+            }
+            return;
+        }
+    }
+    for (uint32_t k = 0; k < g.n_obstacles; ++k) {
+        if (fn(k)) return;
+    }
+}
+
 // ---- two launches per sub-step
 // ground_body needs 246 VGPRs (two waves per SIMD) — and most bodies of a scene need none of it: they sleep, or are nowhere
 // near the plane.  As ONE kernel over all slots (the first version) even those paid for the solver's occupancy: two waves per
@@ -794,11 +950,12 @@ __global__ void __launch_bounds__(256) k_ground_select(WorldView w, GroundParams
                 const float reach = (__builtin_fabsf(cs.x) + __builtin_fabsf(cs.y) + __builtin_fabsf(cs.z)) * 1.01f + 0.05f;
                 const float rx = reach + __builtin_fabsf(v.x) * g.dt * 1.01f, ry = reach + __builtin_fabsf(v.y) * g.dt * 1.01f,
                             rz = reach + __builtin_fabsf(v.z) * g.dt * 1.01f;
-                for (uint32_t k = 0; k < g.n_obstacles && !boxes; ++k) {
+                for_each_obstacle_near(g, pos.x - rx, pos.x + rx, pos.z - rz, pos.z + rz, [&](uint32_t k) {
                     const float* bb = g.obstacles[k].aabb;
                     boxes = pos.x - rx <= bb[3] && pos.x + rx >= bb[0] && pos.y - ry <= bb[4] && pos.y + ry >= bb[1] && pos.z - rz <= bb[5] &&
                             pos.z + rz >= bb[2];
-                }
+                    return boxes;
+                });
             }
         }
     }
@@ -1256,17 +1413,26 @@ __device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t
     uint32_t accepted[kBoxManifolds];
     int row_of[kBoxManifolds];
     int n_acc = 0;
-    for (uint32_t k = 0; k < g.n_obstacles && n_acc < static_cast<int>(kBoxManifolds); ++k) {
+    // (the obstacle numbers ascend with the entity ids: the kBoxManifolds LOWEST partners are kept, in ascending order, whatever order
+    //  the candidates come in and however often)
+    for_each_obstacle_near(g, fed_mn[0], fed_mx[0], fed_mn[2], fed_mx[2], [&](uint32_t k) {
         const ObstacleRec& o = g.obstacles[k];
-        if (!o.live || o.entity == my_entity) continue;
-        if ((grp & o.mask) == 0u || (o.group & msk) == 0u) continue;
+        if (!o.live || o.entity == my_entity) return false;
+        if ((grp & o.mask) == 0u || (o.group & msk) == 0u) return false;
         const bool overlap = fed_mn[0] <= o.aabb[3] && fed_mx[0] >= o.aabb[0] && fed_mn[1] <= o.aabb[4] && fed_mx[1] >= o.aabb[1] &&
                              fed_mn[2] <= o.aabb[5] && fed_mx[2] >= o.aabb[2];
-        if (!overlap) continue;
-        accepted[n_acc] = k;
-        row_of[n_acc] = -1;
-        n_acc++;
-    }
+        if (!overlap) return false;
+        int at = 0;
+        while (at < n_acc && accepted[at] < k) ++at;
+        if (at < n_acc && accepted[at] == k) return false;                       // seen in another cell
+        if (at >= static_cast<int>(kBoxManifolds)) return false;                 // four lower ones are known already
+        const int last = n_acc < static_cast<int>(kBoxManifolds) ? n_acc : static_cast<int>(kBoxManifolds) - 1;
+        for (int j = last; j > at; --j) accepted[j] = accepted[j - 1];
+        accepted[at] = k;
+        if (n_acc < static_cast<int>(kBoxManifolds)) n_acc++;
+        return false;
+    });
+    for (int a = 0; a < n_acc; ++a) row_of[a] = -1;
     // a manifold lives as long as its pair: rows whose box is no longer a partner (or was re-created) are freed
     uint32_t row_used = 0;
     for (uint32_t e = 0; e < kBoxManifolds; ++e) {
@@ -1471,6 +1637,7 @@ hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundPar
     const dim3 grid(512u * BGE_GROUND_MIN_BLOCKS), block(128);
     const bool boxes = g.box_list != nullptr; // Static / Kinematic box colliders are on
     if (boxes && g.n_obstacles) hipLaunchKernelGGL(k_obstacles, dim3((g.n_obstacles + 63u) / 64u), dim3(64), 0, stream, w, g);
+    if (boxes && g.obstacle_grid) hipLaunchKernelGGL(k_obstacle_grid, dim3(1), dim3(1024), 0, stream, g);
     if (bullet_basis) {
         hipLaunchKernelGGL(k_ground_select<true>, sgrid, sblock, 0, stream, w, g);
         if (g.plane) hipLaunchKernelGGL(k_ground<true>, grid, block, 0, stream, w, g);

@@ -97,10 +97,19 @@ struct GroundParams {
     ObstacleRec* obstacles;         // [n_obstacles] written by k_obstacles
     uint32_t n_obstacles;
     const uint32_t* entity_of_slot;
+    // A grid over the obstacles' fed AABBs in x and z (k_obstacle_grid, rebuilt every sub-step behind k_obstacles when there are more
+    // than kObstacleGridMin of them): the candidate test of a body walks the few cells its own box covers instead of all obstacles.
+    //   words 0..7: [0] 1 = the grid is valid (0: walk all obstacles), [1] cells per axis, [2] wide obstacles (they cover more than 64
+    //               cells and are always tested), [4..7] floats min x, min z, cells per unit in x, in z;  8..39: the wide ones;
+    //   kObstacleGridStart..: start of each cell's items (cells + 1 words);  kObstacleGridItems..: obstacle numbers, cell by cell
+    uint32_t* obstacle_grid;   // null when there are few obstacles
+    uint32_t obstacle_grid_cap; // item capacity
     uint32_t* box_list;        // [n_slots] slots k_ground_select hands to k_contact_boxes
     uint32_t* box_count;       // [0] entries of box_list, [1] workgroups of k_contact_boxes that are done (both zero between sub-steps)
 };
 constexpr uint32_t kGroundShards = 64;
+constexpr uint32_t kObstacleGridMin = 64, kObstacleGridAxis = 64, kObstacleGridWide = 32, kObstacleGridStart = 40,
+                   kObstacleGridItems = kObstacleGridStart + kObstacleGridAxis * kObstacleGridAxis + 1;
 // slots the select workgroups b = shard, shard + 64, ... (256 slots each) can send at most
 inline uint64_t ground_shard_cap(uint64_t n_slots) { return ((n_slots + 255) / 256 + kGroundShards - 1) / kGroundShards * 256; }
 

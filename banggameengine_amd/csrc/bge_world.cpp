@@ -159,7 +159,8 @@ struct bge_world {
     bool static_contacts = false;
     DevBuf crestitution;                              // RigidBody::restitution per slot (allocated with the layout, zero = the component default)
     DevBuf bmanifold;                                 // kBoxManifolds manifold rows per slot (allocated when the feature is switched on)
-    DevBuf obstacle_slots, obstacle_gen, obstacles, box_list, box_count;
+    DevBuf obstacle_slots, obstacle_gen, obstacles, obstacle_grid, box_list, box_count;
+    bool obstacle_grid_on = true; // BGE_OBSTACLE_GRID=0: every body tests every obstacle (measurements)
     uint32_t n_obstacles = 0;
     bool obstacles_stale = true;                      // the compact list of Static / Kinematic box bodies must be rebuilt
     std::vector<uint8_t> body_shape_host;             // bge_shape per entity index as last uploaded
@@ -342,7 +343,7 @@ struct bge_world {
     {
         for (DevBuf* b : {&flags, &parent, &tile_hdr, &slot_of_entity, &entity_of_slot, &root_slots, &root_index, &pos, &euler, &scale, &world, &vel,
                           &angvel, &quat, &inv_mass, &half_extent, &group, &mask, &aabb, &root_worlds, &counter, &stage,
-                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &crestitution, &bmanifold, &obstacle_slots, &obstacle_gen, &obstacles, &box_list, &box_count, &frozen, &trig_slot, &trig_entity, &trig_he, &trig_group,
+                          &stage2, &mass_palette, &normal, &deact, &filter_class, &filter_table, &grav_palette, &bp_partials, &cshape, &cmass, &cfriction, &cinfo, &manifold, &crestitution, &bmanifold, &obstacle_slots, &obstacle_gen, &obstacles, &obstacle_grid, &box_list, &box_count, &frozen, &trig_slot, &trig_entity, &trig_he, &trig_group,
                           &trig_mask, &trig_active, &trig_aabb, &trig_pairs, &trig_count, &trig_lists, &ground_list, &ground_count, &trig_tab[0], &trig_tab[1],
                           &trig_delta_dev, &trig_keys_dev}) {
             b->release();
@@ -839,6 +840,8 @@ int prepare_obstacles(bge_world* w, uint64_t n_slots)
     HIP_TRY(w->obstacle_slots.ensure(n * 4));
     HIP_TRY(w->obstacle_gen.ensure(n * 4));
     HIP_TRY(w->obstacles.ensure(n * sizeof(bge::ObstacleRec)));
+    // (an obstacle on the grid covers at most 64 cells: 64 items each is a capacity that cannot overflow)
+    if (w->n_obstacles > bge::kObstacleGridMin) HIP_TRY(w->obstacle_grid.ensure((bge::kObstacleGridItems + 64ull * n) * 4));
     if (!slots.empty()) {
         HIP_TRY(hipMemcpy(w->obstacle_slots.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(w->obstacle_gen.p, gens.data(), gens.size() * 4, hipMemcpyHostToDevice));
@@ -894,6 +897,7 @@ try {
     w->device = device;
     if (const char* e = std::getenv("BGE_TRIGGER_GRID_MIN")) w->trigger_grid_min = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
     if (const char* e = std::getenv("BGE_TRIGGER_DEVICE_DIFF")) w->trig_device_diff = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("BGE_OBSTACLE_GRID")) w->obstacle_grid_on = std::strtoul(e, nullptr, 10) != 0;
     DeviceGuard guard(device);
     if (desc && desc->stream) {
         w->stream = static_cast<hipStream_t>(desc->stream);
@@ -1634,6 +1638,10 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
                 gp.obstacle_gen = w->obstacle_gen.as<uint32_t>();
                 gp.obstacles = w->obstacles.as<bge::ObstacleRec>();
                 gp.n_obstacles = w->n_obstacles;
+                if (w->obstacle_grid_on && w->n_obstacles > bge::kObstacleGridMin) {
+                    gp.obstacle_grid = w->obstacle_grid.as<uint32_t>();
+                    gp.obstacle_grid_cap = 64u * w->n_obstacles;
+                }
                 gp.entity_of_slot = w->entity_of_slot.as<uint32_t>();
                 gp.box_list = w->box_list.as<uint32_t>();
                 gp.box_count = w->box_count.as<uint32_t>();

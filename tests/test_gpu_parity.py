@@ -1170,6 +1170,99 @@ def test_dynamic_boxes_on_static_boxes_match_oracle_bitwise(basis, plane):
     assert slept > 100, slept
 
 
+@pytest.mark.parametrize("grid", [True, False], ids=["grid", "all-pairs"])
+def test_many_static_boxes_through_the_obstacle_grid_match_oracle_bitwise(grid, monkeypatch):
+    """with more than 64 Static / Kinematic boxes the candidate test of a body walks an x-z grid over the obstacles' fed
+    AABBs (bge_contact.hip k_obstacle_grid) instead of all of them.  400 blocks of mixed footprint on a jittered 20 x 20 layout —
+    neighbours overlap, so that a body can see more than four candidates and the four lowest entities must be the ones kept — plus
+    one slab under a quarter of the field and one long wall (both cover more than 64 cells: the wide list), one block far outside
+    (stretches the bounds), one Kinematic block that is teleported across the field on the way.  800 Dynamic boxes rain on it.  Pose,
+    velocities, every box manifold with its points, activation — bit for bit against the oracle, with the grid and with
+    BGE_OBSTACLE_GRID=0 (every body tests every obstacle)."""
+    monkeypatch.setenv("BGE_OBSTACLE_GRID", "1" if grid else "0")
+    rng = np.random.default_rng(77)
+    n_obs, n_dyn = 404, 800
+    n = n_obs + n_dyn
+    wl = synth.Workload("blocks", synth.FLAT, n, 4242)
+    body_type = np.ones(n, np.uint8)
+    size = np.zeros((n, 3), np.float32)
+    mass = np.ones(n, np.float32)
+    wl.scale[:] = 1.0
+    wl.euler[:] = 0.0
+    k = np.arange(400)
+    wl.pos[:400, 0] = (2.0 * (k % 20) - 20.0 + rng.uniform(-0.4, 0.4, 400)).astype(np.float32)
+    wl.pos[:400, 2] = (2.0 * (k // 20) - 20.0 + rng.uniform(-0.4, 0.4, 400)).astype(np.float32)
+    wl.pos[:400, 1] = rng.uniform(0.4, 1.0, 400).astype(np.float32)
+    size[:400] = np.stack([rng.uniform(1.2, 3.0, 400), rng.uniform(0.4, 1.2, 400), rng.uniform(1.2, 3.0, 400)], 1).astype(np.float32)
+    wl.euler[:400:7, 0] = rng.uniform(-1.0, 1.0, len(k[::7])).astype(np.float32)   # some turned about the vertical
+    wl.euler[3:400:11, 1] = 0.12                                                    # some tilted
+    body_type[:400] = 0
+    wl.pos[400] = (-10.0, 0.15, -10.0); size[400] = (20.0, 0.3, 20.0); body_type[400] = 0      # a slab under a quarter of the field
+    wl.pos[401] = (0.0, 1.2, 9.0); size[401] = (44.0, 2.4, 0.5); body_type[401] = 0            # a long wall
+    wl.pos[402] = (300.0, 1.0, -250.0); size[402] = (1.0, 1.0, 1.0); body_type[402] = 0        # far outside
+    wl.pos[403] = (5.0, 1.6, 5.0); size[403] = (4.0, 0.4, 4.0); body_type[403] = 2             # a Kinematic deck, teleported later
+    d = slice(n_obs, n)
+    wl.pos[d, 0] = rng.uniform(-21.0, 19.0, n_dyn).astype(np.float32)
+    wl.pos[d, 2] = rng.uniform(-21.0, 19.0, n_dyn).astype(np.float32)
+    wl.pos[d, 1] = rng.uniform(2.6, 5.0, n_dyn).astype(np.float32)
+    wl.euler[d] = rng.uniform(-1.0, 1.0, (n_dyn, 3)).astype(np.float32)
+    size[d] = rng.uniform(0.2, 0.8, (n_dyn, 3)).astype(np.float32)
+    size[n_obs:n_obs + 40] = (3.5, 0.3, 3.5)                                 # planks that span several blocks: more than four candidates
+    wl.euler[n_obs:n_obs + 40] = 0.0
+    mass[d] = rng.choice([0.3, 1.0, 5.0], n_dyn)
+    friction = rng.choice([0.3, 0.5, 1.0], n).astype(np.float32)
+    wl.body_type = body_type
+    ref = build_oracle(wl, orient_mode=po.ORIENT_IDEAL, size=size, mass=mass)
+    for i in range(n):
+        ref.SetFriction(i + 1, float(friction[i]))
+    ref.SetGroundPlane(True)
+    ref.SetStaticContacts(True)
+    dyn = body_type == 1
+    most = 0
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(body_type, mass=mass, size=size)
+        w.upload_friction(friction)
+        w.set_ground_plane(True)
+        w.set_static_contacts(True)
+        for tick in range(240):
+            if tick == 120:   # the deck jumps to the other side of the field; the block far outside comes home (the bounds shrink)
+                there = np.array([[-12.0, 2.2, 12.0]], np.float32)
+                home = np.array([[1.0, 2.4, -3.0]], np.float32)
+                ref.SetTRS(404, pos=there[0])
+                w.upload_trs(pos=there, first=403)
+                ref.SetTRS(403, pos=home[0])
+                w.upload_trs(pos=home, first=402)
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, flags=B.TICK_ALL)
+            if tick % 6 and tick > 6 and not (118 <= tick <= 124):
+                continue
+            rb, gb = ref.bulk_bodies(), w.download_bodies()
+            ex = rb["exists"]
+            pos, euler = w.download_pose()
+            rpos, reuler = ref.bulk_pose()
+            assert_bits_equal(pos, rpos, f"tick {tick}: position")
+            assert_bits_equal(euler, reuler, f"tick {tick}: rotationEuler")
+            assert_bits_equal(gb["linvel"][dyn], rb["linvel"][dyn], f"tick {tick}: linear velocity")
+            assert_bits_equal(gb["angvel"][dyn], rb["angvel"][dyn], f"tick {tick}: angular velocity")
+            nb, hdr, pts = w.download_box_contacts()
+            for e in np.flatnonzero(dyn)[:: 4 if tick % 30 else 1]:
+                want = ref.BoxContacts(int(e) + 1)
+                assert nb[e] == len(want), f"tick {tick}: body {e} has {nb[e]} box manifolds, oracle {len(want)}"
+                for m, (other, rows) in enumerate(want):
+                    assert hdr[e, m, 0] == other - 1 and hdr[e, m, 1] == len(rows), f"tick {tick}: body {e} manifold {m}: {hdr[e, m]} vs ({other - 1}, {len(rows)})"
+                    assert_bits_equal(pts[e, m, :len(rows)], rows, f"tick {tick}: body {e} manifold {m} points")
+                most = max(most, len(want))
+            st, _ = w.download_activation()
+            rst, _ = ref.bulk_activation()
+            assert np.array_equal(st[ex], rst[ex].astype(np.uint8)), f"tick {tick}: activation states"
+        final_pos, _ = w.download_pose()
+    assert most == 4, most                                                   # a plank held the four lowest of its candidates
+    assert (final_pos[dyn, 1] > 0.5).sum() > 600                             # the blocks caught most of the rain
+
+
 def test_ground_plane_switched_off_then_scene_grows_then_on_again():
     """the contact manifold store follows the slot layout whether the plane is on or off.  Bodies land and rest
     on the plane, the plane goes off (they fall on), the scene grows across several tile boundaries (bge_world_set_topology
