@@ -650,185 +650,7 @@ inline void CollideBoxBox(BoxManifold& m, const BoxPose& a, const BoxPose& b)
     }
 }
 
-// solveGroup for the island {body}: its manifold with the ground plane (when the plane is on) followed by its manifolds with
-// Static / Kinematic boxes, in ascending entity id.  The
-// other body of every row is a fixed solver body (static and kinematic objects share the zero-velocity one: the reference
-// never gives a Kinematic body a velocity, it teleports it), so its side of every row contributes exactly zero.
-// Row order = Bullet's pool order for one island: every manifold's points in turn (convertContacts), all contact rows of an
-// iteration before all friction rows.  The row set-up follows the COMPILED setupContactConstraint / setupFrictionConstraint /
-// convertContact of the reference's exe (oracle/tools/check_solver_setup.py; contact_ref.h's header lists what that changed).
-// btContactSolverInfo as the reference's exe constructs it (VA 0x1401b8b5b: tau 0.6 ... m_restitutionVelocityThreshold 0.2 at
-// +0x108 of the world — the field exists, so the build is bullet3 >= 2.88).
-inline bool SolveBody(BodyState& b, Manifold* ground, BoxManifold* boxes, int nBoxes, float invMassScalar, const Vec3& invInertiaLocal,
-                      float bodyFriction, const Vec3& force, float dt)
-{
-    constexpr int kIterations = 10;
-    constexpr float kErp2 = 0.2f;
-    constexpr float kSplitThreshold = -0.04f;
-    constexpr float kSplitTurnErp = 0.1f;
-    constexpr float kWarmstart = 0.85f;
-    constexpr float kSor = 1.0f;
-    constexpr float kRestitutionVelocityThreshold = 0.2f;
-    constexpr int kMaxRows = 4 * (1 + kMaxBoxManifolds);
-    const Mat3 invI = InvInertiaWorld(b.basis, invInertiaLocal);
-
-    SolverBody sb;
-    sb.invMass = V(invMassScalar, invMassScalar, invMassScalar);
-    sb.linVel = b.linVel;
-    sb.angVel = b.angVel;
-    sb.extForce = Scale(Scale(force, invMassScalar), dt);
-    sb.extTorque = V(0.0f, 0.0f, 0.0f);
-    sb.extTorque = Add(sb.extTorque, GyroscopicImpulse(invInertiaLocal, b.angVel, b.orn, dt));
-
-    struct Ref {
-        Vec3 worldA, n;
-        float distance, friction, restitution;
-        float* applied;
-        float* appliedLat;
-    };
-    Ref ref[kMaxRows];
-    int nRows = 0;
-    if (ground) {
-        const float combinedFriction = std::max(-10.0f, std::min(10.0f, bodyFriction * 1.0f));
-        for (int j = 0; j < ground->n; ++j) {
-            ContactPoint& cp = ground->p[j];
-            ref[nRows++] = Ref{cp.worldA, V(0.0f, 1.0f, 0.0f), cp.distance, combinedFriction, 0.0f, &cp.appliedImpulse, &cp.appliedImpulseLateral1};
-        }
-    }
-    for (int k = 0; k < nBoxes; ++k) {
-        for (int j = 0; j < boxes[k].n; ++j) {
-            BoxPoint& cp = boxes[k].p[j];
-            ref[nRows++] = Ref{cp.worldA, cp.normalB, cp.distance, boxes[k].friction, boxes[k].restitution, &cp.appliedImpulse, &cp.appliedImpulseLateral1};
-        }
-    }
-
-    SolverRow normalRow[kMaxRows], frictionRow[kMaxRows];
-    const float invTimeStep = 1.0f / dt;
-    for (int j = 0; j < nRows; ++j) {
-        const Ref& cp = ref[j];
-        const Vec3 n = cp.n;
-        SolverRow& c = normalRow[j];
-        c = SolverRow{};
-        const Vec3 rel_pos1 = Sub(cp.worldA, b.origin);
-        const Vec3 vel1 = Add(Add(sb.linVel, sb.extForce), Cross(Add(sb.angVel, sb.extTorque), rel_pos1)); // getVelocityInLocalPointNoDelta
-        const Vec3 vel = Sub(vel1, V(0.0f, 0.0f, 0.0f));
-        const float rel_vel = Dot(n, vel);
-        const float relaxation = kSor;
-        const Vec3 torqueAxis0 = Cross(rel_pos1, n);
-        c.angularComp = MatVec(invI, torqueAxis0);
-        {
-            const Vec3 vec = Cross(c.angularComp, rel_pos1);
-            const float denom0 = InvMassPlusDot(invMassScalar, n, vec);
-            const float cfm0 = 0.0f * invTimeStep;
-            c.jacDiagABInv = relaxation / (denom0 + 0.0f + cfm0);
-        }
-        c.normal = n;
-        c.relposCrossN = torqueAxis0;
-        const float penetration = cp.distance + 0.0f;
-        c.friction = cp.friction;
-        // setupContactConstraint's own relative velocity: the rigid body's, without the external force impulse
-        float restitution = 0.0f;
-        if (cp.restitution != 0.0f) {
-            const Vec3 rbVel = Add(b.linVel, Cross(b.angVel, rel_pos1)); // rb0->getVelocityInLocalPoint(rel_pos1)
-            const float rbRelVel = Dot(n, Sub(rbVel, V(0.0f, 0.0f, 0.0f)));
-            restitution = std::fabs(rbRelVel) < kRestitutionVelocityThreshold ? 0.0f : cp.restitution * -rbRelVel; // restitutionCurve
-            if (restitution <= 0.0f) restitution = 0.0f;
-        }
-        c.applied = *cp.applied * kWarmstart;
-        {
-            const Vec3 lin = V(c.normal.x * sb.invMass.x, c.normal.y * sb.invMass.y, c.normal.z * sb.invMass.z);
-            sb.dLin = Add(sb.dLin, Scale(lin, c.applied));
-            sb.dAng = Add(sb.dAng, Scale(c.angularComp, c.applied * 1.0f));
-        }
-        c.appliedPush = 0.0f;
-        {
-            const float vel1Dotn = DotXZY(c.normal, Add(sb.linVel, sb.extForce)) + DotXZY(c.relposCrossN, Add(sb.angVel, sb.extTorque));
-            const float vel2Dotn = 0.0f + 0.0f;
-            const float rel_vel2 = vel1Dotn + vel2Dotn;
-            float positionalError = 0.0f;
-            float velocityError = restitution - rel_vel2;
-            if (penetration > 0.0f) {
-                positionalError = 0.0f;
-                velocityError -= penetration * invTimeStep;
-            } else {
-                positionalError = -penetration * kErp2 * invTimeStep;
-            }
-            const float penetrationImpulse = positionalError * c.jacDiagABInv;
-            const float velocityImpulse = velocityError * c.jacDiagABInv;
-            if (penetration > kSplitThreshold) {
-                c.rhs = penetrationImpulse + velocityImpulse;
-                c.rhsPenetration = 0.0f;
-            } else {
-                c.rhs = velocityImpulse;
-                c.rhsPenetration = penetrationImpulse;
-            }
-            c.cfm = 0.0f * c.jacDiagABInv;
-            c.lower = 0.0f;
-            c.upper = 1e10f;
-        }
-        Vec3 dir = Sub(vel, Scale(n, rel_vel));
-        const float lat_rel_vel = Dot(dir, dir);
-        if (lat_rel_vel > bt::kEpsilon) {
-            dir = Scale(dir, 1.0f / std::sqrt(lat_rel_vel));
-        } else {
-            dir = PlaneSpace1(n); // (for the plane's (0, 1, 0): (-1, 0, 0), contact_ref.h's FallbackFrictionDir)
-        }
-        SolverRow& f = frictionRow[j];
-        f = SolverRow{};
-        f.friction = cp.friction;
-        f.normal = dir;
-        f.relposCrossN = Cross(rel_pos1, dir);
-        f.angularComp = MatVec(invI, f.relposCrossN);
-        {
-            const Vec3 vec = Cross(f.angularComp, rel_pos1);
-            const float denom0 = InvMassPlusDot(invMassScalar, dir, vec);
-            f.jacDiagABInv = relaxation / (denom0 + 0.0f);
-        }
-        {
-            const float vel1Dotn = DotXZY(f.normal, Add(sb.linVel, sb.extForce)) + DotXZY(f.relposCrossN, sb.angVel);
-            const float vel2Dotn = 0.0f + 0.0f;
-            const float rv = vel1Dotn + vel2Dotn;
-            const float velocityError = 0.0f - rv;
-            const float velocityImpulse = velocityError * f.jacDiagABInv;
-            f.rhs = 0.0f + velocityImpulse;
-            f.rhsPenetration = 0.0f;
-            f.cfm = 0.0f;
-            f.lower = -f.friction;
-            f.upper = f.friction;
-        }
-        f.applied = 0.0f; // setFrictionConstraintImpulse of this Bullet: frictionConstraint1.m_appliedImpulse = 0.f, no warm start
-    }
-    for (int it = 0; it < kIterations; ++it) {
-        for (int j = 0; j < nRows; ++j) ResolveSplitPenetration(sb, normalRow[j]);
-    }
-    for (int it = 0; it < kIterations; ++it) {
-        for (int j = 0; j < nRows; ++j) ResolveRow(sb, normalRow[j], false);
-        for (int j = 0; j < nRows; ++j) {
-            const float totalImpulse = normalRow[j].applied;
-            if (totalImpulse > 0.0f) {
-                frictionRow[j].lower = -(frictionRow[j].friction * totalImpulse);
-                frictionRow[j].upper = frictionRow[j].friction * totalImpulse;
-                ResolveRow(sb, frictionRow[j], true);
-            }
-        }
-    }
-    for (int j = 0; j < nRows; ++j) {
-        *ref[j].applied = normalRow[j].applied;
-        *ref[j].appliedLat = frictionRow[j].applied;
-    }
-    sb.linVel = Add(sb.linVel, sb.dLin);
-    sb.angVel = Add(sb.angVel, sb.dAng);
-    bool moved = false;
-    if (sb.push.x != 0.0f || sb.push.y != 0.0f || sb.push.z != 0.0f || sb.turn.x != 0.0f || sb.turn.y != 0.0f || sb.turn.z != 0.0f) {
-        b.origin = Add(b.origin, Scale(sb.push, dt));
-        b.orn = bt::IntegrateOrientation(b.orn, Scale(sb.turn, kSplitTurnErp), dt);
-        b.basis = bt::MatFromQuat(b.orn);
-        moved = true;
-    }
-    b.linVel = Add(sb.linVel, sb.extForce);
-    b.angVel = Add(sb.angVel, sb.extTorque);
-    return moved;
-}
+// (the solver for these manifolds: island_ref.h — SolveBody for the island {body}, SolveIsland for several Dynamic bodies)
 
 } // namespace ct
 } // namespace orc

@@ -78,7 +78,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "boxbox_ref.h"
+#include "island_ref.h"
 #include "bullet_math.h"
 #include "contact_ref.h"
 #include "ecs_ref.h"
