@@ -5,8 +5,8 @@ TEST INFRASTRUCTURE (oracle/): reads /root/reference/build/bin/RelWithDebInfo/Sa
 interprets the listing symbolically (oracle/tools/symx.py); nothing in it is loaded or run.  VERDICT r02 item 5.
 
 Every function below is located in the symbol-less exe by what it reaches (constants, callers, vtable slots), executed
-symbolically on the control path the restatement takes (body A a Dynamic rigid body, body B a static object: no rigid body
-behind its solver body; warm starting and split impulse on; no contact flags), and the expression tree of every value it stores
+symbolically on the control paths the restatement takes (body A a Dynamic rigid body; body B a static object — no rigid body
+behind its solver body — or, for oracle/island_ref.h, a second Dynamic rigid body; warm starting and split impulse on; no contact flags), and the expression tree of every value it stores
 is compared with the tree of the restatement, written below in the structure of the C++ (DotXZY, InvMassPlusDot, XformPoint ...
 are the helpers of contact_ref.h).  Trees are normalised for the commutativity of + and x, for the sign rules of neg with x and /
 and for a + (-b) = a - b only — not for associativity: Bullet is built with MSVC /fp:fast in this exe, the compiler reassociated
@@ -126,9 +126,10 @@ def find_setup_contact(text_ins):
     return hits
 
 
-def contact_row_restated(bounce, pen_pos, above_split):
+def contact_row_restated(bounce, pen_pos, above_split, two=False):
     E = _E()
     n, r = vec("cp", 0x40), vec("rp1", 0)
+    r2 = vec("rp2", 0)
     inv_i = [vec("rb0", 0x180), vec("rb0", 0x190), vec("rb0", 0x1A0)]
     ang_f = vec("rb0", 0x2C0)
     inv_mass = I("rb0", 0x1D0)
@@ -140,16 +141,28 @@ def contact_row_restated(bounce, pen_pos, above_split):
     ang_comp = V3(*[a * f for a, f in zip(mat_vec(inv_i, torque_axis), ang_f)])
     v = cross(ang_comp, r)
     denom0 = inv_mass_plus_dot(inv_mass, n, v)
-    jac = sor / ((denom0 + C(0.0)) + inv_dt * cfm)
+    zero = V3(C(0.0), C(0.0), C(0.0))
+    if two:
+        inv_i2 = [vec("rb1", 0x180), vec("rb1", 0x190), vec("rb1", 0x1A0)]
+        torque_axis2 = cross(n, r2)                                        # rel_pos2 x -n
+        ang_comp2 = V3(*[a * f for a, f in zip(mat_vec(inv_i2, torque_axis2), vec("rb1", 0x2C0))])
+        denom1 = inv_mass_plus_dot(I("rb1", 0x1D0), n, cross(r2, ang_comp2))
+        rb_vel2 = add(vec("rb1", 0x1B0), cross(vec("rb1", 0x1C0), r2))
+    else:
+        denom1, rb_vel2 = C(0.0), zero
+    jac = sor / ((denom0 + denom1) + inv_dt * cfm)
     penetration = I("cp", 0x50) + slop
     rb_vel = add(vec("rb0", 0x1B0), cross(vec("rb0", 0x1C0), r))
-    rb_rel = n.x * (rb_vel.x - C(0.0)) + n.y * (rb_vel.y - C(0.0)) + n.z * (rb_vel.z - C(0.0))
+    rb_rel = n.x * (rb_vel.x - rb_vel2.x) + n.y * (rb_vel.y - rb_vel2.y) + n.z * (rb_vel.z - rb_vel2.z)
     restitution = E(("max", (-(rb_rel * I("cp", 0x60))).t, C(0.0).t)) if bounce else E(("max", C(0.0).t, C(0.0).t))
     applied = I("cp", 0x84) * warm
-    b_lin = V3(*[C(0.0) + I("bodyB", 0xB0 + 4 * k) for k in range(3)])
-    b_ang = V3(*[C(0.0) + I("bodyB", 0xC0 + 4 * k) for k in range(3)])
-    zero = V3(C(0.0), C(0.0), C(0.0))
-    vel2 = dot_xzy(b_lin, zero) + dot_xzy(b_ang, zero)          # (body B's side: products with the zeroed normal, exact zeros)
+    if two:
+        l2 = add(vec("bodyB", 0xB0), vec("bodyB", 0xD0))
+        vel2 = dot_xzy(torque_axis2, add(vec("bodyB", 0xC0), vec("bodyB", 0xE0))) + ((-(l2.x * n.x) - l2.z * n.z) - l2.y * n.y)
+    else:
+        b_lin = V3(*[C(0.0) + I("bodyB", 0xB0 + 4 * k) for k in range(3)])
+        b_ang = V3(*[C(0.0) + I("bodyB", 0xC0 + 4 * k) for k in range(3)])
+        vel2 = dot_xzy(b_lin, zero) + dot_xzy(b_ang, zero)          # (body B's side: products with the zeroed normal, exact zeros)
     vel1 = dot_xzy(n, lin) + dot_xzy(torque_axis, ang)
     rel_vel = vel2 + vel1
     velocity_error = restitution - rel_vel
@@ -179,7 +192,16 @@ def contact_row_restated(bounce, pen_pos, above_split):
         nk, ik, lk = list(n)[k], list(inv_m)[k], list(lin_f)[k]
         body[0x40 + 4 * k] = I("bodyA", 0x40 + 4 * k) + lk * ((ik * nk) * applied)
         body[0x50 + 4 * k] = I("bodyA", 0x50 + 4 * k) + list(ang_comp)[k] * (list(ang_f2)[k] * applied)
-    return out, body
+    body_b = {}
+    if two:
+        lin_fb, ang_fb, inv_mb = vec("bodyB", 0x70), vec("bodyB", 0x60), vec("bodyB", 0x80)
+        for k in range(3):
+            out[0x20 + 4 * k] = list(torque_axis2)[k]
+            out[0x30 + 4 * k] = -list(n)[k]
+            out[0x50 + 4 * k] = list(ang_comp2)[k]
+            body_b[0x40 + 4 * k] = I("bodyB", 0x40 + 4 * k) - list(lin_fb)[k] * ((list(inv_mb)[k] * list(n)[k]) * applied)
+            body_b[0x50 + 4 * k] = I("bodyB", 0x50 + 4 * k) + list(ang_comp2)[k] * (list(ang_fb)[k] * applied)
+    return out, body, body_b
 
 
 def check_setup_contact(pe, all_ins):
@@ -198,25 +220,29 @@ def check_setup_contact(pe, all_ins):
         reg = ins[i][2].split(",")[1]
         hooks[ins[i + 1][0]] = (lambda name: (lambda m, r=reg: m.gpr.__setitem__(r, P(name))))("bodyB" if reg == "%r8" else "bodyA")
     good = True
-    for variant in ((True, False, True), (False, True, True), (False, False, False), (True, True, True)):
-        bounce, pen_pos, above = variant
+    for variant in ((True, False, True, False), (False, True, True, False), (False, False, False, False), (True, True, True, False),
+                    (True, False, False, True), (False, True, True, True), (False, False, True, True)):
+        bounce, pen_pos, above, two = variant
 
         def decider(m, pc, mn, lf, v=variant):
             _, fm, fo = lf
-            table = {("test", "%r9,%r9"): False, ("test", "%r11,%r11"): True, ("test", "$0x6,%al"): False, ("test", "$0x8,%al"): True,
-                     ("testb", "$0x4,0x58(%rbx)"): False, ("cmp", "%rsi,0xf0(%r10)"): False, ("cmp", "%rsi,0xf0(%r8)"): True,
+            table = {("test", "%r9,%r9"): False, ("test", "%r11,%r11"): not v[3], ("test", "$0x6,%al"): False, ("test", "$0x8,%al"): True,
+                     ("testb", "$0x4,0x58(%rbx)"): False, ("cmp", "%rsi,0xf0(%r10)"): False, ("cmp", "%rsi,0xf0(%r8)"): not v[3],
                      ("cmp", "%esi,0x40(%rbx)"): False, ("comiss", "0x70(%rbx),%xmm0"): v[0], ("comiss", "%xmm13,%xmm11"): not v[1],
                      ("comiss", "0x44(%rbx),%xmm11"): v[2]}
             return table.get((fm, fo))
         m = Machine(pe, ins, gpr={"%rcx": P("solver"), "%rdx": P("sc"), "%r8": ("int", 1), "%r9": ("int", 0)},
                     stack_ptrs={0x28: P("cp"), 0x30: P("info"), 0x38: P("relax"), 0x40: P("rp1"), 0x48: P("rp2")},
-                    ptr_loads={("bodyA", 0xF0): P("rb0"), ("bodyB", 0xF0): ("int", 0)}, pc_hooks=hooks)
+                    ptr_loads={("bodyA", 0xF0): P("rb0"), ("bodyB", 0xF0): P("rb1") if two else ("int", 0)}, pc_hooks=hooks)
+        if two:
+            m.gpr["%r9"] = ("int", 2)
         m.decider = decider
         m.run()
-        want, body = contact_row_restated(*variant)
+        want, body, body_b = contact_row_restated(*variant)
         pairs = [(f"solverConstraint+{k:#x}", m.mem[("sc", k)], w) for k, w in want.items()]
         pairs += [(f"solverBodyA+{k:#x}", m.mem[("bodyA", k)], w) for k, w in body.items()]
-        good &= report(f"  path (|rel_vel| >= threshold: {bounce}, penetration > 0: {pen_pos}, above the split threshold: {above})", pairs)
+        pairs += [(f"solverBodyB+{k:#x}", m.mem[("bodyB", k)], w) for k, w in body_b.items()]
+        good &= report(f"  path ({'two rigid bodies' if two else 'body B static'}; |rel_vel| >= threshold: {bounce}, penetration > 0: {pen_pos}, above the split threshold: {above})", pairs)
     return good
 
 
@@ -245,8 +271,9 @@ def direct_calls(pe, ins):
     return [(pc, _resolve(pe, int(ops, 16))) for pc, mn, ops in ins if mn == "call" and re.fullmatch(r"0x[0-9a-f]+", ops)]
 
 
-def friction_row_restated():
+def friction_row_restated(two=False):
     t, r = vec("axis", 0), vec("rp1", 0)
+    r2 = vec("rp2", 0)
     inv_i = [vec("rb0", 0x180), vec("rb0", 0x190), vec("rb0", 0x1A0)]
     ang_f = vec("rb0", 0x2C0)
     inv_mass = I("rb0", 0x1D0)
@@ -256,16 +283,27 @@ def friction_row_restated():
     c = cross(r, t)
     ang_comp = V3(*[a * f for a, f in zip(mat_vec(inv_i, c), ang_f)])
     v = cross(ang_comp, r)
-    jac = relax / (inv_mass_plus_dot(inv_mass, t, v) + C(0.0))
     vel1 = dot_xzy(t, lin) + dot_xzy(c, ang)
-    z = C(0.0)
-    rel_vel = (vel1 + z * z) + (z * z + z * z) + ((z * z + z * z) + z * z)     # (body B's side: exact zeros, as compiled)
+    if two:
+        c2 = cross(t, r2)
+        ang_comp2 = V3(*[a * f for a, f in zip(mat_vec([vec("rb1", 0x180), vec("rb1", 0x190), vec("rb1", 0x1A0)], c2), vec("rb1", 0x2C0))])
+        jac = relax / (inv_mass_plus_dot(inv_mass, t, v) + inv_mass_plus_dot(I("rb1", 0x1D0), t, cross(r2, ang_comp2)))
+        l2 = add(vec("bodyB", 0xB0), vec("bodyB", 0xD0))
+        rel_vel = dot_xzy(c2, vec("bodyB", 0xC0)) + ((vel1 - l2.z * t.z) + (-(l2.x * t.x) - l2.y * t.y))
+    else:
+        jac = relax / (inv_mass_plus_dot(inv_mass, t, v) + C(0.0))
+        z = C(0.0)
+        rel_vel = (vel1 + z * z) + (z * z + z * z) + ((z * z + z * z) + z * z)     # (body B's side: exact zeros, as compiled)
     out = {0x84: jac, 0x88: C(0.0) + jac * (desired - rel_vel), 0x8C: cfm_slip, 0x90: -I("cp", 0x54), 0x94: I("cp", 0x54), 0x80: I("cp", 0x54)}
     for k in range(3):
         out[4 * k] = list(c)[k]
         out[0x10 + 4 * k] = list(t)[k]
         out[0x40 + 4 * k] = list(ang_comp)[k]
         out[0x70 + 4 * k] = C(0.0)        # m_appliedImpulse
+        if two:
+            out[0x20 + 4 * k] = list(c2)[k]
+            out[0x30 + 4 * k] = -list(t)[k]
+            out[0x50 + 4 * k] = list(ang_comp2)[k]
     return out
 
 
@@ -297,17 +335,19 @@ def check_friction_and_convert(pe, setup_va):
     def sethook(m):
         m.gpr["%rcx"], m.gpr["%r11"], m.gpr["%r10"] = P("bodyB"), P("bodyA"), ("int", 0)
 
-    def decider(m, pc, mn, lf):
-        table = {("test", "%rbx,%rbx"): False, ("test", "%rdi,%rdi"): True, ("testb", "$0x10,0x80(%r9)"): True}
-        return table.get((lf[1], lf[2]))
-    m = Machine(pe, ins, gpr={"%rcx": P("solver"), "%rdx": P("sc"), "%r8": P("axis"), "%r9": ("int", 0)},
-                stack_ptrs={0x30: P("cp"), 0x38: P("rp1"), 0x40: P("rp2"), 0x48: P("colObj0"), 0x50: P("colObj1"), 0x60: P("info")},
-                ptr_loads={("bodyA", 0xF0): P("rb0"), ("bodyB", 0xF0): ("int", 0)}, pc_hooks={first_indexed: sethook})
-    m.decider = decider
-    m.run()
-    want = friction_row_restated()
-    good = report(f"setupFrictionConstraint at VA {setup_friction:#x} (through addFrictionConstraint at {add_friction:#x})",
-                  [(f"solverConstraint+{k:#x}", m.mem[("sc", k)], w) for k, w in want.items()])
+    good = True
+    for two in (False, True):
+        def decider(m, pc, mn, lf, two=two):
+            table = {("test", "%rbx,%rbx"): False, ("test", "%rdi,%rdi"): not two, ("testb", "$0x10,0x80(%r9)"): True}
+            return table.get((lf[1], lf[2]))
+        m = Machine(pe, ins, gpr={"%rcx": P("solver"), "%rdx": P("sc"), "%r8": P("axis"), "%r9": ("int", 0)},
+                    stack_ptrs={0x30: P("cp"), 0x38: P("rp1"), 0x40: P("rp2"), 0x48: P("colObj0"), 0x50: P("colObj1"), 0x60: P("info")},
+                    ptr_loads={("bodyA", 0xF0): P("rb0"), ("bodyB", 0xF0): P("rb1") if two else ("int", 0)}, pc_hooks={first_indexed: sethook})
+        m.decider = decider
+        m.run()
+        want = friction_row_restated(two)
+        good &= report(f"setupFrictionConstraint at VA {setup_friction:#x} (through addFrictionConstraint at {add_friction:#x}; {'two rigid bodies' if two else 'body B static'})",
+                       [(f"solverConstraint+{k:#x}", m.mem[("sc", k)], w) for k, w in want.items()])
     # ---- convertContact: no read of cp.m_appliedImpulseLateral1, friction row's m_appliedImpulse zeroed after the last call
     # %rdi walks the manifold points at +0xb4 from each point's start in this function
     lea = next((ops for pc, mn, ops in cc if mn == "lea" and re.fullmatch(r"0xc4\(%r14\),%rdi", ops)), None)
@@ -344,44 +384,51 @@ def check_friction_and_convert(pe, setup_va):
         rec["axis"] = [m.cell((a[1], a[2] + 4 * k)) for k in range(3)]
         raise Stop()
 
-    def decider2(m, pc, mn, lf):
-        table = {("cmpq", "$0x0,0xf0(%r9)"): False, ("cmpq", "$0x0,0xf0(%rdx)"): True, ("comiss", "-0x5c(%rdi),%xmm9"): True,
-                 ("testb", "$0x20,0x58(%rbx)"): True, ("testb", "$0x40,0x58(%rax)"): False}
-        if lf[1] == "comiss" and "(%rip)" in lf[2] and mn == "jbe":
-            return False                           # lat_rel_vel > SIMD_EPSILON
-        return table.get((lf[1], lf[2]))
     from check_bullet_order import _resolve
     aniso = Counter(t for pc, t in calls if pc > start and t not in (setup_va, add_friction)).most_common(1)[0][0]
-    m = Machine(pe, cc, gpr={"%r9": P("bodyA"), "%rdx": P("bodyB"), "%rdi": P("cp", 0xB4), "%r12": P("colObj0"), "%r13": P("colObj1"), "%rsi": P("solver"),
-                             "%rbx": P("info"), "%rax": P("sc"), "%rbp": P("stk", -0x100), "%r15": P("cp"), "%r14": ("int", 0), "%r10": ("int", 1), "%rcx": ("int", 0)},
-                hooks={setup_va: at_setup, aniso: at_aniso, add_friction: at_add_friction})
-    m.gpr["%rsp"] = P("stk", -0x300)
-    m.memp[("stk", -0x100 - 0x60)] = P("sc")
-    m.memp[("stk", -0x100 + 0x110)] = P("info")
-    m.xmm["%xmm9"] = [("const", 0.0)] * 4
-    m.xmm["%xmm14"] = [("signmask",)] * 4
-    m.decider = decider2
-    try:
-        m.run(start=start)
-    except Stop:
-        pass
-    lin = add(vec("bodyA", 0xB0), vec("bodyA", 0xD0))
-    ang = add(vec("bodyA", 0xC0), vec("bodyA", 0xE0))
-    rp1 = sub(vec("cp", 0x30), vec("colObj0", 0x40))
-    rp2 = sub(vec("cp", 0x20), vec("colObj1", 0x40))
-    vel1 = add(lin, cross(ang, rp1))
-    vel = sub(vel1, V3(C(0.0), C(0.0), C(0.0)))
-    n = vec("cp", 0x40)
-    rel_vel = dot(vel, n)
-    d = sub(vel, scale(n, rel_vel))
-    inv_len = 1.0 / _E()(("sqrtf", dot(d, d).t))
-    axis = scale(d, inv_len)
-    pairs = [(f"rel_pos1.{c}", g, w) for c, g, w in zip("xyz", rec.get("rp1", [("missing",)] * 3), rp1)]
-    pairs += [(f"rel_pos2.{c}", g, w) for c, g, w in zip("xyz", rec.get("rp2", [("missing",)] * 3), rp2)]
-    pairs += [(f"vel.{c}", g, w) for c, g, w in zip("xyz", rec.get("vel", [("missing",)] * 3), vel)]
-    pairs += [("rel_vel", rec.get("rel_vel", ("missing",)), rel_vel)]
-    pairs += [(f"lateral direction.{c}", g, w) for c, g, w in zip("xyz", rec.get("axis", [("missing",)] * 3), axis)]
-    good &= report("convertContact's loop body (rel_pos, getVelocityInLocalPointNoDelta, rel_vel, the normalised lateral direction)", pairs)
+    for two in (False, True):
+        rec.clear()
+
+        def decider2(m, pc, mn, lf, two=two):
+            table = {("cmpq", "$0x0,0xf0(%r9)"): False, ("cmpq", "$0x0,0xf0(%rdx)"): not two, ("comiss", "-0x5c(%rdi),%xmm9"): True,
+                     ("testb", "$0x20,0x58(%rbx)"): True, ("testb", "$0x40,0x58(%rax)"): False}
+            if lf[1] == "comiss" and "(%rip)" in lf[2] and mn == "jbe":
+                return False                           # lat_rel_vel > SIMD_EPSILON
+            return table.get((lf[1], lf[2]))
+        m = Machine(pe, cc, gpr={"%r9": P("bodyA"), "%rdx": P("bodyB"), "%rdi": P("cp", 0xB4), "%r12": P("colObj0"), "%r13": P("colObj1"), "%rsi": P("solver"),
+                                 "%rbx": P("info"), "%rax": P("sc"), "%rbp": P("stk", -0x100), "%r15": P("cp"), "%r14": ("int", 0), "%r10": ("int", 1), "%rcx": ("int", 0)},
+                    hooks={setup_va: at_setup, aniso: at_aniso, add_friction: at_add_friction})
+        m.gpr["%rsp"] = P("stk", -0x300)
+        m.memp[("stk", -0x100 - 0x60)] = P("sc")
+        m.memp[("stk", -0x100 + 0x110)] = P("info")
+        m.xmm["%xmm9"] = [("const", 0.0)] * 4
+        m.xmm["%xmm14"] = [("signmask",)] * 4
+        m.decider = decider2
+        try:
+            m.run(start=start)
+        except Stop:
+            pass
+        lin = add(vec("bodyA", 0xB0), vec("bodyA", 0xD0))
+        ang = add(vec("bodyA", 0xC0), vec("bodyA", 0xE0))
+        rp1 = sub(vec("cp", 0x30), vec("colObj0", 0x40))
+        rp2 = sub(vec("cp", 0x20), vec("colObj1", 0x40))
+        vel1 = add(lin, cross(ang, rp1))
+        if two:
+            vel2 = add(add(vec("bodyB", 0xB0), vec("bodyB", 0xD0)), cross(add(vec("bodyB", 0xC0), vec("bodyB", 0xE0)), rp2))
+        else:
+            vel2 = V3(C(0.0), C(0.0), C(0.0))
+        vel = sub(vel1, vel2)
+        n = vec("cp", 0x40)
+        rel_vel = dot(vel, n)
+        d = sub(vel, scale(n, rel_vel))
+        inv_len = 1.0 / _E()(("sqrtf", dot(d, d).t))
+        axis = scale(d, inv_len)
+        pairs = [(f"rel_pos1.{c}", g, w) for c, g, w in zip("xyz", rec.get("rp1", [("missing",)] * 3), rp1)]
+        pairs += [(f"rel_pos2.{c}", g, w) for c, g, w in zip("xyz", rec.get("rp2", [("missing",)] * 3), rp2)]
+        pairs += [(f"vel.{c}", g, w) for c, g, w in zip("xyz", rec.get("vel", [("missing",)] * 3), vel)]
+        pairs += [("rel_vel", rec.get("rel_vel", ("missing",)), rel_vel)]
+        pairs += [(f"lateral direction.{c}", g, w) for c, g, w in zip("xyz", rec.get("axis", [("missing",)] * 3), axis)]
+        good &= report(f"convertContact's loop body ({'two rigid bodies' if two else 'body B static'}: rel_pos, getVelocityInLocalPointNoDelta, rel_vel, the normalised lateral direction)", pairs)
     return good and fact
 
 
