@@ -243,6 +243,34 @@ int orc_get_box_contacts(void* h, uint32_t id, uint32_t* hdr8, float* out192)
     }
     return static_cast<int>(boxes.size());
 }
+// Dynamic boxes against each other (island_ref.h, physics_ref.h CollideDynamicPairs / StepIsland)
+void orc_set_dynamic_contacts(void* h, int enabled) { S(h)->physics.dynamicContacts = enabled != 0; }
+// the pair cache of Dynamic boxes in ascending (lower entity, higher entity): returns how many pairs there are; for the first `cap`
+// of them hdr[3 k ..] = lower entity, higher entity, points and 4 x 12 floats as orc_get_box_contacts lays a point out
+int orc_get_dynamic_pairs(void* h, int cap, uint32_t* hdr, float* out)
+{
+    const auto& pairs = S(h)->physics.DynamicPairs();
+    int k = 0;
+    for (const auto& kv : pairs) {
+        if (k >= cap) break;
+        const auto& m = kv.second.m;
+        hdr[3 * k] = kv.first.first;
+        hdr[3 * k + 1] = kv.first.second;
+        hdr[3 * k + 2] = static_cast<uint32_t>(m.n);
+        for (int j = 0; j < 4; ++j) {
+            float* o = out + 48 * k + 12 * j;
+            for (int q = 0; q < 12; ++q) o[q] = 0.0f;
+            if (j >= m.n) continue;
+            const auto& c = m.p[j];
+            o[0] = c.localA.x; o[1] = c.localA.y; o[2] = c.localA.z;
+            o[3] = c.localB.x; o[4] = c.localB.y; o[5] = c.localB.z;
+            o[6] = c.normalB.x; o[7] = c.normalB.y; o[8] = c.normalB.z;
+            o[9] = c.distance; o[10] = c.appliedImpulse; o[11] = c.appliedImpulseLateral1;
+        }
+        ++k;
+    }
+    return static_cast<int>(pairs.size());
+}
 uint64_t orc_count_dirty(void* h) { return S(h)->scene.CountDirtyTransforms(); }
 uint64_t orc_transform_count(void* h) { return S(h)->scene.GetTransformCount(); }
 

@@ -75,6 +75,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -117,6 +118,8 @@ struct RefBodyRuntime {
     std::vector<ct::BoxManifold> boxes;
     std::vector<uint32_t> boxGeneration; // generation of the other body when the manifold was made (a re-created body is a new pair)
     uint32_t generation = 0;             // bumped whenever the btRigidBody is (re)created
+    bool collidedGround = false;         // (scratch of one sub-step: the plane pair was collided)
+    bool hadGravity = true;              // applyGravity of this stepSimulation call reached the body (it was not asleep then)
 };
 
 // Trigger volumes.  Follows:
@@ -196,8 +199,17 @@ public:
     // what the reference's world does for every pair the dispatcher accepts (PhysicsSystem.cpp:122-128); capsules against boxes
     // (GJK / EPA) are not restated.  Off by default, like the plane: BASELINE's workloads are free bodies.
     bool staticContacts = false;
+    // Dynamic boxes collide with each other (btBoxBoxCollisionAlgorithm per pair, simulation islands of several bodies solved
+    // together and put to sleep together: island_ref.h and CollideDynamicPairs / StepIsland below).  Off by default.
+    bool dynamicContacts = false;
+
+    struct DynPair {
+        ct::BoxManifold m;
+        uint32_t genA = 0, genB = 0;
+    };
 
     std::unordered_map<EntityId, RefBodyRuntime>& Runtimes() { return runtime_; }
+    const std::map<std::pair<EntityId, EntityId>, DynPair>& DynamicPairs() const { return dynPairs_; }
     std::unordered_map<EntityId, RefTriggerRuntime>& TriggerRuntimes() { return triggerRuntime_; }
     const std::vector<RefTriggerEvent>& LastTriggerEvents() const { return events_; }
 
@@ -245,6 +257,8 @@ public:
             run = std::min(due, maxSubSteps);
             step = fixedStep;
         }
+        // applyGravity, once per stepSimulation call: only bodies that are active then
+        for (auto& kv : runtime_) kv.second.hadGravity = kv.second.activation != kIslandSleeping;
         for (int k = 0; k < run; ++k) StepSimulation(step);
         SyncRigidBodiesFromPhysics(scene);
         ProcessTriggerEvents(scene, run == 0);
@@ -353,7 +367,7 @@ private:
         const bt::Vec3 g{0.0f, gravityY, 0.0f};
         // predictUnconstraintMotion + updateAabbs for every body, from the state the sub-step starts with (a body's fed box
         // depends on nothing but its own state, so this pass is what the per-body loop below used to do in place)
-        if (computeAabbs || staticContacts) {
+        if (computeAabbs || staticContacts || dynamicContacts) {
             for (auto& kv : runtime_) {
                 RefBodyRuntime& rt = kv.second;
                 if (!rt.hasBody) continue;
@@ -385,87 +399,260 @@ private:
             }
             std::sort(obstacles.begin(), obstacles.end());
         }
+        // performDiscreteCollisionDetection for the pairs of Dynamic boxes, then the islands they form (calculateSimulationIslands)
+        std::unordered_map<EntityId, std::vector<EntityId>> islands; // lowest entity of a multi-body island -> its bodies, ascending
+        std::unordered_map<EntityId, EntityId> islandOf;             // body of a multi-body island -> that lowest entity
+        if (dynamicContacts) CollideDynamicPairs(islands, islandOf);
+
         for (auto& kv : runtime_) {
             RefBodyRuntime& rt = kv.second;
             if (!rt.hasBody) continue;
             const bool dynamic = rt.type == RefBodyType::Dynamic && rt.invMass != 0.0f;
             if (!dynamic) continue;
-            const bool spinning = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
-
             // performDiscreteCollisionDetection comes BEFORE the island build: a body that wants to sleep (isActive() is still true
             // for WANTS_DEACTIVATION) is collided once more — its manifolds are refreshed — and only then falls asleep; a sleeping
             // body's pairs with static objects are skipped (btCollisionDispatcher::needsCollision: neither object is active)
-            const bool collides = rt.activation != kIslandSleeping;
-            const bool withGround = collides && groundPlane && (rt.mask & 2u) != 0u;
-            if (withGround) {
-                // the pair (ground, body): group StaticFilter = 2 against the body's mask, the body's group against AllFilter
-                ct::CollideWithGround(rt.ground, rt.shape, rt.contactBreakingThreshold, rt.origin, rt.basis);
-            }
-            if (collides && staticContacts && !rt.shape.capsule) CollideWithBoxes(kv.first, rt, obstacles);
+            rt.collidedGround = CollideOwn(kv.first, rt, obstacles);
+        }
+        for (auto& kv : runtime_) {
+            RefBodyRuntime& rt = kv.second;
+            if (!rt.hasBody) continue;
+            const bool dynamic = rt.type == RefBodyType::Dynamic && rt.invMass != 0.0f;
+            if (!dynamic || islandOf.count(kv.first)) continue;
+            StepFreeBody(rt, g, dt);
+        }
+        for (auto& isl : islands) StepIsland(isl.second, g, dt);
+    }
 
-            // buildIslands: a free body is a one-body island; "all sleeping" unless ACTIVE_TAG / DISABLE_DEACTIVATION
-            if (rt.activation == kWantsDeactivation) rt.activation = kIslandSleeping;
-            if (rt.activation == kIslandSleeping) {
-                // no gravity (it was asleep when applyGravity ran, or its force is dropped by clearForces), not solved,
-                // not integrated; updateActivationState zeroes the velocities of a sleeping body every step
-                rt.linvel = bt::Vec3{0, 0, 0};
-                rt.angvel = bt::Vec3{0, 0, 0};
-                continue;
-            }
+    // a Dynamic body's own pairs: the plane and the Static / Kinematic boxes; returns whether the plane pair was collided
+    bool CollideOwn(EntityId self, RefBodyRuntime& rt, const std::vector<std::pair<EntityId, const RefBodyRuntime*>>& obstacles)
+    {
+        const bool collides = rt.activation != kIslandSleeping;
+        const bool withGround = collides && groundPlane && (rt.mask & 2u) != 0u;
+        if (withGround) {
+            // the pair (ground, body): group StaticFilter = 2 against the body's mask, the body's group against AllFilter
+            ct::CollideWithGround(rt.ground, rt.shape, rt.contactBreakingThreshold, rt.origin, rt.basis);
+        }
+        if (collides && staticContacts && !rt.shape.capsule) CollideWithBoxes(self, rt, obstacles);
+        return withGround;
+    }
 
-            // applyGravity + solver write-back of the external force impulse.  m_gravity = acceleration / m_inverseMass:
-            // a division per component in the reference's build (btRigidBody::setGravity, check_bullet_order.py)
-            const bt::Vec3 force{g.x / rt.invMass, g.y / rt.invMass, g.z / rt.invMass};
-            bool solved = false;
-            bool touching = withGround && rt.ground.n > 0;
-            for (const ct::BoxManifold& bm : rt.boxes) touching = touching || bm.n > 0;
-            if ((withGround || !rt.boxes.empty()) && (touching || spinning)) {
-                // the island {body} through the solver.  A body without a contact and without angular velocity takes the plain
-                // update below — the same arithmetic, (v + 0) + impulse.
-                ct::BodyState b{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
-                const bool moved = ct::SolveBody(b, withGround ? &rt.ground : nullptr, rt.boxes.data(), static_cast<int>(rt.boxes.size()), rt.invMass,
-                                                 rt.invInertiaLocal, rt.friction, force, dt);
-                rt.linvel = b.linVel;
-                rt.angvel = b.angVel;
-                if (moved) { // the split impulse corrected the pose
-                    rt.origin = b.origin;
-                    rt.orn = b.orn;
-                    rt.basis = b.basis;
-                    rt.freshPose = true;
-                }
-                solved = true;
-            }
-            if (!solved) {
-                rt.linvel.x = rt.linvel.x + (force.x * rt.invMass) * dt;
-                rt.linvel.y = rt.linvel.y + (force.y * rt.invMass) * dt;
-                rt.linvel.z = rt.linvel.z + (force.z * rt.invMass) * dt;
-            }
-            // integrateTransforms (with the velocities the solver left)
-            const bool spinningNow = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
-            const bool rotateNow = orientMode != kOrientIdeal || spinningNow;
-            rt.origin.x = rt.origin.x + rt.linvel.x * dt;
-            rt.origin.y = rt.origin.y + rt.linvel.y * dt;
-            rt.origin.z = rt.origin.z + rt.linvel.z * dt;
-            if (rotateNow) {
-                rt.orn = bt::IntegrateOrientation(CurrentOrn(rt), rt.angvel, dt);
-                rt.basis = bt::MatFromQuat(rt.orn);
+    // the island {body}: build, solve, integrate, updateActivationState
+    void StepFreeBody(RefBodyRuntime& rt, const bt::Vec3& g, float dt)
+    {
+        const bool withGround = rt.collidedGround;
+        const bool spinning = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
+        // buildIslands: a free body is a one-body island; "all sleeping" unless ACTIVE_TAG / DISABLE_DEACTIVATION
+        if (rt.activation == kWantsDeactivation) rt.activation = kIslandSleeping;
+        if (rt.activation == kIslandSleeping) {
+            // no gravity (it was asleep when applyGravity ran, or its force is dropped by clearForces), not solved,
+            // not integrated; updateActivationState zeroes the velocities of a sleeping body every step
+            rt.linvel = bt::Vec3{0, 0, 0};
+            rt.angvel = bt::Vec3{0, 0, 0};
+            return;
+        }
+
+        // applyGravity + solver write-back of the external force impulse.  m_gravity = acceleration / m_inverseMass:
+        // a division per component in the reference's build (btRigidBody::setGravity, check_bullet_order.py)
+        const bt::Vec3 force = rt.hadGravity ? bt::Vec3{g.x / rt.invMass, g.y / rt.invMass, g.z / rt.invMass} : bt::Vec3{0, 0, 0};
+        bool solved = false;
+        bool touching = withGround && rt.ground.n > 0;
+        for (const ct::BoxManifold& bm : rt.boxes) touching = touching || bm.n > 0;
+        if ((withGround || !rt.boxes.empty()) && (touching || spinning)) {
+            // the island {body} through the solver.  A body without a contact and without angular velocity takes the plain
+            // update below — the same arithmetic, (v + 0) + impulse.
+            ct::BodyState b{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
+            const bool moved = ct::SolveBody(b, withGround ? &rt.ground : nullptr, rt.boxes.data(), static_cast<int>(rt.boxes.size()), rt.invMass,
+                                             rt.invInertiaLocal, rt.friction, force, dt);
+            rt.linvel = b.linVel;
+            rt.angvel = b.angVel;
+            if (moved) { // the split impulse corrected the pose
+                rt.origin = b.origin;
+                rt.orn = b.orn;
+                rt.basis = b.basis;
                 rt.freshPose = true;
             }
+            solved = true;
+        }
+        if (!solved) {
+            rt.linvel.x = rt.linvel.x + (force.x * rt.invMass) * dt;
+            rt.linvel.y = rt.linvel.y + (force.y * rt.invMass) * dt;
+            rt.linvel.z = rt.linvel.z + (force.z * rt.invMass) * dt;
+        }
+        IntegrateAndUpdateActivation(rt, dt);
+    }
 
-            // updateActivationState: updateDeactivation + wantsSleeping (state is ACTIVE_TAG here)
-            if (rt.activation != kDisableDeactivation) {
-                const float lin2 = rt.linvel.x * rt.linvel.x + rt.linvel.y * rt.linvel.y + rt.linvel.z * rt.linvel.z;
-                const float ang2 = rt.angvel.x * rt.angvel.x + rt.angvel.y * rt.angvel.y + rt.angvel.z * rt.angvel.z;
-                if (lin2 < linearSleepingThreshold * linearSleepingThreshold &&
-                    ang2 < angularSleepingThreshold * angularSleepingThreshold) {
-                    rt.deactivationTime = rt.deactivationTime + dt;
-                } else {
-                    rt.deactivationTime = 0.0f;
-                }
-                // wantsSleeping: never while gDisableDeactivation or gDeactivationTime == 0
-                if (deactivation && deactivationTimeLimit != 0.0f && rt.deactivationTime > deactivationTimeLimit)
-                    rt.activation = kWantsDeactivation;
+    // integrateTransforms (with the velocities the solver left) and updateActivationState for an active body
+    void IntegrateAndUpdateActivation(RefBodyRuntime& rt, float dt)
+    {
+        const bool spinningNow = rt.angvel.x != 0.0f || rt.angvel.y != 0.0f || rt.angvel.z != 0.0f;
+        const bool rotateNow = orientMode != kOrientIdeal || spinningNow;
+        rt.origin.x = rt.origin.x + rt.linvel.x * dt;
+        rt.origin.y = rt.origin.y + rt.linvel.y * dt;
+        rt.origin.z = rt.origin.z + rt.linvel.z * dt;
+        if (rotateNow) {
+            rt.orn = bt::IntegrateOrientation(CurrentOrn(rt), rt.angvel, dt);
+            rt.basis = bt::MatFromQuat(rt.orn);
+            rt.freshPose = true;
+        }
+
+        // updateActivationState: updateDeactivation + wantsSleeping.  The state is ACTIVE_TAG here, or — in an island of several
+        // bodies that is kept awake by another body — WANTS_DEACTIVATION: such a body stays that way while it is slow
+        // (wantsSleeping() is true for the state itself) and turns ACTIVE_TAG again, timer 0, once it is faster than the thresholds
+        if (rt.activation != kDisableDeactivation) {
+            const float lin2 = rt.linvel.x * rt.linvel.x + rt.linvel.y * rt.linvel.y + rt.linvel.z * rt.linvel.z;
+            const float ang2 = rt.angvel.x * rt.angvel.x + rt.angvel.y * rt.angvel.y + rt.angvel.z * rt.angvel.z;
+            bool fast = false;
+            if (lin2 < linearSleepingThreshold * linearSleepingThreshold &&
+                ang2 < angularSleepingThreshold * angularSleepingThreshold) {
+                rt.deactivationTime = rt.deactivationTime + dt;
+            } else {
+                rt.deactivationTime = 0.0f;
+                fast = true; // setActivationState(0)
             }
+            // wantsSleeping: never while gDisableDeactivation or gDeactivationTime == 0
+            const bool may = deactivation && deactivationTimeLimit != 0.0f;
+            if (rt.activation == kWantsDeactivation) {
+                if (fast || !may) rt.activation = kActiveTag;
+            } else if (may && rt.deactivationTime > deactivationTimeLimit) {
+                rt.activation = kWantsDeactivation;
+            }
+        }
+    }
+
+    // Pairs of Dynamic boxes.  As everywhere the pair cache is its history-free core: the fed AABBs overlap (non-strictly) and the
+    // filter passes both ways; body A (the manifold's body0) is the lower entity id.  A pair is collided when at least one of
+    // the two is active (btCollisionDispatcher::needsCollision; WANTS_DEACTIVATION counts as active), its manifold lives as long
+    // as the pair and both btRigidBody generations.  btSimulationIslandManager::findUnions unites the two bodies of EVERY pair in
+    // the cache, touching or not, asleep or not.
+
+    void CollideDynamicPairs(std::unordered_map<EntityId, std::vector<EntityId>>& islands, std::unordered_map<EntityId, EntityId>& islandOf)
+    {
+        std::vector<EntityId> ids;
+        for (const auto& kv : runtime_) {
+            const RefBodyRuntime& rt = kv.second;
+            if (rt.hasBody && rt.type == RefBodyType::Dynamic && rt.invMass != 0.0f && !rt.shape.capsule) ids.push_back(kv.first);
+        }
+        std::sort(ids.begin(), ids.end(), [&](EntityId a, EntityId b) {
+            const float xa = runtime_[a].aabbMin[0], xb = runtime_[b].aabbMin[0];
+            return xa < xb || (xa == xb && a < b);
+        });
+        std::map<std::pair<EntityId, EntityId>, DynPair> next;
+        std::unordered_map<EntityId, EntityId> parent;
+        auto find = [&](EntityId e) {
+            while (true) {
+                auto it = parent.find(e);
+                if (it == parent.end() || it->second == e) return e;
+                e = it->second;
+            }
+        };
+        for (size_t i = 0; i < ids.size(); ++i) {
+            const RefBodyRuntime& p = runtime_[ids[i]];
+            for (size_t j = i + 1; j < ids.size(); ++j) {
+                const RefBodyRuntime& q = runtime_[ids[j]];
+                if (!(q.aabbMin[0] <= p.aabbMax[0])) break;
+                if (!BoxesOverlap(p.aabbMin, p.aabbMax, q.aabbMin, q.aabbMax)) continue;
+                if ((p.layer & q.mask) == 0 || (q.layer & p.mask) == 0) continue;
+                const EntityId ea = std::min(ids[i], ids[j]), eb = std::max(ids[i], ids[j]);
+                RefBodyRuntime& a = runtime_[ea];
+                RefBodyRuntime& b = runtime_[eb];
+                DynPair e;
+                auto old = dynPairs_.find({ea, eb});
+                if (old != dynPairs_.end() && old->second.genA == a.generation && old->second.genB == b.generation) {
+                    e = old->second;
+                } else {
+                    e.genA = a.generation;
+                    e.genB = b.generation;
+                    e.m.other = eb;
+                    e.m.breaking = std::min(a.contactBreakingThreshold, b.contactBreakingThreshold);
+                    e.m.friction = std::max(-10.0f, std::min(10.0f, a.friction * b.friction));
+                    e.m.restitution = a.restitution * b.restitution;
+                }
+                if (a.activation != kIslandSleeping || b.activation != kIslandSleeping) {
+                    const ct::BoxPose pa{a.origin, a.basis, a.shape.dims}, pb{b.origin, b.basis, b.shape.dims};
+                    ct::CollideBoxBox(e.m, pa, pb);
+                }
+                next[{ea, eb}] = e;
+                const EntityId ra = find(ea), rb = find(eb);
+                parent.emplace(ea, ea);
+                parent.emplace(eb, eb);
+                if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+            }
+        }
+        dynPairs_.swap(next);
+        for (const auto& kv : parent) {
+            const EntityId root = find(kv.first);
+            islandOf[kv.first] = root;
+            islands[root].push_back(kv.first);
+        }
+        for (auto& kv : islands) std::sort(kv.second.begin(), kv.second.end());
+    }
+
+    // One island of several Dynamic bodies (ascending entity id): btSimulationIslandManager::buildIslands' activation rule, then
+    // solveGroup over all its manifolds (island_ref.h), integrateTransforms and updateActivationState body by body.
+    void StepIsland(const std::vector<EntityId>& ids, const bt::Vec3& g, float dt)
+    {
+        bool allSleeping = true;
+        for (EntityId id : ids) {
+            const int st = runtime_[id].activation;
+            if (st == kActiveTag || st == kDisableDeactivation) allSleeping = false;
+        }
+        if (allSleeping) {
+            for (EntityId id : ids) {
+                RefBodyRuntime& rt = runtime_[id];
+                rt.activation = kIslandSleeping;
+                rt.linvel = bt::Vec3{0, 0, 0}; // (updateActivationState, every step)
+                rt.angvel = bt::Vec3{0, 0, 0};
+            }
+            return;
+        }
+        std::vector<ct::BodyState> state(ids.size());
+        std::vector<ct::IslandBody> bodies(ids.size());
+        std::vector<ct::IslandManifold> ms;
+        std::unordered_map<EntityId, int> indexOf;
+        for (size_t i = 0; i < ids.size(); ++i) indexOf[ids[i]] = static_cast<int>(i);
+        for (size_t i = 0; i < ids.size(); ++i) {
+            RefBodyRuntime& rt = runtime_[ids[i]];
+            if (rt.activation == kIslandSleeping) { // woken by its island
+                rt.activation = kWantsDeactivation;
+                rt.deactivationTime = 0.0f;
+            }
+            state[i] = ct::BodyState{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
+            bodies[i].state = &state[i];
+            bodies[i].invMass = rt.invMass;
+            bodies[i].invInertiaLocal = rt.invInertiaLocal;
+            // m_totalForce: gravity / invMass from this call's applyGravity — which skipped the body if it was asleep then
+            bodies[i].force = rt.hadGravity ? bt::Vec3{g.x / rt.invMass, g.y / rt.invMass, g.z / rt.invMass} : bt::Vec3{0, 0, 0};
+            // its pair with the plane exists whether or not it was collided this step (a body woken just now keeps its cached points)
+            const bool planePair = groundPlane && (rt.mask & 2u) != 0u;
+            ct::AppendOwnManifolds(ms, static_cast<int>(i), planePair ? &rt.ground : nullptr, rt.boxes.data(), static_cast<int>(rt.boxes.size()), rt.friction);
+            for (auto it = dynPairs_.lower_bound({ids[i], 0}); it != dynPairs_.end() && it->first.first == ids[i]; ++it) {
+                ct::BoxManifold& bm = it->second.m;
+                ct::IslandManifold m;
+                m.a = static_cast<int>(i);
+                m.b = indexOf.at(it->first.second);
+                m.friction = bm.friction;
+                m.restitution = bm.restitution;
+                m.n = bm.n;
+                for (int j = 0; j < bm.n; ++j) {
+                    ct::BoxPoint& cp = bm.p[j];
+                    m.p[j] = ct::IslandPoint{cp.worldA, cp.worldB, cp.normalB, cp.distance, &cp.appliedImpulse, &cp.appliedImpulseLateral1};
+                }
+                ms.push_back(m);
+            }
+        }
+        ct::SolveIsland(bodies.data(), static_cast<int>(bodies.size()), ms.data(), static_cast<int>(ms.size()), dt);
+        for (size_t i = 0; i < ids.size(); ++i) {
+            RefBodyRuntime& rt = runtime_[ids[i]];
+            rt.linvel = state[i].linVel;
+            rt.angvel = state[i].angVel;
+            if (bodies[i].moved) {
+                rt.origin = state[i].origin;
+                rt.orn = state[i].orn;
+                rt.basis = state[i].basis;
+                rt.freshPose = true;
+            }
+            IntegrateAndUpdateActivation(rt, dt);
         }
     }
 
@@ -638,6 +825,7 @@ private:
     }
 
     std::unordered_map<EntityId, RefBodyRuntime> runtime_;
+    std::map<std::pair<EntityId, EntityId>, DynPair> dynPairs_; // the pair cache of Dynamic boxes with its manifolds, (lower, higher) entity
     std::unordered_map<EntityId, RefTriggerRuntime> triggerRuntime_;
     std::vector<RefTriggerEvent> events_;
 };

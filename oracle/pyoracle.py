@@ -68,6 +68,9 @@ class _Lib:
         l.orc_set_static_contacts.argtypes = [C.c_void_p, C.c_int]
         l.orc_get_box_contacts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         l.orc_get_box_contacts.restype = C.c_int
+        l.orc_set_dynamic_contacts.argtypes = [C.c_void_p, C.c_int]
+        l.orc_get_dynamic_pairs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        l.orc_get_dynamic_pairs.restype = C.c_int
         l.orc_get_ground_contacts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         l.orc_get_ground_contacts.restype = C.c_int
         l.orc_set_physics_options.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
@@ -328,6 +331,19 @@ class RefScene:
         out = np.zeros((4, 4, 12), np.float32)
         n = lib().orc_get_box_contacts(self.h, eid, _vp(hdr), _vp(out))
         return [(int(hdr[k, 0]), out[k, :hdr[k, 1]].copy()) for k in range(min(n, 4))]
+
+    def SetDynamicContacts(self, enabled=True):
+        """Dynamic boxes collide with each other; bodies whose fed AABBs overlap form one simulation island (island_ref.h)."""
+        lib().orc_set_dynamic_contacts(self.h, int(enabled))
+
+    def DynamicPairs(self):
+        """(hdr, points): hdr[k] = lower entity id, higher entity id, number of points of the k-th pair of Dynamic boxes in the
+        pair cache (ascending); points[k, j] = the 12 floats BoxContacts documents."""
+        n = lib().orc_get_dynamic_pairs(self.h, 0, None, None)
+        hdr = np.zeros((max(n, 1), 3), np.uint32)
+        out = np.zeros((max(n, 1), 4, 12), np.float32)
+        n = lib().orc_get_dynamic_pairs(self.h, n, _vp(hdr), _vp(out))
+        return hdr[:n], out[:n]
 
     def GroundContacts(self, eid):
         """(n, rows): rows[k] = localA.xyz, appliedImpulse, localB.x, distance, localB.z, appliedImpulseLateral1 of the body's k-th contact."""
