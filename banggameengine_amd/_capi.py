@@ -53,6 +53,8 @@ SYMBOLS = {
     "bge_world_upload_friction_indexed": (C.c_int, [_vp, _u64, _vp, _vp]),
     "bge_world_download_contacts": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
     "bge_world_set_static_contacts": (C.c_int, [_vp, C.c_int]),
+    "bge_world_set_dynamic_contacts": (C.c_int, [_vp, C.c_int]),
+    "bge_world_download_dynamic_pairs": (C.c_int, [_vp, _u64, _vp, _vp, _vp]),
     "bge_world_upload_restitution": (C.c_int, [_vp, _u64, _u64, _vp]),
     "bge_world_upload_restitution_indexed": (C.c_int, [_vp, _u64, _vp, _vp]),
     "bge_world_download_box_contacts": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp]),

@@ -2172,6 +2172,12 @@ int Broadphase::query_boxes(hipStream_t stream, const WorldView& w, const uint32
     return BGE_OK;
 }
 
+PairSlices Broadphase::slices() const
+{
+    const Accum* acc = static_cast<const Accum*>(counters_);
+    return PairSlices{static_cast<const uint2*>(scan_stage_), &acc->shard_count[0][0], shard_capacity(capacity_), kShards};
+}
+
 int Broadphase::compact(hipStream_t stream)
 {
     if (!ran_ || compacted_) return BGE_OK;

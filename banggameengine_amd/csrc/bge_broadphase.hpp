@@ -40,8 +40,18 @@ struct BoxQuery {
     uint32_t cap;
 };
 
+// The pair list of the last run() where the search leaves it: 64 slices of `shard_cap` pairs, slice s holding counts[8 * s] of them
+// (more found than kept when a count exceeds shard_cap)
+struct PairSlices {
+    const uint2* stage;
+    const unsigned long long* counts;
+    uint64_t shard_cap;
+    uint32_t shards;
+};
+
 class Broadphase {
 public:
+    PairSlices slices() const;
     // n_slots: upper bound of bodies; pair_capacity: pairs kept per tick
     int configure(uint64_t n_slots, uint64_t pair_capacity);
     // Collect the overlapping pairs of the AABBs the tick kernel just wrote.

@@ -18,6 +18,8 @@
 // rows) makes this a register-hungry kernel; it touches only bodies at the ground, so it is sized for correctness first.
 #include <hip/hip_runtime.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 
 #include "bge_boxbox_device.hpp"
@@ -935,7 +937,8 @@ __global__ void __launch_bounds__(256) k_ground_select(WorldView w, GroundParams
         if (f != f_in) w.flags[slot] = f;
     }
     // (a body that wants to sleep is still collided this step — only a sleeping one is skipped)
-    const bool awake = in_range && type == 2u && !((f & kDrowsy) && dz == kDeactSleeping);
+    // (a body of an island of several bodies that stays awake is collided and solved by the island kernels, which ran before)
+    const bool awake = in_range && type == 2u && !((f & kDrowsy) && dz == kDeactSleeping) && !(ci0 & kCiIsland);
     // Static / Kinematic box colliders on: a Dynamic BOX that holds manifolds with boxes, or whose reach (conservative: the L1 norm
     // of its half extents bounds its AABB at any orientation, plus this step's motion, plus Bullet's 0.02) touches an obstacle's
     // fed AABB, goes to k_contact_boxes — which decides the pairs exactly and handles the plane for that body too
@@ -1332,18 +1335,20 @@ __device__ void ct_add_contact(CtBody& sb, CtRow* normalRow, CtRow* frictionRow,
     frictionRow[j] = fr;
 }
 
+// `island`: the body belongs to an island of several bodies — its own pairs (plane, Static / Kinematic boxes) are collided here, the
+// island's solver thread does the rest (k_island_solve)
 template <bool BASIS>
-__device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t slot)
+__device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t slot, bool island = false)
 {
     const uint32_t f0 = w.flags[slot];
     if ((f0 & kTypeMask) != 2u) return;
     const uint32_t ci0 = w.cinfo[slot];
     if (ci0 & kCiCapsule) return; // (never routed here)
-    bool collide_only = false;
+    bool collide_only = island;
     if (f0 & kDrowsy) {
         const uint32_t dz = w.deact[slot];
         if (dz == kDeactSleeping) return;
-        collide_only = dz == kDeactWants;
+        collide_only = island || dz == kDeactWants;
     }
     const uint32_t cls = f0 >> kMassShift;
     float inv_mass;
@@ -1469,6 +1474,7 @@ __device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t
             hdr[3] = 0u;
         }
         uint32_t* hdr = rows + static_cast<uint32_t>(row_of[a]) * kBoxManifoldWords;
+        hdr[3] = accepted[a]; // (the obstacle's number, for this sub-step: k_island_solve reads its material through it)
         const float pair_breaking = fminf(breaking, o.breaking); // btCollisionDispatcher::getNewManifold
         const int np = bp_collide(reinterpret_cast<float*>(hdr + 4), static_cast<int>(hdr[1]), pair_breaking, pos, basis, shape.dims, o);
         hdr[1] = static_cast<uint32_t>(np);
@@ -1627,6 +1633,704 @@ __global__ void __launch_bounds__(64) k_contact_boxes(WorldView w, GroundParams 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Dynamic boxes against each other: the pair cache, simulation islands, one solver thread per island (oracle/island_ref.h and
+// oracle/physics_ref.h CollideDynamicPairs / StepIsland, operation for operation).  Sub-step order:
+//   k_island_begin      teleport rule (what k_ground_select does otherwise), the AABB Bullet feeds its broadphase for every body,
+//                       per-slot scratch reset
+//   (Broadphase::run on those AABBs; the host reads the number of pairs back)
+//   k_island_pair_keys  the pairs of two Dynamic boxes as keys lower entity << 32 | higher entity    (sorted by hipcub)
+//   k_island_carry      a pair's manifold from last sub-step's sorted pair list (binary search), or a fresh one
+//   k_island_narrow     btBoxBoxDetector + the persistent manifold for every pair with an active body
+//   k_island_union / k_island_members   union-find over the pairs (findUnions unites every pair of the cache); the bodies that are
+//                       in a pair, keyed root slot << 32 | entity, and whether their island holds an ACTIVE_TAG body   (sorted by hipcub)
+//   k_island_flags      bodies of islands that stay awake get kCiIsland; k_island_own collides their own pairs (plane, obstacles)
+//   k_island_solve      one thread per island: solver bodies and rows in global memory, Bullet's iteration order
+// then k_ground_select / k_ground / k_contact_boxes for the one-body islands and k_tick for everybody, as always.
+struct IslBody {
+    F3 dLin, dAng, push, turn, linVel, angVel, extForce, extTorque;
+    float invMass;
+    float invI[9];
+    F3 origin;
+    uint32_t slot, woken, pad;
+};
+static_assert(sizeof(IslBody) == kIslBodyBytes, "IslandParams::solver_bodies");
+struct IslRow {
+    F3 normal, relposCrossN, angularComp, relpos2CrossN, angularCompB;
+    float jacDiagABInv, rhs, rhsPenetration, cfm, lower, upper, friction, applied, appliedPush;
+    uint32_t a, b;       // positions in the sorted body list; b = kNone: the fixed solver body
+    float* out;          // the manifold point's appliedImpulse (contact rows only)
+    uint32_t lateral_at; // ... and how many floats behind it appliedImpulseLateral1 is
+    uint32_t pad[3];
+};
+static_assert(sizeof(IslRow) == kIslRowBytes, "IslandParams::rows");
+
+__device__ __forceinline__ uint32_t isl_find(uint32_t* parent, uint32_t s)
+{
+    while (true) {
+        const uint32_t p = __hip_atomic_load(&parent[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == s) return s;
+        s = p;
+    }
+}
+
+template <bool BASIS>
+__global__ void __launch_bounds__(256) k_island_begin(WorldView w, GroundParams g, IslandParams ip)
+{
+    const uint64_t slot64 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (slot64 >= ip.n_slots) return;
+    const uint32_t slot = static_cast<uint32_t>(slot64);
+    ip.parent[slot] = slot;
+    ip.member[slot] = 0u;
+    ip.active[slot] = 0u;
+    ip.index_of_slot[slot] = kNone;
+    uint32_t f = w.flags[slot];
+    const uint32_t type = f & kTypeMask;
+    if (type == 0u) return;
+    if (ip.repose && (f & kValid) && (f & (kTDirty | kBDirty))) {
+        // (k_ground_select's re-pose, word for word: launch_ground is told not to do it again)
+        const uint32_t f_in = f;
+        const Q4 q = bt_quat_from_transform_euler(ld3(w.euler, slot));
+        st4(w.quat, slot, q);
+        f &= ~kSettled;
+        const F3 zero{0.0f, 0.0f, 0.0f};
+        if (type == 2u) st3(w.vel, slot, zero);
+        if (f & kSpin) {
+            st3(w.angvel, slot, zero);
+            f &= ~kSpin;
+        }
+        if (type == 2u) st3(w.euler, slot, bt_transform_euler_from_mat(bt_mat_from_quat(q)));
+        if (f != f_in) w.flags[slot] = f;
+    }
+    const uint32_t ci0 = w.cinfo[slot];
+    const uint32_t ci = ci0 & ~(kCiIsland | (ip.repose ? kCiNoGravity : 0u));
+    if (ci != ci0) w.cinfo[slot] = ci;
+    // predictUnconstraintMotion / updateAabbs: the box of the pose united with the box of the predicted pose (k_tick's AABB block)
+    const F3 pos = ld3(w.pos, slot);
+    const Q4 q = ld4(w.quat, slot);
+    const M3 basis = bt_mat_from_quat(q);
+    const F3 he = ld3(w.half_extent, slot);
+    float mn[3], mx[3];
+    bt_aabb_of_pose(pos, basis, he, mn, mx);
+    if (type == 2u) {
+        const bool spin = (f & kSpin) != 0;
+        const F3 v = ld3(w.vel, slot);
+        const F3 av = spin ? ld3(w.angvel, slot) : F3{0.0f, 0.0f, 0.0f};
+        const F3 pp{pos.x + v.x * g.dt, pos.y + v.y * g.dt, pos.z + v.z * g.dt};
+        float mn2[3], mx2[3];
+        if (BASIS || spin) {
+            const M3 r2 = bt_mat_from_quat(bt_integrate_orientation(BASIS ? bt_quat_from_mat(basis) : q, av, g.dt));
+            bt_aabb_of_pose(pp, r2, he, mn2, mx2);
+        } else {
+            bt_aabb_of_pose(pp, basis, he, mn2, mx2);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = mn2[a] < mn[a] ? mn2[a] : mn[a];
+            mx[a] = mx2[a] > mx[a] ? mx2[a] : mx[a];
+        }
+    }
+    float* bb = w.aabb + 6ull * slot;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        bb[a] = mn[a];
+        bb[3 + a] = mx[a];
+    }
+}
+
+__device__ __forceinline__ bool isl_dynamic_box(const WorldView& w, uint32_t slot)
+{
+    return (w.flags[slot] & kTypeMask) == 2u && !(w.cinfo[slot] & kCiCapsule);
+}
+
+__global__ void __launch_bounds__(256) k_island_pair_keys(WorldView w, IslandParams ip)
+{
+    // workgroup b walks slice b % shards, interleaved with the other workgroups of that slice
+    const uint32_t shard = blockIdx.x % ip.bp_shards, part = blockIdx.x / ip.bp_shards, parts = gridDim.x / ip.bp_shards;
+    const unsigned long long found = ip.bp_counts[8u * shard];
+    if (found > ip.bp_shard_cap && threadIdx.x == 0 && part == 0) atomicOr(&ip.counts[3], 2u); // the broadphase dropped pairs
+    const uint32_t n = static_cast<uint32_t>(found < ip.bp_shard_cap ? found : ip.bp_shard_cap);
+    const uint2* slice = ip.bp_stage + static_cast<uint64_t>(shard) * ip.bp_shard_cap;
+    for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
+        const uint2 pr = slice[i];
+        if (pr.x >= ip.n_slots || pr.y >= ip.n_slots) continue;
+        if (!isl_dynamic_box(w, pr.x) || !isl_dynamic_box(w, pr.y)) continue;
+        const uint32_t ea = ip.entity_of_slot[pr.x], eb = ip.entity_of_slot[pr.y];
+        const uint64_t key = ea < eb ? (static_cast<uint64_t>(ea) << 32) | eb : (static_cast<uint64_t>(eb) << 32) | ea;
+        const uint32_t at = atomicAdd(&ip.counts[0], 1u);
+        if (at < ip.pair_cap) ip.keys_raw[at] = key;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_island_carry(IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_pairs) return;
+    const uint64_t key = ip.keys[i];
+    const uint32_t ga = ip.gen_of_entity[static_cast<uint32_t>(key >> 32)], gb = ip.gen_of_entity[static_cast<uint32_t>(key)];
+    uint32_t lo = 0, hi = ip.n_prev;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ip.prev_keys[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    uint32_t* m = ip.man + static_cast<uint64_t>(i) * kBoxManifoldWords;
+    const uint32_t* old = ip.prev_man + static_cast<uint64_t>(lo) * kBoxManifoldWords;
+    if (lo < ip.n_prev && ip.prev_keys[lo] == key && old[1] == ga && old[2] == gb) {
+        for (uint32_t k = 0; k < kBoxManifoldWords; ++k) m[k] = old[k];
+    } else {
+        m[0] = 0u;
+        m[1] = ga;
+        m[2] = gb;
+        for (uint32_t k = 3; k < kBoxManifoldWords; ++k) m[k] = 0u;
+    }
+}
+
+__device__ __forceinline__ bool isl_sleeping(const WorldView& w, uint32_t slot)
+{
+    return (w.flags[slot] & kDrowsy) && w.deact[slot] == kDeactSleeping;
+}
+
+__global__ void __launch_bounds__(64) k_island_narrow(WorldView w, IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_pairs) return;
+    const uint64_t key = ip.keys[i];
+    const uint32_t sa = ip.slot_of_entity[static_cast<uint32_t>(key >> 32)], sb = ip.slot_of_entity[static_cast<uint32_t>(key)];
+    // btCollisionDispatcher::needsCollision: not when neither body is active (WANTS_DEACTIVATION counts as active)
+    if (isl_sleeping(w, sa) && isl_sleeping(w, sb)) return;
+    const float4 ca = w.cshape[sa], cb = w.cshape[sb];
+    CtShape shape_a, shape_b;
+    shape_a.capsule = shape_b.capsule = false;
+    shape_a.dims = F3{ca.x, ca.y, ca.z};
+    shape_b.dims = F3{cb.x, cb.y, cb.z};
+    const F3 pos_a = ld3(w.pos, sa), pos_b = ld3(w.pos, sb);
+    const M3 basis_a = bt_mat_from_quat(ld4(w.quat, sa)), basis_b = bt_mat_from_quat(ld4(w.quat, sb));
+    ObstacleRec o;
+    o.origin[0] = pos_b.x; o.origin[1] = pos_b.y; o.origin[2] = pos_b.z;
+    o.half[0] = cb.x; o.half[1] = cb.y; o.half[2] = cb.z;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.basis[3 * r + c] = basis_b.m[r][c];
+    }
+    uint32_t* m = ip.man + static_cast<uint64_t>(i) * kBoxManifoldWords;
+    const float breaking = fminf(ct_breaking_threshold(shape_a), ct_breaking_threshold(shape_b)); // btCollisionDispatcher::getNewManifold
+    m[0] = static_cast<uint32_t>(bp_collide(reinterpret_cast<float*>(m + 4), static_cast<int>(m[0]), breaking, pos_a, basis_a, shape_a.dims, o));
+}
+
+// lock-free union by index: the larger root goes under the smaller one, so an island's root is its lowest slot
+__global__ void __launch_bounds__(256) k_island_union(IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_pairs) return;
+    const uint64_t key = ip.keys[i];
+    uint32_t a = ip.slot_of_entity[static_cast<uint32_t>(key >> 32)], b = ip.slot_of_entity[static_cast<uint32_t>(key)];
+    while (true) {
+        a = isl_find(ip.parent, a);
+        b = isl_find(ip.parent, b);
+        if (a == b) break;
+        if (a < b) {
+            const uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(&ip.parent[a], a, b) == a) break;
+    }
+}
+
+__device__ __forceinline__ void isl_list_body(const WorldView& w, const IslandParams& ip, uint32_t s)
+{
+    if (atomicExch(&ip.member[s], 1u) != 0u) return;
+    const uint32_t root = isl_find(ip.parent, s);
+    const uint32_t at = atomicAdd(&ip.counts[1], 1u);
+    if (at < ip.body_cap) {
+        ip.body_keys_raw[at] = (static_cast<uint64_t>(root) << 32) | ip.entity_of_slot[s];
+        ip.body_slot_raw[at] = s;
+    }
+    // buildIslands: "all sleeping" unless a body is ACTIVE_TAG (or DISABLE_DEACTIVATION: such a world keeps no records at all)
+    const uint32_t f = w.flags[s];
+    const uint32_t dz = (f & kDrowsy) ? w.deact[s] : 0u;
+    if (dz != kDeactSleeping && dz != kDeactWants) atomicOr(&ip.active[root], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_island_members(WorldView w, IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_pairs) return;
+    const uint64_t key = ip.keys[i];
+    isl_list_body(w, ip, ip.slot_of_entity[static_cast<uint32_t>(key >> 32)]);
+    isl_list_body(w, ip, ip.slot_of_entity[static_cast<uint32_t>(key)]);
+}
+
+// a body that was woken earlier in this stepSimulation call and is in no pair any more: an island of its own on this path (its
+// gravity is off until the call ends, which only the island solver knows how to do)
+__global__ void __launch_bounds__(256) k_island_orphans(WorldView w, IslandParams ip)
+{
+    const uint64_t slot64 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (slot64 >= ip.n_slots) return;
+    const uint32_t s = static_cast<uint32_t>(slot64);
+    if ((w.flags[s] & kTypeMask) != 2u || !(w.cinfo[s] & kCiNoGravity)) return;
+    if (isl_sleeping(w, s)) return;
+    isl_list_body(w, ip, s);
+}
+
+__global__ void __launch_bounds__(256) k_island_flags(WorldView w, IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_bodies) return;
+    const uint32_t s = ip.body_slot[i];
+    ip.index_of_slot[s] = i;
+    if (ip.active[static_cast<uint32_t>(ip.body_keys[i] >> 32)]) w.cinfo[s] |= kCiIsland;
+}
+
+template <bool BASIS>
+__global__ void __launch_bounds__(64) k_island_own(WorldView w, GroundParams g, IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_bodies) return;
+    const uint32_t s = ip.body_slot[i];
+    if (w.cinfo[s] & kCiIsland) contact_body<BASIS>(w, g, s, true);
+}
+
+__device__ __forceinline__ float isl_dpps(const F3& u, const F3& v) { return (u.x * v.x + u.y * v.y) + u.z * v.z; }
+__device__ __forceinline__ float isl_dot3s(const F3& u, const F3& v) { return u.x * v.x + (u.y * v.y + u.z * v.z); }
+__device__ __forceinline__ F3 neg3(const F3& a) { return F3{-a.x, -a.y, -a.z}; }
+
+// oracle/island_ref.h isl::ResolveRow2
+__device__ void isl_resolve_row(IslBody* sb, IslRow& c, bool withUpperLimit)
+{
+    IslBody& a = sb[c.a];
+    const bool two = c.b != kNone;
+    float deltaImpulse = c.rhs - c.applied * c.cfm;
+    const float dv1 = isl_dpps(c.relposCrossN, a.dAng) + isl_dpps(c.normal, a.dLin);
+    const float dv2 = two ? isl_dpps(neg3(c.normal), sb[c.b].dLin) + isl_dpps(c.relpos2CrossN, sb[c.b].dAng) : 0.0f + 0.0f;
+    deltaImpulse = __builtin_fmaf(-dv1, c.jacDiagABInv, deltaImpulse);
+    deltaImpulse = __builtin_fmaf(-dv2, c.jacDiagABInv, deltaImpulse);
+    const float sum = c.applied + deltaImpulse;
+    if (c.lower < sum) {
+        if (withUpperLimit && !(sum < c.upper)) {
+            deltaImpulse = c.upper - c.applied;
+            c.applied = c.upper;
+        } else {
+            c.applied = sum;
+        }
+    } else {
+        deltaImpulse = c.lower - c.applied;
+        c.applied = c.lower;
+    }
+    a.dLin = F3{__builtin_fmaf(c.normal.x * a.invMass, deltaImpulse, a.dLin.x), __builtin_fmaf(c.normal.y * a.invMass, deltaImpulse, a.dLin.y),
+                __builtin_fmaf(c.normal.z * a.invMass, deltaImpulse, a.dLin.z)};
+    a.dAng = F3{__builtin_fmaf(c.angularComp.x, deltaImpulse, a.dAng.x), __builtin_fmaf(c.angularComp.y, deltaImpulse, a.dAng.y),
+                __builtin_fmaf(c.angularComp.z, deltaImpulse, a.dAng.z)};
+    if (two) {
+        IslBody& b = sb[c.b];
+        b.dLin = F3{__builtin_fmaf(-c.normal.x * b.invMass, deltaImpulse, b.dLin.x), __builtin_fmaf(-c.normal.y * b.invMass, deltaImpulse, b.dLin.y),
+                    __builtin_fmaf(-c.normal.z * b.invMass, deltaImpulse, b.dLin.z)};
+        b.dAng = F3{__builtin_fmaf(c.angularCompB.x, deltaImpulse, b.dAng.x), __builtin_fmaf(c.angularCompB.y, deltaImpulse, b.dAng.y),
+                    __builtin_fmaf(c.angularCompB.z, deltaImpulse, b.dAng.z)};
+    }
+}
+
+// oracle/island_ref.h isl::ResolveSplitPenetration2
+__device__ void isl_resolve_split(IslBody* sb, IslRow& c)
+{
+    if (!c.rhsPenetration) return;
+    IslBody& a = sb[c.a];
+    const bool two = c.b != kNone;
+    float deltaImpulse = c.rhsPenetration - c.appliedPush * c.cfm;
+    const float dv1 = isl_dot3s(c.normal, a.push) + isl_dot3s(c.relposCrossN, a.turn);
+    const float dv2 = two ? isl_dot3s(neg3(c.normal), sb[c.b].push) + isl_dot3s(c.relpos2CrossN, sb[c.b].turn) : 0.0f + 0.0f;
+    deltaImpulse = deltaImpulse - dv1 * c.jacDiagABInv;
+    deltaImpulse = deltaImpulse - dv2 * c.jacDiagABInv;
+    const float sum = c.appliedPush + deltaImpulse;
+    if (sum < c.lower) {
+        deltaImpulse = c.lower - c.appliedPush;
+        c.appliedPush = c.lower;
+    } else {
+        c.appliedPush = sum;
+    }
+    const F3 lin = F3{c.normal.x * a.invMass, c.normal.y * a.invMass, c.normal.z * a.invMass};
+    a.push = add3(a.push, scale3(lin, deltaImpulse));
+    a.turn = add3(a.turn, scale3(c.angularComp, deltaImpulse));
+    if (two) {
+        IslBody& b = sb[c.b];
+        const F3 lin2 = F3{-c.normal.x * b.invMass, -c.normal.y * b.invMass, -c.normal.z * b.invMass};
+        b.push = add3(b.push, scale3(lin2, deltaImpulse));
+        b.turn = add3(b.turn, scale3(c.angularCompB, deltaImpulse));
+    }
+}
+
+__device__ __forceinline__ M3 isl_inv_i(const IslBody& b)
+{
+    M3 m;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m.m[r][c] = b.invI[3 * r + c];
+    }
+    return m;
+}
+
+// One contact's two rows, warm started: oracle/island_ref.h SolveIsland's loop body (ct_add_contact with a second body)
+__device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia, uint32_t ib, float invTimeStep, const F3& worldA, const F3& worldB,
+                                const F3& n, float distance, float friction, float combinedRestitution, float* out, uint32_t lateral_at)
+{
+    constexpr float kErp2 = 0.2f, kSplitThreshold = -0.04f, kWarmstart = 0.85f, kSor = 1.0f, kRestitutionVelocityThreshold = 0.2f;
+    IslBody& A = sb[ia];
+    const bool two = ib != kNone;
+    const F3 zero{0.0f, 0.0f, 0.0f};
+    c.a = fr.a = ia;
+    c.b = fr.b = ib;
+    c.out = out;
+    c.lateral_at = lateral_at;
+    fr.out = nullptr;
+    fr.lateral_at = 0u;
+    const M3 invIA = isl_inv_i(A);
+    const F3 rel_pos1 = sub3(worldA, A.origin);
+    const F3 vel1 = add3(add3(A.linVel, A.extForce), cross3(add3(A.angVel, A.extTorque), rel_pos1));
+    F3 rel_pos2 = zero, vel2 = zero;
+    if (two) {
+        const IslBody& B = sb[ib];
+        rel_pos2 = sub3(worldB, B.origin);
+        vel2 = add3(add3(B.linVel, B.extForce), cross3(add3(B.angVel, B.extTorque), rel_pos2));
+    }
+    const F3 vel = sub3(vel1, vel2);
+    const float rel_vel = dot3(n, vel);
+    const float relaxation = kSor;
+    const F3 torqueAxis0 = cross3(rel_pos1, n);
+    c.angularComp = mat_vec(invIA, torqueAxis0);
+    F3 torqueAxis1 = zero;
+    c.angularCompB = zero;
+    {
+        const F3 vec = cross3(c.angularComp, rel_pos1);
+        const float denom0 = inv_mass_plus_dot(A.invMass, n, vec);
+        float denom1 = 0.0f;
+        if (two) {
+            const IslBody& B = sb[ib];
+            torqueAxis1 = cross3(n, rel_pos2);
+            c.angularCompB = mat_vec(isl_inv_i(B), torqueAxis1);
+            denom1 = inv_mass_plus_dot(B.invMass, n, cross3(rel_pos2, c.angularCompB));
+        }
+        const float cfm0 = 0.0f * invTimeStep;
+        c.jacDiagABInv = relaxation / (denom0 + denom1 + cfm0);
+    }
+    c.normal = n;
+    c.relposCrossN = torqueAxis0;
+    c.relpos2CrossN = torqueAxis1;
+    const float penetration = distance + 0.0f;
+    c.friction = friction;
+    float restitution = 0.0f;
+    if (combinedRestitution != 0.0f) {
+        const F3 rbVel1 = add3(A.linVel, cross3(A.angVel, rel_pos1));
+        F3 rbVel2 = zero;
+        if (two) rbVel2 = add3(sb[ib].linVel, cross3(sb[ib].angVel, rel_pos2));
+        const float rbRelVel = dot3(n, sub3(rbVel1, rbVel2));
+        restitution = __builtin_fabsf(rbRelVel) < kRestitutionVelocityThreshold ? 0.0f : combinedRestitution * -rbRelVel;
+        if (restitution <= 0.0f) restitution = 0.0f;
+    }
+    c.applied = *out * kWarmstart;
+    {
+        const F3 lin = F3{c.normal.x * A.invMass, c.normal.y * A.invMass, c.normal.z * A.invMass};
+        A.dLin = add3(A.dLin, scale3(lin, c.applied));
+        A.dAng = add3(A.dAng, scale3(c.angularComp, c.applied * 1.0f));
+        if (two) {
+            IslBody& B = sb[ib];
+            const F3 linB = F3{B.invMass * n.x, B.invMass * n.y, B.invMass * n.z};
+            B.dLin = sub3(B.dLin, scale3(linB, c.applied));
+            B.dAng = add3(B.dAng, scale3(c.angularCompB, c.applied * 1.0f));
+        }
+    }
+    c.appliedPush = 0.0f;
+    {
+        const float vel1Dotn = dot_xzy(c.normal, add3(A.linVel, A.extForce)) + dot_xzy(c.relposCrossN, add3(A.angVel, A.extTorque));
+        float vel2Dotn = 0.0f + 0.0f;
+        if (two) {
+            const IslBody& B = sb[ib];
+            const F3 l = add3(B.linVel, B.extForce);
+            vel2Dotn = dot_xzy(c.relpos2CrossN, add3(B.angVel, B.extTorque)) + ((-(l.x * n.x) - l.z * n.z) - l.y * n.y);
+        }
+        const float rel_vel2 = vel1Dotn + vel2Dotn;
+        float positionalError = 0.0f;
+        float velocityError = restitution - rel_vel2;
+        if (penetration > 0.0f) {
+            positionalError = 0.0f;
+            velocityError -= penetration * invTimeStep;
+        } else {
+            positionalError = -penetration * kErp2 * invTimeStep;
+        }
+        const float penetrationImpulse = positionalError * c.jacDiagABInv;
+        const float velocityImpulse = velocityError * c.jacDiagABInv;
+        if (penetration > kSplitThreshold) {
+            c.rhs = penetrationImpulse + velocityImpulse;
+            c.rhsPenetration = 0.0f;
+        } else {
+            c.rhs = velocityImpulse;
+            c.rhsPenetration = penetrationImpulse;
+        }
+        c.cfm = 0.0f * c.jacDiagABInv;
+        c.lower = 0.0f;
+        c.upper = 1e10f;
+    }
+    F3 dir = sub3(vel, scale3(n, rel_vel));
+    const float lat_rel_vel = dot3(dir, dir);
+    if (lat_rel_vel > kBtEpsilon) {
+        dir = scale3(dir, 1.0f / __builtin_sqrtf(lat_rel_vel));
+    } else {
+        dir = ct_plane_space1(n);
+    }
+    fr.friction = friction;
+    fr.normal = dir;
+    fr.relposCrossN = cross3(rel_pos1, dir);
+    fr.angularComp = mat_vec(invIA, fr.relposCrossN);
+    fr.relpos2CrossN = zero;
+    fr.angularCompB = zero;
+    {
+        const F3 vec = cross3(fr.angularComp, rel_pos1);
+        const float denom0 = inv_mass_plus_dot(A.invMass, dir, vec);
+        float denom1 = 0.0f;
+        if (two) {
+            const IslBody& B = sb[ib];
+            fr.relpos2CrossN = cross3(dir, rel_pos2);
+            fr.angularCompB = mat_vec(isl_inv_i(B), fr.relpos2CrossN);
+            denom1 = inv_mass_plus_dot(B.invMass, dir, cross3(rel_pos2, fr.angularCompB));
+        }
+        fr.jacDiagABInv = relaxation / (denom0 + denom1);
+    }
+    {
+        const float vel1Dotn = dot_xzy(fr.normal, add3(A.linVel, A.extForce)) + dot_xzy(fr.relposCrossN, A.angVel);
+        float rv;
+        if (two) {
+            const IslBody& B = sb[ib];
+            const F3 l = add3(B.linVel, B.extForce);
+            rv = dot_xzy(fr.relpos2CrossN, B.angVel) + ((vel1Dotn - l.z * dir.z) + (-(l.x * dir.x) - l.y * dir.y));
+        } else {
+            const float vel2Dotn = 0.0f + 0.0f;
+            rv = vel1Dotn + vel2Dotn;
+        }
+        const float velocityError = 0.0f - rv;
+        const float velocityImpulse = velocityError * fr.jacDiagABInv;
+        fr.rhs = 0.0f + velocityImpulse;
+        fr.rhsPenetration = 0.0f;
+        fr.cfm = 0.0f;
+        fr.lower = -fr.friction;
+        fr.upper = fr.friction;
+    }
+    fr.applied = 0.0f;
+    fr.appliedPush = 0.0f;
+}
+
+template <bool BASIS>
+__global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g, IslandParams ip)
+{
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
+    if (first >= ip.n_bodies) return;
+    const uint32_t root = static_cast<uint32_t>(ip.body_keys[first] >> 32);
+    if (first > 0 && static_cast<uint32_t>(ip.body_keys[first - 1] >> 32) == root) return; // not the island's first body
+    if (!ip.active[root]) return; // "all sleeping": k_tick turns its WANTS_DEACTIVATION bodies to ISLAND_SLEEPING, the others sleep already
+    uint32_t end = first + 1;
+    while (end < ip.n_bodies && static_cast<uint32_t>(ip.body_keys[end] >> 32) == root) ++end;
+    IslBody* sb = static_cast<IslBody*>(ip.solver_bodies);
+    constexpr int kIterations = 10;
+    constexpr float kSplitTurnErp = 0.1f;
+    const float invTimeStep = 1.0f / g.dt;
+    // ---- convertBodies, and how many rows the island needs
+    uint32_t n_points = 0;
+    for (uint32_t i = first; i < end; ++i) {
+        const uint32_t slot = ip.body_slot[i];
+        const uint32_t f0 = w.flags[slot];
+        const uint32_t ci = w.cinfo[slot];
+        const bool woken = (f0 & kDrowsy) && w.deact[slot] == kDeactSleeping;
+        const bool no_gravity = woken || (ci & kCiNoGravity);
+        const uint32_t cls = f0 >> kMassShift;
+        float inv_mass;
+        F3 force;
+        if (cls != kMassClassArray) {
+            const float4 gf = w.grav_palette[cls];
+            inv_mass = gf.w;
+            force = F3{gf.x, gf.y, gf.z};
+        } else {
+            inv_mass = w.inv_mass[slot];
+            force = F3{g.gx / inv_mass, g.gy / inv_mass, g.gz / inv_mass};
+        }
+        if (no_gravity) force = F3{0.0f, 0.0f, 0.0f};
+        const float4 cs = w.cshape[slot];
+        CtShape shape;
+        shape.capsule = false;
+        shape.dims = F3{cs.x, cs.y, cs.z};
+        const F3 invInertiaLocal = ct_inv_inertia_local(ct_local_inertia(shape, w.cmass[slot]));
+        const bool spin = (f0 & kSpin) != 0;
+        const Q4 q = ld4(w.quat, slot);
+        const M3 basis = bt_mat_from_quat(q);
+        const Q4 orn = BASIS ? bt_quat_from_mat(basis) : q;
+        const M3 invI = ct_inv_inertia_world(basis, invInertiaLocal);
+        IslBody b;
+        b.dLin = b.dAng = b.push = b.turn = F3{0.0f, 0.0f, 0.0f};
+        b.linVel = ld3(w.vel, slot);
+        b.angVel = spin ? ld3(w.angvel, slot) : F3{0.0f, 0.0f, 0.0f};
+        b.invMass = inv_mass;
+        b.extForce = scale3(scale3(force, inv_mass), g.dt);
+        b.extTorque = F3{0.0f, 0.0f, 0.0f};
+        b.extTorque = add3(b.extTorque, ct_gyroscopic_impulse(invInertiaLocal, b.angVel, orn, g.dt));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) b.invI[3 * r + c] = invI.m[r][c];
+        }
+        b.origin = ld3(w.pos, slot);
+        b.slot = slot;
+        b.woken = woken ? 1u : 0u;
+        b.pad = 0u;
+        sb[i] = b;
+        if (g.plane != 0u && (ci & kCiGroundMask)) n_points += (ci >> kCiCountShift) & 7u;
+        if (ci & kCiBoxes) {
+            const uint32_t* rows = w.bmanifold + static_cast<uint64_t>(slot) * (kBoxManifolds * kBoxManifoldWords);
+            for (uint32_t e = 0; e < kBoxManifolds; ++e) {
+                if (rows[e * kBoxManifoldWords] != kBoxNone) n_points += rows[e * kBoxManifoldWords + 1];
+            }
+        }
+    }
+    // the pairs owned by the island's bodies (keys ascend with the owner's entity, so they are one run per body)
+    for (uint32_t i = first; i < end; ++i) {
+        const uint64_t owner = static_cast<uint64_t>(ip.entity_of_slot[ip.body_slot[i]]) << 32;
+        uint32_t lo = 0, hi = ip.n_pairs;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ip.keys[mid] < owner) lo = mid + 1;
+            else hi = mid;
+        }
+        for (uint32_t k = lo; k < ip.n_pairs && (ip.keys[k] >> 32) == (owner >> 32); ++k) n_points += ip.man[static_cast<uint64_t>(k) * kBoxManifoldWords];
+    }
+    IslRow* rows_base = nullptr;
+    if (n_points) {
+        const uint32_t at = atomicAdd(&ip.counts[2], 2u * n_points);
+        if (at + 2u * n_points > ip.row_cap) {
+            atomicOr(&ip.counts[3], 1u); // (cannot happen: the host sizes the pool for every point the manifolds can hold)
+            return;
+        }
+        rows_base = static_cast<IslRow*>(ip.rows) + at;
+    }
+    IslRow* normalRow = rows_base;
+    IslRow* frictionRow = rows_base + n_points;
+    // ---- convertContacts: body by body (ascending entity) its plane manifold, its manifolds with obstacles (ascending entity), its pairs
+    //      with Dynamic boxes of higher entity (ascending)
+    uint32_t j = 0;
+    for (uint32_t i = first; i < end; ++i) {
+        const uint32_t slot = sb[i].slot;
+        const uint32_t ci = w.cinfo[slot];
+        const M3 basis = bt_mat_from_quat(ld4(w.quat, slot));
+        const F3 pos = sb[i].origin;
+        const float bodyFriction = w.cfriction[slot], bodyRestitution = w.crestitution ? w.crestitution[slot] : 0.0f;
+        if (g.plane != 0u && (ci & kCiGroundMask)) {
+            const uint32_t n = (ci >> kCiCountShift) & 7u;
+            const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, bodyFriction * 1.0f));
+            float* mp = w.manifold + 32ull * slot;
+            for (uint32_t k = 0; k < n; ++k) {
+                const F3 worldA = xform_point(basis, pos, F3{mp[8 * k], mp[8 * k + 1], mp[8 * k + 2]});
+                isl_add_contact(sb, normalRow[j], frictionRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, F3{0.0f, 1.0f, 0.0f}, mp[8 * k + 5],
+                                combinedFriction, 0.0f, mp + 8 * k + 3, 4u);
+                j++;
+            }
+        }
+        if (ci & kCiBoxes) {
+            uint32_t* rows = w.bmanifold + static_cast<uint64_t>(slot) * (kBoxManifolds * kBoxManifoldWords);
+            uint32_t done = 0;
+            for (uint32_t pass = 0; pass < kBoxManifolds; ++pass) { // (the rows are in no particular order: lowest entity first)
+                uint32_t best = kBoxManifolds;
+                for (uint32_t e = 0; e < kBoxManifolds; ++e) {
+                    if ((done & (1u << e)) || rows[e * kBoxManifoldWords] == kBoxNone) continue;
+                    if (best == kBoxManifolds || rows[e * kBoxManifoldWords] < rows[best * kBoxManifoldWords]) best = e;
+                }
+                if (best == kBoxManifolds) break;
+                done |= 1u << best;
+                uint32_t* hdr = rows + best * kBoxManifoldWords;
+                const ObstacleRec& o = g.obstacles[hdr[3]];
+                const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, bodyFriction * o.friction));
+                const float combinedRestitution = bodyRestitution * o.restitution;
+                float* pts = reinterpret_cast<float*>(hdr + 4);
+                for (uint32_t k = 0; k < hdr[1]; ++k) {
+                    float* c = pts + 12 * k;
+                    const F3 worldA = xform_point(basis, pos, bp_get3(c, 0));
+                    isl_add_contact(sb, normalRow[j], frictionRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, bp_get3(c, 6), c[9], combinedFriction,
+                                    combinedRestitution, c + 10, 1u);
+                    j++;
+                }
+            }
+        }
+        const uint64_t owner = static_cast<uint64_t>(ip.entity_of_slot[slot]) << 32;
+        uint32_t lo = 0, hi = ip.n_pairs;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ip.keys[mid] < owner) lo = mid + 1;
+            else hi = mid;
+        }
+        for (uint32_t k = lo; k < ip.n_pairs && (ip.keys[k] >> 32) == (owner >> 32); ++k) {
+            uint32_t* m = ip.man + static_cast<uint64_t>(k) * kBoxManifoldWords;
+            const uint32_t other_slot = ip.slot_of_entity[static_cast<uint32_t>(ip.keys[k])];
+            const uint32_t ib = ip.index_of_slot[other_slot];
+            const M3 basis_b = bt_mat_from_quat(ld4(w.quat, other_slot));
+            const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, bodyFriction * w.cfriction[other_slot]));
+            const float combinedRestitution = bodyRestitution * (w.crestitution ? w.crestitution[other_slot] : 0.0f);
+            float* pts = reinterpret_cast<float*>(m + 4);
+            for (uint32_t q = 0; q < m[0]; ++q) {
+                float* c = pts + 12 * q;
+                const F3 worldA = xform_point(basis, pos, bp_get3(c, 0));
+                const F3 worldB = xform_point_b(basis_b, sb[ib].origin, bp_get3(c, 3));
+                isl_add_contact(sb, normalRow[j], frictionRow[j], i, ib, invTimeStep, worldA, worldB, bp_get3(c, 6), c[9], combinedFriction, combinedRestitution,
+                                c + 10, 1u);
+                j++;
+            }
+        }
+    }
+    // ---- solveGroupCacheFriendlySplitImpulseIterations, solveGroupCacheFriendlyIterations
+    for (int it = 0; it < kIterations; ++it) {
+        for (uint32_t r = 0; r < n_points; ++r) isl_resolve_split(sb, normalRow[r]);
+    }
+    for (int it = 0; it < kIterations; ++it) {
+        for (uint32_t r = 0; r < n_points; ++r) isl_resolve_row(sb, normalRow[r], false);
+        for (uint32_t r = 0; r < n_points; ++r) {
+            const float totalImpulse = normalRow[r].applied;
+            if (totalImpulse > 0.0f) {
+                frictionRow[r].lower = -(frictionRow[r].friction * totalImpulse);
+                frictionRow[r].upper = frictionRow[r].friction * totalImpulse;
+                isl_resolve_row(sb, frictionRow[r], true);
+            }
+        }
+    }
+    // ---- solveGroupCacheFriendlyFinish
+    for (uint32_t r = 0; r < n_points; ++r) {
+        normalRow[r].out[0] = normalRow[r].applied;
+        normalRow[r].out[normalRow[r].lateral_at] = frictionRow[r].applied;
+    }
+    for (uint32_t i = first; i < end; ++i) {
+        IslBody& s = sb[i];
+        const uint32_t slot = s.slot;
+        s.linVel = add3(s.linVel, s.dLin);
+        s.angVel = add3(s.angVel, s.dAng);
+        uint32_t ci = w.cinfo[slot] | kCiSolved;
+        if (s.push.x != 0.0f || s.push.y != 0.0f || s.push.z != 0.0f || s.turn.x != 0.0f || s.turn.y != 0.0f || s.turn.z != 0.0f) {
+            const Q4 q = ld4(w.quat, slot);
+            const Q4 orn = BASIS ? bt_quat_from_mat(bt_mat_from_quat(q)) : q;
+            st3(w.pos, slot, add3(s.origin, scale3(s.push, g.dt)));
+            st4(w.quat, slot, bt_integrate_orientation(orn, scale3(s.turn, kSplitTurnErp), g.dt));
+            ci |= kCiMoved;
+        }
+        const F3 v = add3(s.linVel, s.extForce), av = add3(s.angVel, s.extTorque);
+        st3(w.vel, slot, v);
+        st3(w.angvel, slot, av);
+        uint32_t f0 = w.flags[slot];
+        uint32_t f = (av.x != 0.0f || av.y != 0.0f || av.z != 0.0f) ? (f0 | kSpin) : (f0 & ~kSpin);
+        if (s.woken) {
+            // buildIslands: a sleeping body of an island that has an active body -> WANTS_DEACTIVATION, timer 0; gravity passed it by
+            w.deact[slot] = kDeactWants;
+            f |= kDrowsy;
+            ci |= kCiNoGravity;
+        }
+        if (f != f0) w.flags[slot] = f;
+        w.cinfo[slot] = ci;
+    }
+}
+
 } // namespace
 
 hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundParams& g, bool bullet_basis)
@@ -1636,8 +2340,10 @@ hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundPar
     // what is resident: 2 x BGE_GROUND_MIN_BLOCKS workgroups of 128 threads on each of the 256 CUs (a multiple of the shard count)
     const dim3 grid(512u * BGE_GROUND_MIN_BLOCKS), block(128);
     const bool boxes = g.box_list != nullptr; // Static / Kinematic box colliders are on
-    if (boxes && g.n_obstacles) hipLaunchKernelGGL(k_obstacles, dim3((g.n_obstacles + 63u) / 64u), dim3(64), 0, stream, w, g);
-    if (boxes && g.obstacle_grid) hipLaunchKernelGGL(k_obstacle_grid, dim3(1), dim3(1024), 0, stream, g);
+    if (!g.obstacles_ready) {
+        if (boxes && g.n_obstacles) hipLaunchKernelGGL(k_obstacles, dim3((g.n_obstacles + 63u) / 64u), dim3(64), 0, stream, w, g);
+        if (boxes && g.obstacle_grid) hipLaunchKernelGGL(k_obstacle_grid, dim3(1), dim3(1024), 0, stream, g);
+    }
     if (bullet_basis) {
         hipLaunchKernelGGL(k_ground_select<true>, sgrid, sblock, 0, stream, w, g);
         if (g.plane) hipLaunchKernelGGL(k_ground<true>, grid, block, 0, stream, w, g);
@@ -1646,6 +2352,67 @@ hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundPar
         hipLaunchKernelGGL(k_ground_select<false>, sgrid, sblock, 0, stream, w, g);
         if (g.plane) hipLaunchKernelGGL(k_ground<false>, grid, block, 0, stream, w, g);
         if (boxes) hipLaunchKernelGGL(k_contact_boxes<false>, dim3(256), dim3(64), 0, stream, w, g);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_obstacles(hipStream_t stream, const WorldView& w, const GroundParams& g)
+{
+    if (g.box_list && g.n_obstacles) hipLaunchKernelGGL(k_obstacles, dim3((g.n_obstacles + 63u) / 64u), dim3(64), 0, stream, w, g);
+    if (g.box_list && g.obstacle_grid) hipLaunchKernelGGL(k_obstacle_grid, dim3(1), dim3(1024), 0, stream, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_island_begin(hipStream_t stream, const WorldView& w, const GroundParams& g, const IslandParams& ip, bool bullet_basis)
+{
+    if (ip.n_slots == 0) return hipSuccess;
+    const dim3 grid(static_cast<uint32_t>((ip.n_slots + 255) / 256)), block(256);
+    if (bullet_basis) hipLaunchKernelGGL(k_island_begin<true>, grid, block, 0, stream, w, g, ip);
+    else hipLaunchKernelGGL(k_island_begin<false>, grid, block, 0, stream, w, g, ip);
+    return hipGetLastError();
+}
+
+hipError_t launch_island_pair_keys(hipStream_t stream, const WorldView& w, const IslandParams& ip)
+{
+    hipLaunchKernelGGL(k_island_pair_keys, dim3(ip.bp_shards * 16u), dim3(256), 0, stream, w, ip);
+    return hipGetLastError();
+}
+
+// (tmp == nullptr: only the size of the temporary storage is returned)
+hipError_t island_sort_keys(hipStream_t stream, void* tmp, size_t& tmp_bytes, const uint64_t* in, uint64_t* out, uint32_t n)
+{
+    return hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, in, out, static_cast<int>(n), 0, 64, stream);
+}
+
+hipError_t island_sort_pairs(hipStream_t stream, void* tmp, size_t& tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint32_t n)
+{
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, static_cast<int>(n), 0, 64, stream);
+}
+
+hipError_t launch_island_build(hipStream_t stream, const WorldView& w, const IslandParams& ip, bool orphans)
+{
+    if (ip.n_pairs) {
+        const dim3 grid((ip.n_pairs + 255u) / 256u), block(256);
+        hipLaunchKernelGGL(k_island_carry, grid, block, 0, stream, ip);
+        hipLaunchKernelGGL(k_island_narrow, dim3((ip.n_pairs + 63u) / 64u), dim3(64), 0, stream, w, ip);
+        hipLaunchKernelGGL(k_island_union, grid, block, 0, stream, ip);
+        hipLaunchKernelGGL(k_island_members, grid, block, 0, stream, w, ip);
+    }
+    if (orphans) hipLaunchKernelGGL(k_island_orphans, dim3(static_cast<uint32_t>((ip.n_slots + 255) / 256)), dim3(256), 0, stream, w, ip);
+    return hipGetLastError();
+}
+
+hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const GroundParams& g, const IslandParams& ip, bool bullet_basis)
+{
+    if (ip.n_bodies == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_island_flags, dim3((ip.n_bodies + 255u) / 256u), dim3(256), 0, stream, w, ip);
+    const dim3 grid((ip.n_bodies + 63u) / 64u), block(64);
+    if (bullet_basis) {
+        hipLaunchKernelGGL(k_island_own<true>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL(k_island_solve<true>, grid, block, 0, stream, w, g, ip);
+    } else {
+        hipLaunchKernelGGL(k_island_own<false>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL(k_island_solve<false>, grid, block, 0, stream, w, g, ip);
     }
     return hipGetLastError();
 }

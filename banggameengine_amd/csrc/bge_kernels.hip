@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 const uint32_t dz0 = (kSleepEnabled && (f & kDrowsy)) ? (ground_early ? dz_early : w.deact[slot]) : 0u;
                 uint32_t dz = dz0;
                 // buildIslands: a free body is an island of its own; WANTS_DEACTIVATION -> ISLAND_SLEEPING
-                if (dz == kDeactWants) dz = kDeactSleeping;
+                // (kCiIsland: an island of several bodies with an active body in it keeps this one awake — bge_contact.hip k_island_flags)
+                if (dz == kDeactWants && !(ci & kCiIsland)) dz = kDeactSleeping;
                 if (inv_mass != 0.0f && dz == kDeactSleeping) {
                     // asleep: no gravity, not solved, not integrated; updateActivationState zeroes the velocities
                     v = F3{0.0f, 0.0f, 0.0f};
@@ -414,7 +415,11 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                         const float lin2 = v.x * v.x + v.y * v.y + v.z * v.z;
                         const float ang2 = av.x * av.x + av.y * av.y + av.z * av.z;
                         const bool slow = lin2 < p.sleep_lin2 && ang2 < p.sleep_ang2;
-                        if (slow || dz != 0u) {
+                        if (dz == kDeactWants) {
+                            // kept awake by its island: wantsSleeping() is true for the state itself while the body is slow; faster
+                            // than the thresholds it is ACTIVE_TAG again, timer 0
+                            if (!slow) dz = 0u;
+                        } else if (slow || dz != 0u) {
                             const float t = slow ? __uint_as_float(dz) + p.dt : 0.0f;
                             dz = (p.sleep_time != 0.0f && t > p.sleep_time) ? kDeactWants : __float_as_uint(t);
                         }
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                         st3(w.euler, slot, eul);
                     }
                 }
-                if (ci & (kCiSolved | kCiMoved)) w.cinfo[slot] = ci & ~(kCiSolved | kCiMoved); // consumed
+                if (ci & (kCiSolved | kCiMoved | kCiIsland)) w.cinfo[slot] = ci & ~(kCiSolved | kCiMoved | kCiIsland); // consumed
                 if (valid) f |= kTDirty; // transform->MarkDirty()
             }
             if (valid) f &= ~kBDirty; // (an orphaned body is not re-created: its dirty bit waits for the Transform)

@@ -59,6 +59,11 @@ constexpr uint32_t kCiSolved = 4u;       // k_ground ran the solver for this bod
 constexpr uint32_t kCiMoved = 8u;        // ... and the split impulse corrected the pose (rotationEuler must be rewritten)
 constexpr uint32_t kCiCountShift = 4;    // bits 4..6: contact points in the manifold (0..4)
 constexpr uint32_t kCiBoxes = 0x80u;     // the body holds at least one manifold with a box (its bmanifold rows are live)
+constexpr uint32_t kCiIsland = 0x100u;   // Dynamic boxes collide with each other: this sub-step the body is in a simulation island of several
+                                         // bodies that stays awake — the island kernels collide and solve it (k_ground_select leaves it alone),
+                                         // k_tick does not put it to sleep on WANTS_DEACTIVATION; consumed by k_tick like kCiSolved
+constexpr uint32_t kCiNoGravity = 0x200u; // the body was asleep when this stepSimulation call applied gravity and was woken by its island
+                                         // since: no gravity until the call ends (cleared by the first sub-step of the next call)
 
 // A Dynamic box keeps at most this many manifolds with Static / Kinematic boxes (the lowest entity ids; Bullet has no limit —
 // oracle/boxbox_ref.h kMaxBoxManifolds, a stated specification choice)
@@ -106,7 +111,46 @@ struct GroundParams {
     uint32_t obstacle_grid_cap; // item capacity
     uint32_t* box_list;        // [n_slots] slots k_ground_select hands to k_contact_boxes
     uint32_t* box_count;       // [0] entries of box_list, [1] workgroups of k_contact_boxes that are done (both zero between sub-steps)
+    uint32_t obstacles_ready;  // the island phases of this sub-step ran k_obstacles (launch_obstacles) already
 };
+// Dynamic boxes against each other (round 3, bge_contact.hip "islands"): the pair cache of Dynamic boxes with a persistent manifold per
+// pair, simulation islands by union-find over the pairs, one solver thread per island.  All arrays are device memory of the world.
+struct IslandParams {
+    float dt, gx, gy, gz;
+    uint64_t n_slots;
+    uint32_t repose;                // first sub-step of a stepSimulation call
+    const uint32_t* entity_of_slot;
+    const uint32_t* slot_of_entity;
+    const uint32_t* gen_of_entity;  // how often the entity's body was (re)created
+    uint32_t* counts;               // [0] pairs of Dynamic boxes found, [1] bodies in islands, [2] rows handed out, [3] error bits
+    // pairs: key = lower entity << 32 | higher entity
+    const uint2* bp_stage;          // the broadphase's pair list (slot, slot) in its shard slices (Broadphase::slices)
+    const unsigned long long* bp_counts;
+    uint64_t bp_shard_cap;
+    uint32_t bp_shards;
+    uint64_t* keys_raw;             // [pair_cap] unsorted
+    const uint64_t* keys;           // [n_pairs] ascending
+    uint32_t pair_cap, n_pairs;
+    uint32_t* man;                  // [n_pairs][kBoxManifoldWords]: points, generation of A, of B, 0; then 4 x 12 floats as in bmanifold
+    const uint64_t* prev_keys;      // last sub-step's pairs and manifolds
+    const uint32_t* prev_man;
+    uint32_t n_prev;
+    // islands
+    uint32_t* parent;               // [n_slots] union-find over slots
+    uint32_t* member;               // [n_slots] 1: listed as an island body this sub-step
+    uint32_t* active;               // [n_slots] by root: the island holds a body that is ACTIVE_TAG
+    uint32_t* index_of_slot;        // [n_slots] position in the sorted body list
+    uint64_t* body_keys_raw;        // [body_cap] root slot << 32 | entity
+    uint32_t* body_slot_raw;
+    const uint64_t* body_keys;      // sorted
+    const uint32_t* body_slot;
+    uint32_t body_cap, n_bodies;
+    void* solver_bodies;            // [n_bodies] IslBody
+    void* rows;                     // [row_cap] IslRow x 2 per contact point
+    uint32_t row_cap;
+};
+constexpr uint32_t kIslBodyBytes = 160, kIslRowBytes = 128;
+
 constexpr uint32_t kGroundShards = 64;
 constexpr uint32_t kObstacleGridMin = 64, kObstacleGridAxis = 64, kObstacleGridWide = 32, kObstacleGridStart = 40,
                    kObstacleGridItems = kObstacleGridStart + kObstacleGridAxis * kObstacleGridAxis + 1;
@@ -148,6 +192,14 @@ hipError_t launch_pose_only(hipStream_t stream, const WorldView& w, uint64_t n_s
 
 // Ground plane y = 0: collide every Dynamic body with it and run Bullet's solver for the bodies in contact (bge_contact.hip);
 // launched before launch_tick of the same sub-step.
+// the phases of a sub-step with Dynamic-against-Dynamic contacts (the host reads counts[] back between them: the sorts need them)
+hipError_t launch_obstacles(hipStream_t stream, const WorldView& w, const GroundParams& g);
+hipError_t launch_island_begin(hipStream_t stream, const WorldView& w, const GroundParams& g, const IslandParams& ip, bool bullet_basis);
+hipError_t launch_island_pair_keys(hipStream_t stream, const WorldView& w, const IslandParams& ip);
+hipError_t island_sort_keys(hipStream_t stream, void* tmp, size_t& tmp_bytes, const uint64_t* in, uint64_t* out, uint32_t n);
+hipError_t island_sort_pairs(hipStream_t stream, void* tmp, size_t& tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint32_t n);
+hipError_t launch_island_build(hipStream_t stream, const WorldView& w, const IslandParams& ip, bool orphans);
+hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const GroundParams& g, const IslandParams& ip, bool bullet_basis);
 hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundParams& g, bool bullet_basis);
 
 hipError_t launch_scatter_rows(hipStream_t stream, const uint32_t* slot_of_entity, uint64_t first, uint64_t count,

@@ -212,6 +212,18 @@ struct bge_world {
     // sharded broadphase (bge_route.hip): records routed to spatial slabs, pair search over what was received
     bge::ShardRouter router;
     bge::Broadphase slab_broadphase;
+    // Dynamic boxes against each other (bge_contact.hip "islands"): a broadphase of its own over the sub-step's fed AABBs (the tick's
+    // pair list and the trigger query keep theirs), the sorted pair cache with its manifolds in two generations, per-slot scratch
+    bool dynamic_contacts = false;
+    bge::Broadphase island_bp;
+    DevBuf isl_slot_words, isl_counts, isl_identity, isl_gen, isl_keys_raw, isl_keys[2], isl_man[2], isl_body_keys_raw, isl_body_slot_raw,
+        isl_body_keys, isl_body_slot, isl_solver_bodies, isl_rows, isl_sort_tmp;
+    uint32_t* isl_counts_host = nullptr; // pinned
+    int isl_cur = 0;
+    uint32_t isl_n_prev = 0;
+    uint64_t isl_identity_n = 0;
+    bool isl_gen_stale = true;
+    uint32_t isl_last_pairs = 0, isl_last_bodies = 0;
     bool pairs_from_slab = false;          // bge_world_pairs reads the slab search (global ids) instead of the local one
     std::vector<uint32_t> global_id_host;  // per entity index; empty = identity
     DevBuf global_of_slot, bp_send, bp_recv, bp_small, bp_hist;
@@ -352,6 +364,12 @@ struct bge_world {
         trig_delta_host = nullptr;
         broadphase.release();
         slab_broadphase.release();
+        island_bp.release();
+        for (DevBuf* b : {&isl_slot_words, &isl_counts, &isl_identity, &isl_gen, &isl_keys_raw, &isl_keys[0], &isl_keys[1], &isl_man[0], &isl_man[1], &isl_body_keys_raw,
+                          &isl_body_slot_raw, &isl_body_keys, &isl_body_slot, &isl_solver_bodies, &isl_rows, &isl_sort_tmp})
+            b->release();
+        if (isl_counts_host) (void)hipHostFree(isl_counts_host);
+        isl_counts_host = nullptr;
         router.release();
         for (DevBuf* b : {&global_of_slot, &bp_send, &bp_recv, &bp_small, &bp_hist}) b->release();
         comm.destroy();
@@ -847,6 +865,152 @@ int prepare_obstacles(bge_world* w, uint64_t n_slots)
         HIP_TRY(hipMemcpy(w->obstacle_gen.p, gens.data(), gens.size() * 4, hipMemcpyHostToDevice));
     }
     w->obstacles_stale = false;
+    return BGE_OK;
+}
+
+// the world's collision-filter palette as the broadphase takes it (uploads the table when it changed)
+int filter_palette_of(bge_world* w, bge::FilterPalette* out)
+{
+    if (w->filter_table_stale && !w->filter_overflow) {
+        std::vector<uint32_t> tab(256 * 4, 0u);
+        for (size_t c = 0; c < w->filter_palette.size(); ++c) {
+            tab[4 * c] = w->filter_palette[c].group;
+            tab[4 * c + 1] = w->filter_palette[c].mask;
+            tab[4 * c + 2] = w->filter_palette[c].is_static;
+        }
+        HIP_TRY(hipMemcpyAsync(w->filter_table.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream)); // `tab` is a local
+        w->filter_table_stale = false;
+    }
+    *out = bge::FilterPalette{w->filter_overflow ? nullptr : w->filter_class.as<uint32_t>(), w->filter_overflow ? nullptr : w->filter_table.as<uint4>(),
+                              static_cast<uint32_t>(w->filter_palette.size())};
+    return BGE_OK;
+}
+
+// One sub-step's collision detection and constraint solving for the Dynamic boxes that touch each other (bge_contact.hip "islands";
+// oracle/physics_ref.h CollideDynamicPairs / StepIsland).  Runs before k_ground_select; two small read-backs (pairs, island bodies)
+// size the sorts between its phases.
+int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool bullet_basis, bool later_sub_step)
+{
+    const uint64_t n_entities = std::max<uint64_t>(w->flat.n_entities, 1);
+    HIP_TRY(w->isl_slot_words.ensure(std::max<uint64_t>(n_slots, 1) * 16));
+    HIP_TRY(w->isl_counts.ensure(64));
+    if (!w->isl_counts_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->isl_counts_host), 64));
+    if (w->isl_identity_n < n_slots) {
+        std::vector<uint32_t> iota(n_slots);
+        for (uint64_t i = 0; i < n_slots; ++i) iota[i] = static_cast<uint32_t>(i);
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        HIP_TRY(w->isl_identity.ensure(n_slots * 4));
+        HIP_TRY(hipMemcpy(w->isl_identity.p, iota.data(), n_slots * 4, hipMemcpyHostToDevice));
+        w->isl_identity_n = n_slots;
+    }
+    if (w->isl_gen_stale || w->isl_gen.bytes < n_entities * 4) {
+        std::vector<uint32_t> gens(n_entities, 0u);
+        for (uint64_t e = 0; e < n_entities && e < w->body_gen_host.size(); ++e) gens[e] = w->body_gen_host[e];
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        HIP_TRY(w->isl_gen.ensure(n_entities * 4));
+        HIP_TRY(hipMemcpy(w->isl_gen.p, gens.data(), n_entities * 4, hipMemcpyHostToDevice));
+        w->isl_gen_stale = false;
+    }
+    const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * w->flat.n_entities, 4096);
+    int rc = w->island_bp.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
+    if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->island_bp.error());
+    HIP_TRY(w->isl_keys_raw.ensure(cap * 8));
+
+    bge::IslandParams ip{};
+    ip.dt = gp.dt;
+    ip.gx = gp.gx;
+    ip.gy = gp.gy;
+    ip.gz = gp.gz;
+    ip.n_slots = n_slots;
+    ip.repose = gp.repose;
+    ip.entity_of_slot = w->entity_of_slot.as<uint32_t>();
+    ip.slot_of_entity = w->slot_of_entity.as<uint32_t>();
+    ip.gen_of_entity = w->isl_gen.as<uint32_t>();
+    ip.counts = w->isl_counts.as<uint32_t>();
+    ip.keys_raw = w->isl_keys_raw.as<uint64_t>();
+    ip.pair_cap = static_cast<uint32_t>(std::min<uint64_t>(cap, 0xffffffffu));
+    ip.parent = w->isl_slot_words.as<uint32_t>();
+    ip.member = ip.parent + n_slots;
+    ip.active = ip.member + n_slots;
+    ip.index_of_slot = ip.active + n_slots;
+    gp.entity_of_slot = w->entity_of_slot.as<uint32_t>();
+
+    HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
+    if (w->static_contacts) HIP_TRY(bge::launch_obstacles(w->stream, w->view, gp));
+    gp.obstacles_ready = 1u;
+    HIP_TRY(bge::launch_island_begin(w->stream, w->view, gp, ip, bullet_basis));
+    gp.repose = 0u; // (done: k_ground_select must not derive the quaternions a second time from the angles k_island_begin wrote)
+    bge::FilterPalette palette{};
+    if (int prc = filter_palette_of(w, &palette)) return prc;
+    rc = w->island_bp.run(w->stream, w->view, n_slots, w->isl_identity.as<uint32_t>(), nullptr, &palette, nullptr);
+    if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->island_bp.error());
+    const bge::PairSlices sl = w->island_bp.slices();
+    ip.bp_stage = sl.stage;
+    ip.bp_counts = sl.counts;
+    ip.bp_shard_cap = sl.shard_cap;
+    ip.bp_shards = sl.shards;
+    HIP_TRY(bge::launch_island_pair_keys(w->stream, w->view, ip));
+    HIP_TRY(hipMemcpyAsync(w->isl_counts_host, w->isl_counts.p, 16, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (w->isl_counts_host[3] & 2u || w->isl_counts_host[0] > ip.pair_cap) {
+        return fail(BGE_ERR_INVALID, "more overlapping body pairs than pair_capacity (%llu) holds: create the world with a larger pair_capacity",
+                    (unsigned long long)cap);
+    }
+    const uint32_t n_pairs = w->isl_counts_host[0];
+    w->isl_last_pairs = n_pairs;
+    w->isl_last_bodies = 0;
+    const int cur = w->isl_cur, prev = cur ^ 1;
+    if (n_pairs) {
+        HIP_TRY(w->isl_keys[cur].ensure(static_cast<size_t>(n_pairs) * 8));
+        HIP_TRY(w->isl_man[cur].ensure(static_cast<size_t>(n_pairs) * bge::kBoxManifoldWords * 4));
+        size_t tmp_bytes = 0;
+        HIP_TRY(bge::island_sort_keys(w->stream, nullptr, tmp_bytes, ip.keys_raw, w->isl_keys[cur].as<uint64_t>(), n_pairs));
+        HIP_TRY(w->isl_sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+        HIP_TRY(bge::island_sort_keys(w->stream, w->isl_sort_tmp.p, tmp_bytes, ip.keys_raw, w->isl_keys[cur].as<uint64_t>(), n_pairs));
+    }
+    ip.keys = w->isl_keys[cur].as<uint64_t>();
+    ip.man = w->isl_man[cur].as<uint32_t>();
+    ip.n_pairs = n_pairs;
+    ip.prev_keys = w->isl_keys[prev].as<uint64_t>();
+    ip.prev_man = w->isl_man[prev].as<uint32_t>();
+    ip.n_prev = w->isl_n_prev;
+    const uint64_t body_cap = std::max<uint64_t>(n_slots, 1);
+    HIP_TRY(w->isl_body_keys_raw.ensure(body_cap * 8));
+    HIP_TRY(w->isl_body_slot_raw.ensure(body_cap * 4));
+    ip.body_keys_raw = w->isl_body_keys_raw.as<uint64_t>();
+    ip.body_slot_raw = w->isl_body_slot_raw.as<uint32_t>();
+    ip.body_cap = static_cast<uint32_t>(body_cap);
+    w->isl_cur = prev; // (this sub-step's list is the next one's "previous", also when the rest finds nothing to do)
+    w->isl_n_prev = n_pairs;
+    if (n_pairs == 0 && !later_sub_step) return BGE_OK;
+    HIP_TRY(bge::launch_island_build(w->stream, w->view, ip, later_sub_step));
+    HIP_TRY(hipMemcpyAsync(w->isl_counts_host, w->isl_counts.p, 16, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    const uint32_t n_bodies = w->isl_counts_host[1];
+    w->isl_last_bodies = n_bodies;
+    if (n_bodies == 0) return BGE_OK;
+    HIP_TRY(w->isl_body_keys.ensure(static_cast<size_t>(n_bodies) * 8));
+    HIP_TRY(w->isl_body_slot.ensure(static_cast<size_t>(n_bodies) * 4));
+    {
+        size_t tmp_bytes = 0;
+        HIP_TRY(bge::island_sort_pairs(w->stream, nullptr, tmp_bytes, ip.body_keys_raw, w->isl_body_keys.as<uint64_t>(), ip.body_slot_raw,
+                                       w->isl_body_slot.as<uint32_t>(), n_bodies));
+        HIP_TRY(w->isl_sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+        HIP_TRY(bge::island_sort_pairs(w->stream, w->isl_sort_tmp.p, tmp_bytes, ip.body_keys_raw, w->isl_body_keys.as<uint64_t>(), ip.body_slot_raw,
+                                       w->isl_body_slot.as<uint32_t>(), n_bodies));
+    }
+    ip.body_keys = w->isl_body_keys.as<uint64_t>();
+    ip.body_slot = w->isl_body_slot.as<uint32_t>();
+    ip.n_bodies = n_bodies;
+    // every point the manifolds can hold: 4 on the plane + 4 x 4 on obstacles per body, 4 per pair; two rows a point
+    const uint64_t row_cap = 2ull * (20ull * n_bodies + 4ull * n_pairs);
+    HIP_TRY(w->isl_solver_bodies.ensure(static_cast<size_t>(n_bodies) * bge::kIslBodyBytes));
+    HIP_TRY(w->isl_rows.ensure(static_cast<size_t>(row_cap) * bge::kIslRowBytes));
+    ip.solver_bodies = w->isl_solver_bodies.p;
+    ip.rows = w->isl_rows.p;
+    ip.row_cap = static_cast<uint32_t>(std::min<uint64_t>(row_cap, 0xffffffffu));
+    HIP_TRY(bge::launch_island_solve(w->stream, w->view, gp, ip, bullet_basis));
     return BGE_OK;
 }
 
@@ -1346,6 +1510,7 @@ static int upload_bodies_impl(bge_world* w, uint64_t first, uint64_t count, cons
                 if (w->body_gen_host.size() < w->body_type_host.size()) w->body_gen_host.resize(w->body_type_host.size(), 0u);
                 w->body_shape_host[e] = sh;
                 w->body_gen_host[e] += 1u; // EnsureRigidBody re-creates the btRigidBody: its pairs and their manifolds are gone
+                w->isl_gen_stale = true;
                 w->obstacles_stale = true;
             }
         }
@@ -1506,7 +1671,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
     // launches on one stream), so it is off by default.
     uint32_t first_eager = 0;
     const bool use_graph = std::getenv("BGE_USE_GRAPH") != nullptr;
-    if (use_graph && !sub.no_repose && !w->ground_plane && !w->graph_disabled && phys && ticks >= 2 * bge_world::kGraphTicks && w->profiling != 2 &&
+    if (use_graph && !sub.no_repose && !w->ground_plane && !w->dynamic_contacts && !w->graph_disabled && phys && ticks >= 2 * bge_world::kGraphTicks && w->profiling != 2 &&
         !(flags & (BGE_TICK_BROADPHASE | BGE_TICK_AABBS | BGE_TICK_GATHER_ROOTS)) && w->flat.n_tiles_ticked <= bge_world::kGraphMaxTiles &&
         w->flat.n_tiles_ticked > 0) {
         const bool same = w->graph_exec && w->graph_flags == flags && w->graph_dt == dt && w->graph_g[0] == gravity[0] &&
@@ -1605,7 +1770,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
             }
             p.bp_partial = w->bp_partials.as<float4>();
         }
-        if (phys && (w->ground_plane || w->static_contacts)) {
+        if (phys && (w->ground_plane || w->static_contacts || w->dynamic_contacts)) {
             // Ground plane on.  Bullet's order inside PhysicsSystem::Update: teleport dirty bodies (before stepSimulation), then per
             // sub-step collision detection + solver, then integrateTransforms — so k_ground_select re-poses them (once per
             // stepSimulation call) and picks the bodies at the ground, k_ground collides and solves those, and the tick kernel
@@ -1645,6 +1810,9 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
                 gp.entity_of_slot = w->entity_of_slot.as<uint32_t>();
                 gp.box_list = w->box_list.as<uint32_t>();
                 gp.box_count = w->box_count.as<uint32_t>();
+            }
+            if (w->dynamic_contacts) {
+                if (int rc = island_substep(w, gp, n_slots, (flags & BGE_TICK_BULLET_BASIS) != 0, sub.no_repose != 0)) return rc;
             }
             HIP_TRY(bge::launch_ground(w->stream, w->view, gp, (flags & BGE_TICK_BULLET_BASIS) != 0));
             p.no_repose = 1u;
@@ -1882,6 +2050,52 @@ try {
     return BGE_OK;
 }
 BGE_CATCH_ALL("bge_world_set_static_contacts")
+
+int bge_world_set_dynamic_contacts(bge_world* w, int enabled)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    DeviceGuard guard(w->device);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->dynamic_contacts = enabled != 0;
+    w->isl_n_prev = 0; // (off and on again: the pair cache starts empty)
+    w->isl_gen_stale = true;
+    w->drop_graph();
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_set_dynamic_contacts")
+
+int bge_world_download_dynamic_pairs(bge_world* w, uint64_t cap, uint32_t* header3, float* points48, uint64_t* total)
+try {
+    if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
+    if (!total) return fail(BGE_ERR_INVALID, "total is NULL");
+    DeviceGuard guard(w->device);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    const uint32_t n = w->dynamic_contacts ? w->isl_n_prev : 0u;
+    *total = n;
+    const uint64_t take = std::min<uint64_t>(n, cap);
+    if (take == 0 || (!header3 && !points48)) return BGE_OK;
+    const int at = w->isl_cur ^ 1; // (island_substep flipped the generations)
+    std::vector<uint64_t> keys(take);
+    std::vector<uint32_t> man(take * bge::kBoxManifoldWords);
+    HIP_TRY(hipMemcpy(keys.data(), w->isl_keys[at].p, take * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(man.data(), w->isl_man[at].p, take * bge::kBoxManifoldWords * 4, hipMemcpyDeviceToHost));
+    for (uint64_t k = 0; k < take; ++k) {
+        const uint32_t* m = man.data() + k * bge::kBoxManifoldWords;
+        if (header3) {
+            header3[3 * k] = static_cast<uint32_t>(keys[k] >> 32);
+            header3[3 * k + 1] = static_cast<uint32_t>(keys[k]);
+            header3[3 * k + 2] = m[0];
+        }
+        if (points48) {
+            float* o = points48 + 48 * k;
+            for (uint32_t j = 0; j < 4; ++j) {
+                for (uint32_t q = 0; q < 12; ++q) o[12 * j + q] = j < m[0] ? reinterpret_cast<const float*>(m + 4)[12 * j + q] : 0.0f;
+            }
+        }
+    }
+    return BGE_OK;
+}
+BGE_CATCH_ALL("bge_world_download_dynamic_pairs")
 
 static int upload_restitution_impl(bge_world* w, uint64_t first, uint64_t count, const uint32_t* index, const float* restitution)
 {

@@ -120,6 +120,23 @@ class World:
         r = _arr(restitution, np.float32)
         check(lib().bge_world_upload_restitution(self._h, first, len(r), _p(r)))
 
+    def set_dynamic_contacts(self, enabled=True):
+        """Dynamic boxes collide with each other: a persistent manifold per pair, simulation islands of several bodies
+        (bge_world_set_dynamic_contacts)."""
+        check(lib().bge_world_set_dynamic_contacts(self._h, int(enabled)))
+
+    def download_dynamic_pairs(self):
+        """(hdr, points): hdr[k] = lower entity index, higher entity index, points of the k-th pair of Dynamic boxes in the pair
+        cache (ascending); points[k, j] = localA.xyz, localB.xyz, normalWorldOnB.xyz, distance, appliedImpulse, appliedImpulseLateral1."""
+        total = C.c_uint64(0)
+        check(lib().bge_world_download_dynamic_pairs(self._h, 0, None, None, C.byref(total)))
+        n = int(total.value)
+        hdr = np.zeros((max(n, 1), 3), np.uint32)
+        pts = np.zeros((max(n, 1), 4, 12), np.float32)
+        if n:
+            check(lib().bge_world_download_dynamic_pairs(self._h, n, _p(hdr), _p(pts), C.byref(total)))
+        return hdr[:n], pts[:n]
+
     def download_box_contacts(self, first=0, count=None):
         """(n_manifolds[count], header[count, 4, 2] = (other entity, points), points[count, 4, 4, 12]) — ascending other entity."""
         count = self.n - first if count is None else count

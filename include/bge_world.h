@@ -286,7 +286,7 @@ BGE_API int bge_world_download_contacts(bge_world* world, uint64_t first, uint64
  *       4-point persistent manifold per pair, all of a body's manifolds (the plane's too) in ONE sequential-impulse island per
  *       body — a static body merges no islands.  Combined friction = product of both frictions clamped to +-10, combined
  *       restitution = product of both restitutions (btManifoldResult), so RigidBody::restitution (:438) is live here.
- *       Not built: capsules against boxes (GJK / EPA), Dynamic against Dynamic.  A body holds at most 4 such manifolds (lowest
+ *       Not built: capsules against boxes (GJK / EPA); Dynamic against Dynamic is bge_world_set_dynamic_contacts.  A body holds at most 4 such manifolds (lowest
  *       entity indices); the Dynamic body is always the pair's body A — Bullet orders a pair by proxy creation, which the
  *       reference leaves to an unordered_map's iteration order (oracle/boxbox_ref.h states every such choice).
  *   bge_world_upload_restitution   RigidBody::restitution per entity (default 0, src/ecs/PhysicsComponents.h:33).
@@ -299,6 +299,25 @@ BGE_API int bge_world_upload_restitution(bge_world* world, uint64_t first, uint6
 BGE_API int bge_world_upload_restitution_indexed(bge_world* world, uint64_t count, const uint32_t* entity_index, const float* restitution);
 BGE_API int bge_world_download_box_contacts(bge_world* world, uint64_t first, uint64_t count, uint8_t* n_manifolds, uint32_t* header8,
                                             float* points192);
+/*
+ * Dynamic boxes against EACH OTHER (round 3, after SURVEY.md section 8(f) rank 4).  In the reference every RigidBody is a
+ * btRigidBody of one btDiscreteDynamicsWorld (src/physics/PhysicsSystem.cpp:122-131, 421-474): two Dynamic boxes collide, rest on
+ * each other, and bodies whose AABBs overlap form ONE simulation island that is solved together and sleeps / wakes together.
+ *   bge_world_set_dynamic_contacts  0 (default) = off; 1 = every pair of Dynamic bodies with BOX colliders whose fed AABBs overlap
+ *       and whose layer / mask pass both ways is a pair of the cache (body A = the lower entity index): btBoxBoxDetector into a 4-point
+ *       persistent manifold per pair; btSimulationIslandManager's rule — the bodies of every pair are united, touching or not; an
+ *       island sleeps only when none of its bodies is ACTIVE_TAG, otherwise its sleeping bodies turn WANTS_DEACTIVATION (timer 0,
+ *       no gravity until the stepSimulation call ends) — and btSequentialImpulseConstraintSolver over all manifolds of an island
+ *       (the bodies in ascending entity index, each body's plane manifold, its manifolds with Static / Kinematic boxes, its pairs
+ *       with Dynamic boxes of higher index: oracle/island_ref.h states why this order and not Bullet's pool order).  One device
+ *       thread solves one island; the sub-step reads two counters back (pairs, island bodies).  Capsules take no part (GJK / EPA).
+ *       Works with or without the plane and the static contacts; pair_capacity (bge_world_create) bounds the overlapping pairs.
+ *   bge_world_download_dynamic_pairs  the pair cache after the last tick in ascending (lower, higher) entity index: *total pairs;
+ *       for the first `cap`: header3 = lower index, higher index, points; points48 = 4 x (localA.xyz, localB.xyz, normalWorldOnB.xyz,
+ *       distance, appliedImpulse, appliedImpulseLateral1).  header3 / points48 may be NULL.
+ */
+BGE_API int bge_world_set_dynamic_contacts(bge_world* world, int enabled);
+BGE_API int bge_world_download_dynamic_pairs(bge_world* world, uint64_t cap, uint32_t* header3, float* points48, uint64_t* total);
 /* Scene::CountDirtyTransforms (src/ecs/Scene.cpp:435-446): a device-side wave-reduced count. */
 BGE_API int bge_world_dirty_count(bge_world* world, uint64_t* out);
 /* Overlapping pairs of the last BROADPHASE tick as (a, b) entity indices, a < b, unordered list.

@@ -1263,6 +1263,158 @@ def test_many_static_boxes_through_the_obstacle_grid_match_oracle_bitwise(grid, 
     assert (final_pos[dyn, 1] > 0.5).sum() > 600                             # the blocks caught most of the rain
 
 
+def _compare_dynamic_world(w, ref, tick, dyn, plane, static):
+    rb, gb = ref.bulk_bodies(), w.download_bodies()
+    ex = rb["exists"]
+    pos, euler = w.download_pose()
+    rpos, reuler = ref.bulk_pose()
+    st, tm = w.download_activation()
+    rst, rtm = ref.bulk_activation()
+    assert np.array_equal(st[ex], rst[ex].astype(np.uint8)), f"tick {tick}: activation states differ at {np.flatnonzero(st[ex] != rst[ex])[:8]}"
+    hdr, pts = w.download_dynamic_pairs()
+    rhdr, rpts = ref.DynamicPairs()
+    rhdr = rhdr.copy()
+    rhdr[:, :2] -= 1                                                          # entity id -> index
+    assert hdr.shape == rhdr.shape and np.array_equal(hdr, rhdr), f"tick {tick}: pair cache {hdr.tolist()[:6]} vs oracle {rhdr.tolist()[:6]}"
+    assert_bits_equal(pts, rpts, f"tick {tick}: points of the pair manifolds")
+    assert_bits_equal(gb["linvel"][dyn], rb["linvel"][dyn], f"tick {tick}: linear velocity")
+    assert_bits_equal(gb["angvel"][dyn], rb["angvel"][dyn], f"tick {tick}: angular velocity")
+    assert_bits_equal(pos, rpos, f"tick {tick}: position")
+    assert_bits_equal(gb["quat"][ex], rb["quat"][ex], f"tick {tick}: quaternion")
+    assert_bits_equal(euler, reuler, f"tick {tick}: rotationEuler")
+    assert_bits_equal(tm[ex & (rst == 1)], rtm[ex & (rst == 1)], f"tick {tick}: deactivation timers")
+    if plane:
+        cn, cpts = w.download_contacts()
+        for e in np.flatnonzero(dyn)[::3]:
+            rn, rpts2 = ref.GroundContacts(int(e) + 1)
+            assert cn[e] == rn, f"tick {tick}: body {e} has {cn[e]} plane contacts, oracle {rn}"
+            assert_bits_equal(cpts[e, :rn], rpts2, f"tick {tick}: plane contact points of body {e}")
+    if static:
+        nb, bh, bp = w.download_box_contacts()
+        for e in np.flatnonzero(dyn)[::3]:
+            want = ref.BoxContacts(int(e) + 1)
+            assert nb[e] == len(want), f"tick {tick}: body {e} has {nb[e]} box manifolds, oracle {len(want)}"
+            for k, (other, rows) in enumerate(want):
+                assert bh[e, k, 0] == other - 1 and bh[e, k, 1] == len(rows)
+                assert_bits_equal(bp[e, k, :len(rows)], rows, f"tick {tick}: body {e} manifold {k} points")
+    return st, hdr
+
+
+@pytest.mark.parametrize("basis,plane,static", [(False, True, False), (True, True, True), (False, False, True)],
+                         ids=["default-plane", "bullet_basis-plane-obstacles", "default-obstacles"])
+def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, static):
+    """Dynamic boxes collide with EACH OTHER (bge_world_set_dynamic_contacts; bge_contact.hip "islands" against oracle/island_ref.h and
+    physics_ref.h CollideDynamicPairs / StepIsland).  Three towers of five, a loose heap of 120 boxes of mixed size, mass, friction and
+    restitution raining on a 7 x 7 m patch (they pile up three deep), a far-away pair that only ever touches each other, a few
+    capsules and a filtered-out layer that take no part; the plane below and / or Static platforms.  A heavy box is thrown into the
+    first tower after everything fell asleep, a resting body is re-created, a tower's base is teleported away.  Every compared tick:
+    the pair cache (which pairs, their points and impulses), pose, rotationEuler, quaternion, velocities, plane and obstacle
+    manifolds, activation state and timers — bit for bit."""
+    rng = np.random.default_rng(99)
+    n_stat = 5 if static else 0
+    n_tower, n_heap, n_misc = 15, 120, 8
+    n = n_stat + n_tower + n_heap + n_misc + 2
+    wl = synth.Workload("heap", synth.FLAT, n, 777)
+    body_type = np.ones(n, np.uint8)
+    shape = np.zeros(n, np.uint8)
+    size = np.full((n, 3), 0.5, np.float32)
+    mass = np.ones(n, np.float32)
+    wl.scale[:] = 1.0
+    wl.euler[:] = 0.0
+    floor_y = 0.0
+    if static:
+        # a floor slab (top at y = 0.0 when the plane is off it is what everything rests on) and four platforms
+        wl.pos[0] = (0.0, -0.5, 0.0); size[0] = (30.0, 0.5, 30.0)
+        for k in range(1, 5):
+            wl.pos[k] = (-9.0 + 6.0 * k, 0.3, -6.0); size[k] = (1.5, 0.3, 1.5)
+        body_type[:n_stat] = 0
+    at = n_stat
+    for t in range(3):
+        for k in range(5):
+            wl.pos[at] = (-8.0 + 4.0 * t, floor_y + 0.5 + 1.0 * k + 0.002 * k, 6.0)
+            at += 1
+    heap = slice(at, at + n_heap)
+    wl.pos[heap, 0] = rng.uniform(-3.5, 3.5, n_heap).astype(np.float32)
+    wl.pos[heap, 2] = rng.uniform(-3.5, 3.5, n_heap).astype(np.float32)
+    wl.pos[heap, 1] = rng.uniform(0.6, 14.0, n_heap).astype(np.float32)
+    wl.euler[heap] = rng.uniform(-1.2, 1.2, (n_heap, 3)).astype(np.float32)
+    size[heap] = rng.uniform(0.2, 0.6, (n_heap, 3)).astype(np.float32)
+    mass[heap] = rng.choice([0.3, 1.0, 4.0], n_heap)
+    at += n_heap
+    misc = slice(at, at + n_misc)
+    wl.pos[misc, 0] = rng.uniform(-3.0, 3.0, n_misc).astype(np.float32)
+    wl.pos[misc, 2] = rng.uniform(-3.0, 3.0, n_misc).astype(np.float32)
+    wl.pos[misc, 1] = rng.uniform(3.0, 9.0, n_misc).astype(np.float32)
+    shape[at:at + 4] = 1                                                    # capsules: fall through the boxes
+    size[at:at + 4] = (0.3, 0.5, 0.3)
+    layer = np.ones(n, np.uint32)
+    mask = np.full(n, 0xFFFFFFFF, np.uint32)
+    layer[at + 4:at + n_misc] = 4
+    mask[heap] = 0xFFFFFFFB                                                 # the heap ignores layer 4: those boxes fall through it
+    at += n_misc
+    wl.pos[at] = (40.0, 0.5, 40.0)                                          # a pair far away: an island of its own
+    wl.pos[at + 1] = (40.2, 3.0, 40.1)
+    friction = rng.choice([0.2, 0.5, 1.0], n).astype(np.float32)
+    restitution = rng.choice([0.0, 0.0, 0.6], n).astype(np.float32)
+    mode = po.ORIENT_BASIS if basis else po.ORIENT_IDEAL
+    wl.body_type = body_type
+    ref = build_oracle(wl, orient_mode=mode, shape=shape, size=size, mass=mass, layer=layer, mask=mask)
+    for i in range(n):
+        ref.SetFriction(i + 1, float(friction[i]))
+        ref.SetRestitution(i + 1, float(restitution[i]))
+    ref.SetGroundPlane(plane)
+    ref.SetStaticContacts(static)
+    ref.SetDynamicContacts(True)
+    flags = B.TICK_ALL | (B.TICK_BULLET_BASIS if basis else 0)
+    dyn = body_type == 1
+    most_pairs, most_asleep, tower_woke = 0, 0, False
+    tower0 = np.arange(n_stat, n_stat + 5)
+    thrower = n_stat + n_tower + 3                                           # a heap box, re-created and thrown later
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(body_type, mass=mass, shape=shape, size=size, layer=layer, mask=mask)
+        w.upload_friction(friction)
+        w.upload_restitution(restitution)
+        w.set_ground_plane(plane)
+        w.set_static_contacts(static)
+        w.set_dynamic_contacts(True)
+        for tick in range(1100):
+            if tick == 700:   # the towers sleep (the heap keeps jittering, as heaps do in Bullet): a box is re-created beside the first tower and thrown into it
+                there = np.array([[-10.5, 2.6, 6.0]], np.float32)
+                ref.SetTRS(thrower + 1, pos=there[0])
+                ref.MarkBodyDirty(thrower + 1)
+                w.upload_trs(pos=there, first=thrower)
+                w.upload_bodies(body_type[thrower:thrower + 1], mass=mass[thrower:thrower + 1], shape=shape[thrower:thrower + 1], size=size[thrower:thrower + 1],
+                                layer=layer[thrower:thrower + 1], mask=mask[thrower:thrower + 1], first=thrower)
+            if tick == 702:
+                vel = np.zeros((n, 3), np.float32)
+                vel[thrower] = (9.0, 1.0, 0.0)
+                cur = w.download_bodies()["linvel"]
+                cur[thrower] = vel[thrower]
+                ref.bulk_set_velocity(cur, w.download_bodies()["angvel"])
+                w.set_velocities(cur, w.download_bodies()["angvel"])
+            if tick == 900:   # the base of the second tower is teleported away from under it
+                away = np.array([[20.0, 0.5, -20.0]], np.float32)
+                e = n_stat + 5
+                ref.SetTRS(e + 1, pos=away[0])
+                w.upload_trs(pos=away, first=e)
+            ref.PhysicsSystemUpdate(DT)
+            ref.TransformSystemUpdate()
+            w.tick(dt=DT, flags=flags)
+            if tick % 5 and tick > 10 and not (698 <= tick <= 712) and not (898 <= tick <= 905):
+                continue
+            st, hdr = _compare_dynamic_world(w, ref, tick, dyn, plane, static)
+            most_pairs = max(most_pairs, len(hdr))
+            most_asleep = max(most_asleep, int((st[dyn & (shape == 0)] == 2).sum()))
+            tower_woke = tower_woke or (tick > 702 and (st[tower0] != 2).all())
+        assert_bits_equal(w.download_world(), ref.bulk_world()[0], "world matrices at the end")
+        final_pos, _ = w.download_pose()
+    assert most_pairs > 150, most_pairs                                      # the heap is a real pile
+    assert most_asleep >= 15 and tower_woke                                  # whole islands fell asleep; the thrown box woke the first tower at once
+    assert final_pos[heap, 1].max() > 1.2                                    # boxes rest on boxes
+
+
 def test_ground_plane_switched_off_then_scene_grows_then_on_again():
     """the contact manifold store follows the slot layout whether the plane is on or off.  Bodies land and rest
     on the plane, the plane goes off (they fall on), the scene grows across several tile boundaries (bge_world_set_topology
