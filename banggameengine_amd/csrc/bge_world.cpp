@@ -1295,7 +1295,7 @@ try {
         HIP_TRY(hipMemsetAsync(w->manifold.p, 0, w->manifold.bytes, w->stream));
     }
     HIP_TRY(w->crestitution.ensure(S * 4)); // (k_init_slots writes the default, the carry below the surviving values)
-    if (w->static_contacts || w->bmanifold.p) { // (exists from the first bge_world_set_static_contacts(1) on and follows every layout, like the plane's store)
+    if (w->static_contacts || w->dynamic_contacts || w->bmanifold.p) { // (exists from the first bge_world_set_static_contacts(1) on and follows every layout, like the plane's store)
         HIP_TRY(w->bmanifold.ensure(S * bge::kBoxManifolds * bge::kBoxManifoldWords * 4));
         HIP_TRY(hipMemsetAsync(w->bmanifold.p, 0xff, w->bmanifold.bytes, w->stream));
     }
@@ -2056,6 +2056,14 @@ try {
     if (!w) return fail(BGE_ERR_INVALID, "world is NULL");
     DeviceGuard guard(w->device);
     HIP_TRY(hipStreamSynchronize(w->stream));
+    // (a body of an island collides its own pairs through contact_body, which keeps the obstacle manifold rows of its slot tidy
+    //  whether or not there are obstacles: the store exists from here on, as after bge_world_set_static_contacts(1))
+    const uint64_t bytes = std::max<uint64_t>(w->flat.n_slots, bge::kTile) * bge::kBoxManifolds * bge::kBoxManifoldWords * 4;
+    if (enabled && w->has_topology && w->bmanifold.bytes < bytes) {
+        HIP_TRY(w->bmanifold.ensure(bytes));
+        HIP_TRY(hipMemsetAsync(w->bmanifold.p, 0xff, w->bmanifold.bytes, w->stream)); // every row free (bge::kBoxNone)
+        w->rebuild_view();
+    }
     w->dynamic_contacts = enabled != 0;
     w->isl_n_prev = 0; // (off and on again: the pair cache starts empty)
     w->isl_gen_stale = true;
