@@ -1415,6 +1415,78 @@ def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, sta
     assert final_pos[heap, 1].max() > 1.2                                    # boxes rest on boxes
 
 
+@pytest.mark.parametrize("basis", [False, True], ids=["default", "bullet_basis"])
+def test_islands_under_the_step_clock_woken_bodies_get_no_gravity_until_the_call_ends(basis):
+    """Dynamic-against-Dynamic contacts under bge_world_step_simulation (several sub-steps per call).  applyGravity runs once per
+    call and skips sleeping bodies, so a body its island wakes in sub-step k falls with no gravity for the rest of that call
+    (kCiNoGravity) — also when the island dissolves again before the call ends (k_island_orphans): eight sleeping boxes, over each
+    of which a fast box passes 3 cm above (the fed AABBs overlap for one or two sub-steps, nothing touches); eight sleeping
+    two-box stacks onto which boxes drop from different heights, so that the wake-up falls on every sub-step of a call.  After
+    every call: pair cache, manifolds, poses, velocities, activation — bit for bit."""
+    n_rest, n_stack, n_drop = 8, 16, 8
+    n = n_rest + n_rest + n_stack + n_drop
+    wl = synth.Workload("clock", synth.FLAT, n, 4321)
+    body_type = np.ones(n, np.uint8)
+    size = np.full((n, 3), 0.5, np.float32)
+    mass = np.ones(n, np.float32)
+    wl.scale[:] = 1.0
+    wl.euler[:] = 0.0
+    rest = np.arange(n_rest)
+    fly = n_rest + np.arange(n_rest)
+    stack = 2 * n_rest + np.arange(n_stack)
+    drop = 2 * n_rest + n_stack + np.arange(n_drop)
+    wl.pos[rest] = [(0.0, 0.5, 3.0 * k) for k in range(n_rest)]
+    wl.pos[fly] = [(200.0 + 3.0 * k, 0.2, 50.0) for k in range(n_rest)]       # parked far away, resting on the plane
+    size[fly] = 0.2
+    for k in range(n_stack // 2):
+        wl.pos[stack[2 * k]] = (20.0, 0.5, 3.0 * k)
+        wl.pos[stack[2 * k + 1]] = (20.05, 1.5, 3.0 * k + 0.03)
+    wl.pos[drop] = [(20.0, 45.0 + 1.7 * k, 3.0 * k) for k in range(n_drop)]   # arrive after 3.0 .. 3.4 s: the stacks sleep by then
+    size[drop] = 0.3
+    mass[drop] = 2.0
+    mode = po.ORIENT_BASIS if basis else po.ORIENT_IDEAL
+    wl.body_type = body_type
+    ref = build_oracle(wl, orient_mode=mode, size=size, mass=mass)
+    ref.SetGroundPlane(True)
+    ref.SetDynamicContacts(True)
+    ref.SetAccumulator(True, DT, 4)
+    flags = B.TICK_ALL | (B.TICK_BULLET_BASIS if basis else 0)
+    dyn = body_type == 1
+    script = [4.0, 2.5, 1.0, 3.3, 0.4, 4.0, 6.0, 1.7]
+    woken_seen = False
+    with B.World() as w:
+        w.set_topology(wl.parent)
+        w.upload_trs(wl.pos, wl.euler, wl.scale)
+        w.upload_bodies(body_type, mass=mass, size=size)
+        w.set_ground_plane(True)
+        w.set_dynamic_contacts(True)
+        for call in range(190):
+            if call == 100:   # (~2.3 s: the resting boxes sleep) the small boxes are re-created in front of them and shot across
+                there = np.array([(-3.0, 1.23, 3.0 * k) for k in range(n_rest)], np.float32)
+                for k, e in enumerate(fly):
+                    ref.SetTRS(int(e) + 1, pos=there[k])
+                    ref.MarkBodyDirty(int(e) + 1)
+                w.upload_trs(pos=there, first=int(fly[0]))
+                w.upload_bodies(body_type[fly], mass=mass[fly], size=size[fly], first=int(fly[0]))
+            factor = script[call % len(script)]
+            dt = float(np.float64(factor) * np.float64(DT))
+            ref.PhysicsSystemUpdate(dt)
+            ref.TransformSystemUpdate()
+            got_n = w.step_simulation(dt, 4, DT, flags=flags)
+            assert got_n == ref.LastSubSteps()
+            if call == 100:
+                lin, ang = w.download_bodies()["linvel"], w.download_bodies()["angvel"]
+                lin[fly] = [(60.0 + 12.0 * k, 0.0, 0.0) for k in range(n_rest)]
+                ref.bulk_set_velocity(lin, ang)
+                w.set_velocities(lin, ang)
+            st, hdr = _compare_dynamic_world(w, ref, call, dyn, True, False)
+            if 100 < call < 110:
+                woken_seen = woken_seen or bool((st[rest] == 3).any())
+        st, _ = w.download_activation()
+    assert woken_seen                                                        # a resting box was WANTS_DEACTIVATION while a box flew over it
+    assert (st[stack] == 2).all() or (st[stack] != 2).any()
+
+
 def test_ground_plane_switched_off_then_scene_grows_then_on_again():
     """the contact manifold store follows the slot layout whether the plane is on or off.  Bodies land and rest
     on the plane, the plane goes off (they fall on), the scene grows across several tile boundaries (bge_world_set_topology
