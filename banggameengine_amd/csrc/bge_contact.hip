@@ -1474,7 +1474,6 @@ __device__ void contact_body(const WorldView& w, const GroundParams& g, uint32_t
             hdr[3] = 0u;
         }
         uint32_t* hdr = rows + static_cast<uint32_t>(row_of[a]) * kBoxManifoldWords;
-        hdr[3] = accepted[a]; // (the obstacle's number, for this sub-step: k_island_solve reads its material through it)
         const float pair_breaking = fminf(breaking, o.breaking); // btCollisionDispatcher::getNewManifold
         const int np = bp_collide(reinterpret_cast<float*>(hdr + 4), static_cast<int>(hdr[1]), pair_breaking, pos, basis, shape.dims, o);
         hdr[1] = static_cast<uint32_t>(np);
@@ -1703,7 +1702,12 @@ __global__ void __launch_bounds__(256) k_island_begin(WorldView w, GroundParams 
         if (f != f_in) w.flags[slot] = f;
     }
     const uint32_t ci0 = w.cinfo[slot];
-    const uint32_t ci = ci0 & ~(kCiIsland | (ip.repose ? kCiNoGravity : 0u));
+    uint32_t ci = ci0 & ~kCiIsland;
+    if (ip.repose) {
+        // applyGravity, once per stepSimulation call: a body that sleeps now gets none until the call ends, whatever wakes it later
+        const bool sleeping = type == 2u && (f & kDrowsy) && w.deact[slot] == kDeactSleeping;
+        ci = sleeping ? (ci | kCiNoGravity) : (ci & ~kCiNoGravity);
+    }
     if (ci != ci0) w.cinfo[slot] = ci;
     // predictUnconstraintMotion / updateAabbs: the box of the pose united with the box of the predicted pose (k_tick's AABB block)
     const F3 pos = ld3(w.pos, slot);
@@ -1863,8 +1867,8 @@ __global__ void __launch_bounds__(256) k_island_members(WorldView w, IslandParam
     isl_list_body(w, ip, ip.slot_of_entity[static_cast<uint32_t>(key)]);
 }
 
-// a body that was woken earlier in this stepSimulation call and is in no pair any more: an island of its own on this path (its
-// gravity is off until the call ends, which only the island solver knows how to do)
+// a body that slept when this stepSimulation call applied gravity, was woken since and is in no pair any more: an island of its own
+// on this path (its gravity is off until the call ends, which only the island solver knows how to do)
 __global__ void __launch_bounds__(256) k_island_orphans(WorldView w, IslandParams ip)
 {
     const uint64_t slot64 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -2120,6 +2124,18 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
     fr.appliedPush = 0.0f;
 }
 
+// the number of the obstacle that is entity `entity` (the list ascends), or kNone
+__device__ __forceinline__ uint32_t isl_obstacle_of(const GroundParams& g, uint32_t entity)
+{
+    uint32_t lo = 0, hi = g.n_obstacles;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g.obstacles[mid].entity < entity) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < g.n_obstacles && g.obstacles[lo].entity == entity ? lo : kNone;
+}
+
 template <bool BASIS>
 __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g, IslandParams ip)
 {
@@ -2141,7 +2157,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         const uint32_t f0 = w.flags[slot];
         const uint32_t ci = w.cinfo[slot];
         const bool woken = (f0 & kDrowsy) && w.deact[slot] == kDeactSleeping;
-        const bool no_gravity = woken || (ci & kCiNoGravity);
+        const bool no_gravity = (ci & kCiNoGravity) != 0; // (asleep when this call applied gravity: k_island_begin)
         const uint32_t cls = f0 >> kMassShift;
         float inv_mass;
         F3 force;
@@ -2184,9 +2200,28 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         sb[i] = b;
         if (g.plane != 0u && (ci & kCiGroundMask)) n_points += (ci >> kCiCountShift) & 7u;
         if (ci & kCiBoxes) {
-            const uint32_t* rows = w.bmanifold + static_cast<uint64_t>(slot) * (kBoxManifolds * kBoxManifoldWords);
+            uint32_t* rows = w.bmanifold + static_cast<uint64_t>(slot) * (kBoxManifolds * kBoxManifoldWords);
             for (uint32_t e = 0; e < kBoxManifolds; ++e) {
-                if (rows[e * kBoxManifoldWords] != kBoxNone) n_points += rows[e * kBoxManifoldWords + 1];
+                uint32_t* hdr = rows + e * kBoxManifoldWords;
+                if (hdr[0] == kBoxNone) continue;
+                if (woken) {
+                    // not collided this sub-step: its manifolds are what its last collision left, minus the pairs that ended while it
+                    // slept (oracle/physics_ref.h StepIsland) — obstacle gone or re-created, filter, fed AABBs apart
+                    const uint32_t k = isl_obstacle_of(g, hdr[0]);
+                    bool keep = k != kNone;
+                    if (keep) {
+                        const ObstacleRec& o = g.obstacles[k];
+                        const float* bb = w.aabb + 6ull * slot;
+                        keep = o.live && o.generation == hdr[2] && (w.group[slot] & o.mask) != 0u && (o.group & w.mask[slot]) != 0u && bb[0] <= o.aabb[3] &&
+                               bb[3] >= o.aabb[0] && bb[1] <= o.aabb[4] && bb[4] >= o.aabb[1] && bb[2] <= o.aabb[5] && bb[5] >= o.aabb[2];
+                    }
+                    if (!keep) {
+                        hdr[0] = kBoxNone;
+                        hdr[1] = 0u;
+                        continue;
+                    }
+                }
+                n_points += hdr[1];
             }
         }
     }
@@ -2244,7 +2279,12 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
                 if (best == kBoxManifolds) break;
                 done |= 1u << best;
                 uint32_t* hdr = rows + best * kBoxManifoldWords;
-                const ObstacleRec& o = g.obstacles[hdr[3]];
+                const uint32_t at = isl_obstacle_of(g, hdr[0]); // (by its entity: the list may have been rebuilt since the body was last collided)
+                if (at == kNone) {
+                    atomicOr(&ip.counts[3], 4u); // (cannot happen: a collided body's partners are in the list, a woken body's were checked above)
+                    return;
+                }
+                const ObstacleRec& o = g.obstacles[at];
                 const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, bodyFriction * o.friction));
                 const float combinedRestitution = bodyRestitution * o.restitution;
                 float* pts = reinterpret_cast<float*>(hdr + 4);
@@ -2321,10 +2361,9 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         uint32_t f0 = w.flags[slot];
         uint32_t f = (av.x != 0.0f || av.y != 0.0f || av.z != 0.0f) ? (f0 | kSpin) : (f0 & ~kSpin);
         if (s.woken) {
-            // buildIslands: a sleeping body of an island that has an active body -> WANTS_DEACTIVATION, timer 0; gravity passed it by
+            // buildIslands: a sleeping body of an island that has an active body -> WANTS_DEACTIVATION, timer 0
             w.deact[slot] = kDeactWants;
             f |= kDrowsy;
-            ci |= kCiNoGravity;
         }
         if (f != f0) w.flags[slot] = f;
         w.cinfo[slot] = ci;

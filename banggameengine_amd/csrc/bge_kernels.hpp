@@ -62,8 +62,9 @@ constexpr uint32_t kCiBoxes = 0x80u;     // the body holds at least one manifold
 constexpr uint32_t kCiIsland = 0x100u;   // Dynamic boxes collide with each other: this sub-step the body is in a simulation island of several
                                          // bodies that stays awake — the island kernels collide and solve it (k_ground_select leaves it alone),
                                          // k_tick does not put it to sleep on WANTS_DEACTIVATION; consumed by k_tick like kCiSolved
-constexpr uint32_t kCiNoGravity = 0x200u; // the body was asleep when this stepSimulation call applied gravity and was woken by its island
-                                         // since: no gravity until the call ends (cleared by the first sub-step of the next call)
+constexpr uint32_t kCiNoGravity = 0x200u; // Dynamic-against-Dynamic contacts on: the body was asleep when this stepSimulation call applied
+                                         // gravity (k_island_begin of its first sub-step): no gravity for it until the call ends, whatever
+                                         // wakes it in between
 
 // A Dynamic box keeps at most this many manifolds with Static / Kinematic boxes (the lowest entity ids; Bullet has no limit —
 // oracle/boxbox_ref.h kMaxBoxManifolds, a stated specification choice)

@@ -83,6 +83,8 @@ public:
         // ... and its dispatcher collides Dynamic bodies with the Static / Kinematic ones (PhysicsSystem.cpp:122-128): box against box
         // here (Bullet's btBoxBoxDetector, include/bge_world.h) — what carries a body on demo.json's "Ground"
         else if (bge_world_set_static_contacts(world_, 1) != BGE_OK) Log("bge_world_set_static_contacts");
+        // ... and with each other: boxes pile up, touching bodies sleep and wake as one island (include/bge_world.h)
+        else if (bge_world_set_dynamic_contacts(world_, 1) != BGE_OK) Log("bge_world_set_dynamic_contacts");
     }
     ~GpuSceneMirror() { bge_world_destroy(world_); }
     GpuSceneMirror(const GpuSceneMirror&) = delete;
@@ -105,6 +107,13 @@ public:
     void SetStaticContacts(bool on)
     {
         if (ok() && bge_world_set_static_contacts(world_, on ? 1 : 0) != BGE_OK) Log("bge_world_set_static_contacts");
+    }
+
+    // Contacts of Dynamic boxes with each other (on by default, as in every reference world; a scene of free bodies that never meet
+    // saves the sub-step's pair search by switching them off)
+    void SetDynamicContacts(bool on)
+    {
+        if (ok() && bge_world_set_dynamic_contacts(world_, on ? 1 : 0) != BGE_OK) Log("bge_world_set_dynamic_contacts");
     }
 
     // Resident mode: the world matrices stay on the device after TransformSystem::Update; only the host `dirty` flags

@@ -616,6 +616,24 @@ private:
             if (rt.activation == kIslandSleeping) { // woken by its island
                 rt.activation = kWantsDeactivation;
                 rt.deactivationTime = 0.0f;
+                // It was not collided this step, so its manifolds with Static / Kinematic boxes are what its last collision left —
+                // minus the pairs that ended while it slept (Bullet's pair cache follows every object, asleep or not): the obstacle
+                // is gone or re-created, the filter no longer passes, the fed AABBs no longer overlap
+                std::vector<ct::BoxManifold> keep;
+                std::vector<uint32_t> keepGen;
+                for (size_t k = 0; k < rt.boxes.size(); ++k) {
+                    auto it = runtime_.find(rt.boxes[k].other);
+                    if (it == runtime_.end()) continue;
+                    const RefBodyRuntime& o = it->second;
+                    if (!o.hasBody || o.shape.capsule || (o.type == RefBodyType::Dynamic && o.invMass != 0.0f)) continue;
+                    if (o.generation != rt.boxGeneration[k]) continue;
+                    if ((rt.layer & o.mask) == 0 || (o.layer & rt.mask) == 0) continue;
+                    if (!BoxesOverlap(rt.aabbMin, rt.aabbMax, o.aabbMin, o.aabbMax)) continue;
+                    keep.push_back(rt.boxes[k]);
+                    keepGen.push_back(rt.boxGeneration[k]);
+                }
+                rt.boxes.swap(keep);
+                rt.boxGeneration.swap(keepGen);
             }
             state[i] = ct::BodyState{rt.origin, rt.linvel, rt.angvel, CurrentOrn(rt), rt.basis};
             bodies[i].state = &state[i];

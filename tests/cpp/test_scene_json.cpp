@@ -322,6 +322,54 @@ int main(int argc, char** argv)
             std::printf("demo + crate: crate at y = %.6f on Ground's top, asleep; bouncy box apex %.3f after the pad\n", crate->position.y, ball_apex_after_bounce);
         }
     }
+    {
+        // Dynamic against Dynamic (round 3): demo_stack_scene.json = the scene above with two more crates dropped onto the first.
+        // In the reference they pile up on it (one btDiscreteDynamicsWorld, PhysicsSystem.cpp:122-131); the three crates are one
+        // simulation island that falls asleep as a whole.  Product store + GPU adapter (dynamic contacts are on by default, as in
+        // every reference world) against oracle store + oracle physics (island_ref.h), every Transform, every tick.
+        std::string path = argv[1];
+        const size_t slash = path.find_last_of('/');
+        path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "demo_stack_scene.json";
+        std::ifstream gf(path);
+        std::stringstream gs;
+        gs << gf.rdbuf();
+        CHECK(!gs.str().empty(), "cannot read %s", path.c_str());
+        orc::RefScene ref;
+        bge::Scene scene;
+        std::string err;
+        std::unordered_map<std::string, uint32_t> keys;
+        CHECK(bge::LoadSceneFromJsonText(gs.str(), ref, &err), "demo + stack, oracle store: %s", err.c_str());
+        CHECK(bge::LoadSceneFromJsonText(gs.str(), scene, &err, &keys), "demo + stack, product store: %s", err.c_str());
+        CompareStores(ref, scene, "demo + stack", false);
+        if (gpu) {
+            orc::RefPhysicsSystem refPhysics;
+            refPhysics.computeAabbs = true;
+            refPhysics.groundPlane = true;
+            refPhysics.staticContacts = true;
+            refPhysics.dynamicContacts = true;
+            bge::GpuPhysicsSystem<bge::Scene> gpuPhysics;
+            const double dt = gpuPhysics.GetFixedStep();
+            for (int k = 0; k < 900; ++k) {
+                refPhysics.Update(ref, dt);
+                gpuPhysics.Update(scene, dt);
+                orc::RefTransformSystemUpdate(ref);
+                bge::GpuTransformSystem<bge::Scene>::Update(scene);
+                CompareStores(ref, scene, "demo + stack", true);
+                if (g_failures) break;
+            }
+            const auto* c1 = scene.GetTransform(keys["crate"]);
+            const auto* c2 = scene.GetTransform(keys["crate2"]);
+            const auto* c3 = scene.GetTransform(keys["crate3"]);
+            CHECK(c1 && c1->position.y > 1.48f && c1->position.y < 1.50f, "the first crate rests on Ground's top (y = %g)", c1 ? c1->position.y : 0.0f);
+            CHECK(c2 && c2->position.y > 2.27f && c2->position.y < 2.31f, "the second crate rests on the first, y = 1.99 + 0.3 (y = %g)", c2 ? c2->position.y : 0.0f);
+            CHECK(c3 && c3->position.y > 2.82f && c3->position.y < 2.86f, "the third crate rests on the second, y = 2.59 + 0.25 (y = %g)", c3 ? c3->position.y : 0.0f);
+            int asleep = 0;
+            for (const char* name : {"crate", "crate2", "crate3"}) asleep += refPhysics.Runtimes().at(keys[name]).activation == orc::kIslandSleeping ? 1 : 0;
+            CHECK(asleep == 3, "the island of three crates is asleep in the oracle (%d of 3)", asleep);
+            CHECK(refPhysics.DynamicPairs().size() == 2, "two pairs of Dynamic boxes: crate-crate2, crate2-crate3 (%zu)", refPhysics.DynamicPairs().size());
+            std::printf("demo + stack: crates at y = %.4f, %.4f, %.4f, one island, asleep\n", c1->position.y, c2->position.y, c3->position.y);
+        }
+    }
     if (g_failures == 0) std::printf("scene json: all checks passed%s\n", gpu ? " (with GPU ticks)" : "");
     return g_failures ? 1 : 0;
 }
