@@ -424,8 +424,17 @@ private:
             index_of_[kv.first] = i;
             fresh_.push_back(i);
         }
+        // New entities take their indices in ASCENDING ENTITY ID (the store is an unordered_map): where the device orders entities — the
+        // lowest four obstacles of a body, body A of a pair of Dynamic boxes, the bodies and manifolds of a simulation island — it
+        // orders by index, the oracle by entity id; for entities that first appear together (a loaded scene) the two agree.  A reused
+        // index (free list) can break the agreement: results stay deterministic, the solver's row order is then another one.
+        new_ids_.clear();
         for (auto& kv : transforms) {
-            if (index_of_.count(kv.first)) continue;
+            if (!index_of_.count(kv.first)) new_ids_.push_back(kv.first);
+        }
+        std::sort(new_ids_.begin(), new_ids_.end());
+        for (const Id new_id : new_ids_) {
+            struct { Id first; } kv{new_id};
             uint32_t i;
             while (!free_.empty() && !is_free_[free_.back()]) free_.pop_back(); // taken back above
             if (!free_.empty()) {
@@ -600,6 +609,7 @@ private:
     std::vector<Id> last_ids_;                  // dense index -> the id it last belonged to
     std::unordered_map<Id, uint32_t> index_of_;
     std::vector<uint32_t> parent_, free_, fresh_, index_list_, gone_bodies_;
+    std::vector<Id> new_ids_;
     std::vector<uint8_t> has_tf_, written_, limbo_, seen_, is_free_, has_trigger_, seen_trigger_;
     std::unordered_map<Id, uint32_t> retired_;  // last index of ids that lost their Transform
     std::unordered_map<Id, uint32_t> orphan_of_; // ids without a Transform whose body lives on, on the index they had
