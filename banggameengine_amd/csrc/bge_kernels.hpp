@@ -149,6 +149,7 @@ struct IslandParams {
     void* solver_bodies;            // [n_bodies] IslBody
     void* rows;                     // [row_cap] IslRow x 2 per contact point
     uint32_t row_cap;
+    uint32_t iterations;            // 10 (btContactSolverInfo::m_numIterations); BGE_ISLAND_ITERATIONS overrides it for MEASUREMENTS only
 };
 constexpr uint32_t kIslBodyBytes = 160, kIslRowBytes = 128;
 

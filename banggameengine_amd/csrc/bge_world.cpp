@@ -1010,6 +1010,8 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     ip.solver_bodies = w->isl_solver_bodies.p;
     ip.rows = w->isl_rows.p;
     ip.row_cap = static_cast<uint32_t>(std::min<uint64_t>(row_cap, 0xffffffffu));
+    ip.iterations = 10u;
+    if (const char* e = std::getenv("BGE_ISLAND_ITERATIONS")) ip.iterations = static_cast<uint32_t>(std::strtoul(e, nullptr, 10)); // (measurements: what the set-up costs)
     HIP_TRY(bge::launch_island_solve(w->stream, w->view, gp, ip, bullet_basis));
     return BGE_OK;
 }
