@@ -389,6 +389,66 @@ def measure_ground_config(B, synth, torch, entities, check):
         world.close()
 
 
+def measure_stacks_config(B, synth, torch, check, n=200_000):
+    """Dynamic boxes against each other (bge_world_set_dynamic_contacts; after SURVEY 8(f) rank 4): n / 2 two-box stacks resting on
+    the plane — n / 2 pairs, n / 2 simulation islands of two, every island through the pair cache, the narrowphase and one solver
+    thread — timed awake and resting.  The checker replays the first 512 stacks on the oracle (island_ref.h)."""
+    import numpy as np
+    from banggameengine_amd.world import FIXED_DT, GRAVITY
+    wl = synth.config("flat1m", n=n)
+    side = int(np.ceil(np.sqrt(n / 2)))
+    k = np.arange(n)
+    wl.pos[:, 0] = ((k // 2) % side).astype(np.float32) * 4.0
+    wl.pos[:, 2] = ((k // 2) // side).astype(np.float32) * 4.0
+    wl.pos[:, 1] = (0.5 + 1.0 * (k % 2)).astype(np.float32)
+    wl.euler[:] = 0.0
+    wl.body_type[:] = 1
+    stream = torch.cuda.current_stream()
+    world = B.World(stream=stream.cuda_stream, pair_capacity=16 * n)
+    try:
+        world.load(wl)
+        world.set_ground_plane(True)
+        world.set_dynamic_contacts(True)
+        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=B.TICK_ALL, ticks=30)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        world.tick(dt=FIXED_DT, gravity=GRAVITY, flags=B.TICK_ALL, ticks=60)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 60 * 1e3
+        hdr, _ = world.download_dynamic_pairs()
+        out = {"label": "Dynamic boxes against each other: two-box stacks resting on the plane (pair cache, islands, one solver thread per island)",
+               "workload": "two-box stacks + ground plane + dynamic contacts", "entities": n, "pairs": int(len(hdr)), "ms_per_step": ms,
+               "value": n / (ms * 1e-3),
+               "note": "wall clock per tick, two counter read-backs per sub-step included; sequential impulses inside an island: no roofline fraction is quoted"}
+        if check:
+            from oracle import pyoracle as po
+            sample = 1024
+            swl = synth.config("flat1m", n=sample)
+            swl.pos[:] = wl.pos[:sample]
+            swl.euler[:] = 0.0
+            swl.body_type[:] = 1
+            parent_i32 = np.where(swl.parent == 0xFFFFFFFF, -1, swl.parent.astype(np.int64)).astype(np.int32)
+            ref = po.RefScene().bulk_build(parent_i32, swl.pos, swl.euler, swl.scale, body_type=swl.body_type)
+            ref.SetPhysicsOptions(gravity_y=-9.81, orient_mode=po.ORIENT_IDEAL)
+            ref.SetGroundPlane(True)
+            ref.SetDynamicContacts(True)
+            for _ in range(90):
+                ref.PhysicsSystemUpdate(FIXED_DT)
+                ref.TransformSystemUpdate()
+            want_p, _ = ref.bulk_pose()
+            want_v = ref.bulk_bodies()["linvel"]
+            ref.close()
+            got_p, _ = world.download_pose(0, sample)
+            got_v = world.download_bodies(0, sample)["linvel"]
+            same = bool(np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32)) and np.array_equal(got_v.view(np.uint32), want_v.view(np.uint32)))
+            err = float(np.max(np.abs(got_p.astype(np.float64) - want_p.astype(np.float64))))
+            out["parity"] = {"checker": "oracle port (CPU) with its island restatement, same tick sequence", "sample_entities": sample, "ticks": 90,
+                             "max_abs_err_position": err, "bit_identical": same, "ok": bool(err <= 1e-5)}
+        return out
+    finally:
+        world.close()
+
+
 # ----------------------------------------------------------------------------------------------------------- a rank
 def run_rank(args):
     # stdout carries exactly ONE line, the result.  Libraries print there too (RCCL writes its version banner to fd 1
@@ -797,6 +857,14 @@ def run_rank(args):
                 rc = rc or 4
         except Exception as e:
             extras.append({"label": "configs[1] on the reference's ground plane", "workload": "flat1m + ground plane", "error": repr(e)})
+            rc = rc or 5
+        try:   # (beyond SURVEY 8(f): Dynamic boxes against each other)
+            extras.append(measure_stacks_config(B, synth, torch, check))
+            if extras[-1].get("parity", {}).get("ok") is False:
+                print("[bench] PARITY FAILURE on the two-box stacks: the device state is outside 1e-5 of the CPU port", file=sys.stderr)
+                rc = rc or 4
+        except Exception as e:
+            extras.append({"label": "Dynamic boxes against each other: two-box stacks", "workload": "two-box stacks + ground plane + dynamic contacts", "error": repr(e)})
             rc = rc or 5
         out["configs"] = extras
 
