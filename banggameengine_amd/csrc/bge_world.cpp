@@ -894,7 +894,10 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
 {
     const uint64_t n_entities = std::max<uint64_t>(w->flat.n_entities, 1);
     HIP_TRY(w->isl_slot_words.ensure(std::max<uint64_t>(n_slots, 1) * 16));
-    HIP_TRY(w->isl_counts.ensure(64));
+    if (!w->isl_counts.p) {
+        HIP_TRY(w->isl_counts.ensure(64));
+        HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
+    }
     if (!w->isl_counts_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->isl_counts_host), 64));
     if (w->isl_identity_n < n_slots) {
         std::vector<uint32_t> iota(n_slots);
@@ -936,7 +939,7 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     ip.index_of_slot = ip.active + n_slots;
     gp.entity_of_slot = w->entity_of_slot.as<uint32_t>();
 
-    HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
+    HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 12, w->stream)); // (word 3, the error bits, stays: the solver's are read with the NEXT sub-step's counts)
     if (w->static_contacts) HIP_TRY(bge::launch_obstacles(w->stream, w->view, gp));
     gp.obstacles_ready = 1u;
     HIP_TRY(bge::launch_island_begin(w->stream, w->view, gp, ip, bullet_basis));
@@ -953,7 +956,13 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     HIP_TRY(bge::launch_island_pair_keys(w->stream, w->view, ip));
     HIP_TRY(hipMemcpyAsync(w->isl_counts_host, w->isl_counts.p, 16, hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    if (w->isl_counts_host[3] & 5u) {
+        HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
+        return fail(BGE_ERR_HIP, "internal error in the island solver of the previous sub-step (bits %#x): row pool exhausted or an obstacle record missing",
+                    w->isl_counts_host[3]);
+    }
     if (w->isl_counts_host[3] & 2u || w->isl_counts_host[0] > ip.pair_cap) {
+        HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
         return fail(BGE_ERR_INVALID, "more overlapping body pairs than pair_capacity (%llu) holds: create the world with a larger pair_capacity",
                     (unsigned long long)cap);
     }

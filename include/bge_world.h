@@ -312,6 +312,8 @@ BGE_API int bge_world_download_box_contacts(bge_world* world, uint64_t first, ui
  *       with Dynamic boxes of higher index: oracle/island_ref.h states why this order and not Bullet's pool order).  One device
  *       thread solves one island; the sub-step reads two counters back (pairs, island bodies).  Capsules take no part (GJK / EPA).
  *       Works with or without the plane and the static contacts; pair_capacity (bge_world_create) bounds the overlapping pairs.
+ *       Islands live inside ONE world: a scene sharded over several worlds (bge_partition_subtrees) does not collide bodies of
+ *       different shards with each other.
  *   bge_world_download_dynamic_pairs  the pair cache after the last tick in ascending (lower, higher) entity index: *total pairs;
  *       for the first `cap`: header3 = lower index, higher index, points; points48 = 4 x (localA.xyz, localB.xyz, normalWorldOnB.xyz,
  *       distance, appliedImpulse, appliedImpulseLateral1).  header3 / points48 may be NULL.

@@ -1487,6 +1487,27 @@ def test_islands_under_the_step_clock_woken_bodies_get_no_gravity_until_the_call
     assert (st[stack] == 2).all() or (st[stack] != 2).any()
 
 
+def test_more_overlapping_pairs_than_pair_capacity_is_an_error_not_a_silent_drop():
+    """bge_world_set_dynamic_contacts: the sub-step's pair search keeps at most pair_capacity pairs; a pile that overlaps more fails
+    the tick with an error that names the knob (a dropped pair would be two bodies passing through each other)."""
+    n = 3000
+    rng = np.random.default_rng(8)
+    wl = synth.Workload("dense", synth.FLAT, n, 99)
+    wl.pos[:] = rng.uniform(-2.0, 2.0, (n, 3)).astype(np.float32)          # 3,000 unit boxes in a 4 m cube: every body overlaps hundreds
+    wl.pos[:, 1] += np.float32(3.0)
+    wl.euler[:] = 0.0
+    wl.scale[:] = 1.0
+    wl.body_type[:] = 1
+    with B.World(pair_capacity=4096) as w:
+        w.load(wl)
+        w.set_dynamic_contacts(True)
+        with pytest.raises(Exception) as err:
+            w.tick(dt=DT, flags=B.TICK_ALL)
+        assert "pair_capacity" in str(err.value)
+        w.set_dynamic_contacts(False)                                       # the world is still usable without the switch
+        w.tick(dt=DT, flags=B.TICK_ALL)
+
+
 def test_ground_plane_switched_off_then_scene_grows_then_on_again():
     """the contact manifold store follows the slot layout whether the plane is on or off.  Bodies land and rest
     on the plane, the plane goes off (they fall on), the scene grows across several tile boundaries (bge_world_set_topology
