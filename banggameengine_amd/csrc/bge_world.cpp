@@ -224,6 +224,7 @@ struct bge_world {
     uint64_t isl_identity_n = 0;
     bool isl_gen_stale = true;
     uint32_t isl_last_pairs = 0, isl_last_bodies = 0;
+    uint64_t isl_pair_cap = 0; // pair capacity of island_bp (grows by itself unless bge_world_create fixed pair_capacity)
     bool pairs_from_slab = false;          // bge_world_pairs reads the slab search (global ids) instead of the local one
     std::vector<uint32_t> global_id_host;  // per entity index; empty = identity
     DevBuf global_of_slot, bp_send, bp_recv, bp_small, bp_hist;
@@ -915,10 +916,10 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
         HIP_TRY(hipMemcpy(w->isl_gen.p, gens.data(), n_entities * 4, hipMemcpyHostToDevice));
         w->isl_gen_stale = false;
     }
-    const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * w->flat.n_entities, 4096);
-    int rc = w->island_bp.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
-    if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->island_bp.error());
-    HIP_TRY(w->isl_keys_raw.ensure(cap * 8));
+    // pair_capacity: what bge_world_create was given, or — left to the world — 8 pairs per entity to begin with, doubled whenever a
+    // sub-step finds more (the pair search reports Dynamic-Static pairs too: a dropped pair would be two bodies passing through each other)
+    if (w->isl_pair_cap == 0) w->isl_pair_cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * w->flat.n_entities, 4096);
+    if (!w->pair_capacity_req) w->isl_pair_cap = std::max<uint64_t>(w->isl_pair_cap, std::max<uint64_t>(8 * w->flat.n_entities, 4096));
 
     bge::IslandParams ip{};
     ip.dt = gp.dt;
@@ -931,8 +932,6 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     ip.slot_of_entity = w->slot_of_entity.as<uint32_t>();
     ip.gen_of_entity = w->isl_gen.as<uint32_t>();
     ip.counts = w->isl_counts.as<uint32_t>();
-    ip.keys_raw = w->isl_keys_raw.as<uint64_t>();
-    ip.pair_cap = static_cast<uint32_t>(std::min<uint64_t>(cap, 0xffffffffu));
     ip.parent = w->isl_slot_words.as<uint32_t>();
     ip.member = ip.parent + n_slots;
     ip.active = ip.member + n_slots;
@@ -946,25 +945,35 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     gp.repose = 0u; // (done: k_ground_select must not derive the quaternions a second time from the angles k_island_begin wrote)
     bge::FilterPalette palette{};
     if (int prc = filter_palette_of(w, &palette)) return prc;
-    rc = w->island_bp.run(w->stream, w->view, n_slots, w->isl_identity.as<uint32_t>(), nullptr, &palette, nullptr);
-    if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->island_bp.error());
-    const bge::PairSlices sl = w->island_bp.slices();
-    ip.bp_stage = sl.stage;
-    ip.bp_counts = sl.counts;
-    ip.bp_shard_cap = sl.shard_cap;
-    ip.bp_shards = sl.shards;
-    HIP_TRY(bge::launch_island_pair_keys(w->stream, w->view, ip));
-    HIP_TRY(hipMemcpyAsync(w->isl_counts_host, w->isl_counts.p, 16, hipMemcpyDeviceToHost, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
-    if (w->isl_counts_host[3] & 5u) {
+    for (;;) {
+        const uint64_t cap = w->isl_pair_cap;
+        int rc = w->island_bp.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
+        if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->island_bp.error());
+        HIP_TRY(w->isl_keys_raw.ensure(cap * 8));
+        ip.keys_raw = w->isl_keys_raw.as<uint64_t>();
+        ip.pair_cap = static_cast<uint32_t>(std::min<uint64_t>(cap, 0xffffffffu));
+        rc = w->island_bp.run(w->stream, w->view, n_slots, w->isl_identity.as<uint32_t>(), nullptr, &palette, nullptr);
+        if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->island_bp.error());
+        const bge::PairSlices sl = w->island_bp.slices();
+        ip.bp_stage = sl.stage;
+        ip.bp_counts = sl.counts;
+        ip.bp_shard_cap = sl.shard_cap;
+        ip.bp_shards = sl.shards;
+        HIP_TRY(bge::launch_island_pair_keys(w->stream, w->view, ip));
+        HIP_TRY(hipMemcpyAsync(w->isl_counts_host, w->isl_counts.p, 16, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        if (w->isl_counts_host[3] & 5u) {
+            HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
+            return fail(BGE_ERR_HIP, "internal error in the island solver of the previous sub-step (bits %#x): row pool exhausted or an obstacle record missing",
+                        w->isl_counts_host[3]);
+        }
+        if (!(w->isl_counts_host[3] & 2u) && w->isl_counts_host[0] <= ip.pair_cap) break;
         HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
-        return fail(BGE_ERR_HIP, "internal error in the island solver of the previous sub-step (bits %#x): row pool exhausted or an obstacle record missing",
-                    w->isl_counts_host[3]);
-    }
-    if (w->isl_counts_host[3] & 2u || w->isl_counts_host[0] > ip.pair_cap) {
-        HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
-        return fail(BGE_ERR_INVALID, "more overlapping body pairs than pair_capacity (%llu) holds: create the world with a larger pair_capacity",
-                    (unsigned long long)cap);
+        if (w->pair_capacity_req || cap >= (1ull << 31)) {
+            return fail(BGE_ERR_INVALID, "more overlapping body pairs than pair_capacity (%llu) holds: create the world with a larger pair_capacity",
+                        (unsigned long long)cap);
+        }
+        w->isl_pair_cap = cap * 2; // (the pair search is repeated on the same boxes: nothing else of the sub-step has run yet)
     }
     const uint32_t n_pairs = w->isl_counts_host[0];
     w->isl_last_pairs = n_pairs;

@@ -311,7 +311,9 @@ BGE_API int bge_world_download_box_contacts(bge_world* world, uint64_t first, ui
  *       (the bodies in ascending entity index, each body's plane manifold, its manifolds with Static / Kinematic boxes, its pairs
  *       with Dynamic boxes of higher index: oracle/island_ref.h states why this order and not Bullet's pool order).  One device
  *       thread solves one island; the sub-step reads two counters back (pairs, island bodies).  Capsules take no part (GJK / EPA).
- *       Works with or without the plane and the static contacts; pair_capacity (bge_world_create) bounds the overlapping pairs.
+ *       Works with or without the plane and the static contacts.  The sub-step's pair search (all bodies, Static ones too) keeps
+ *       pair_capacity pairs when bge_world_create was given one — more is BGE_ERR_INVALID, never a silent drop — and otherwise starts at
+ *       8 per entity and doubles by itself whenever a sub-step finds more.
  *       Islands live inside ONE world: a scene sharded over several worlds (bge_partition_subtrees) does not collide bodies of
  *       different shards with each other.
  *   bge_world_download_dynamic_pairs  the pair cache after the last tick in ascending (lower, higher) entity index: *total pairs;

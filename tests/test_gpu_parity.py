@@ -1506,6 +1506,13 @@ def test_more_overlapping_pairs_than_pair_capacity_is_an_error_not_a_silent_drop
         assert "pair_capacity" in str(err.value)
         w.set_dynamic_contacts(False)                                       # the world is still usable without the switch
         w.tick(dt=DT, flags=B.TICK_ALL)
+    # left to the world (no pair_capacity given) the capacity of the sub-step's pair search doubles until everything fits
+    with B.World() as w:
+        w.load(wl)
+        w.set_dynamic_contacts(True)
+        w.tick(dt=DT, flags=B.TICK_ALL)
+        hdr, _ = w.download_dynamic_pairs()
+        assert len(hdr) > 8 * n, len(hdr)
 
 
 def test_ground_plane_switched_off_then_scene_grows_then_on_again():
