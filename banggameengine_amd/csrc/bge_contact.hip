@@ -2439,17 +2439,36 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
             L.row(r, 1) = 0.0f;
             L.row(r, 2) = 0.0f;
         }
+        // (a row's constants are requested one row ahead: the load of row r + 1 is in flight while row r is resolved — what a sweep
+        //  waits for is then the LDS round trip of the bodies it shares with the row before, not a global load per row)
         for (int it = 0; it < kIterations; ++it) {
-            for (uint32_t r = 0; r < n_points; ++r) isl_resolve_split_lds(L, sb, normalRow[r], L.row(r, 1));
+            bool any = false;
+            for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
+            if (!any) break; // (no row takes the split impulse: every sweep would return at its first test)
+            IslRow cur = normalRow[0];
+            for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
+                isl_resolve_split_lds(L, sb, cur, L.row(r, 1));
+                cur = nxt;
+            }
         }
         for (int it = 0; it < kIterations; ++it) {
-            for (uint32_t r = 0; r < n_points; ++r) isl_resolve_row_lds(L, sb, normalRow[r], L.row(r, 0), normalRow[r].lower, normalRow[r].upper, false);
+            if (n_points == 0) break;
+            IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
+                isl_resolve_row_lds(L, sb, cur, L.row(r, 0), cur.lower, cur.upper, false);
+                cur = nxt;
+            }
+            cur = frictionRow[0];
+            for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = frictionRow[r + 1 < n_points ? r + 1 : r];
                 const float totalImpulse = L.row(r, 0);
                 if (totalImpulse > 0.0f) {
-                    const float friction = frictionRow[r].friction;
-                    isl_resolve_row_lds(L, sb, frictionRow[r], L.row(r, 2), -(friction * totalImpulse), friction * totalImpulse, true);
+                    const float friction = cur.friction;
+                    isl_resolve_row_lds(L, sb, cur, L.row(r, 2), -(friction * totalImpulse), friction * totalImpulse, true);
                 }
+                cur = nxt;
             }
         }
         for (uint32_t i = first; i < end; ++i) {
@@ -2463,18 +2482,42 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
             frictionRow[r].applied = L.row(r, 2);
         }
     } else {
+        // (a big island: everything in global memory; a row's constants are requested one row ahead here too, and a resolved row writes
+        //  back the one word that changed)
         for (int it = 0; it < kIterations; ++it) {
-            for (uint32_t r = 0; r < n_points; ++r) isl_resolve_split(sb, normalRow[r]);
+            bool any = false;
+            for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
+            if (!any) break;
+            IslRow cur = normalRow[0];
+            for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
+                if (cur.rhsPenetration) {
+                    isl_resolve_split(sb, cur);
+                    normalRow[r].appliedPush = cur.appliedPush;
+                }
+                cur = nxt;
+            }
         }
         for (int it = 0; it < kIterations; ++it) {
-            for (uint32_t r = 0; r < n_points; ++r) isl_resolve_row(sb, normalRow[r], false);
+            if (n_points == 0) break;
+            IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
+                isl_resolve_row(sb, cur, false);
+                normalRow[r].applied = cur.applied;
+                cur = nxt;
+            }
+            cur = frictionRow[0];
+            for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = frictionRow[r + 1 < n_points ? r + 1 : r];
                 const float totalImpulse = normalRow[r].applied;
                 if (totalImpulse > 0.0f) {
-                    frictionRow[r].lower = -(frictionRow[r].friction * totalImpulse);
-                    frictionRow[r].upper = frictionRow[r].friction * totalImpulse;
-                    isl_resolve_row(sb, frictionRow[r], true);
+                    cur.lower = -(cur.friction * totalImpulse);
+                    cur.upper = cur.friction * totalImpulse;
+                    isl_resolve_row(sb, cur, true);
+                    frictionRow[r].applied = cur.applied;
                 }
+                cur = nxt;
             }
         }
     }
