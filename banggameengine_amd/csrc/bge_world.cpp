@@ -217,13 +217,14 @@ struct bge_world {
     bool dynamic_contacts = false;
     bge::Broadphase island_bp;
     DevBuf isl_slot_words, isl_counts, isl_identity, isl_gen, isl_keys_raw, isl_keys[2], isl_man[2], isl_body_keys_raw, isl_body_slot_raw,
-        isl_body_keys, isl_body_slot, isl_solver_bodies, isl_rows, isl_sort_tmp;
+        isl_body_keys, isl_body_slot, isl_solver_bodies, isl_rows, isl_sort_tmp, isl_big_list, isl_body_words, isl_ints;
     uint32_t* isl_counts_host = nullptr; // pinned
     int isl_cur = 0;
     uint32_t isl_n_prev = 0;
     uint64_t isl_identity_n = 0;
     bool isl_gen_stale = true;
     uint32_t isl_last_pairs = 0, isl_last_bodies = 0;
+    uint32_t isl_big_points = 256; // islands with more contact points go to the workgroup solver (BGE_ISLAND_BIG_POINTS: tests force it)
     uint64_t isl_pair_cap = 0; // pair capacity of island_bp (grows by itself unless bge_world_create fixed pair_capacity)
     bool pairs_from_slab = false;          // bge_world_pairs reads the slab search (global ids) instead of the local one
     std::vector<uint32_t> global_id_host;  // per entity index; empty = identity
@@ -367,7 +368,7 @@ struct bge_world {
         slab_broadphase.release();
         island_bp.release();
         for (DevBuf* b : {&isl_slot_words, &isl_counts, &isl_identity, &isl_gen, &isl_keys_raw, &isl_keys[0], &isl_keys[1], &isl_man[0], &isl_man[1], &isl_body_keys_raw,
-                          &isl_body_slot_raw, &isl_body_keys, &isl_body_slot, &isl_solver_bodies, &isl_rows, &isl_sort_tmp})
+                          &isl_body_slot_raw, &isl_body_keys, &isl_body_slot, &isl_solver_bodies, &isl_rows, &isl_sort_tmp, &isl_big_list, &isl_body_words, &isl_ints})
             b->release();
         if (isl_counts_host) (void)hipHostFree(isl_counts_host);
         isl_counts_host = nullptr;
@@ -939,6 +940,7 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     gp.entity_of_slot = w->entity_of_slot.as<uint32_t>();
 
     HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 12, w->stream)); // (word 3, the error bits, stays: the solver's are read with the NEXT sub-step's counts)
+    HIP_TRY(hipMemsetAsync(w->isl_counts.as<uint32_t>() + 4, 0, 16, w->stream));
     if (w->static_contacts) HIP_TRY(bge::launch_obstacles(w->stream, w->view, gp));
     gp.obstacles_ready = 1u;
     HIP_TRY(bge::launch_island_begin(w->stream, w->view, gp, ip, bullet_basis));
@@ -1028,6 +1030,16 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     ip.solver_bodies = w->isl_solver_bodies.p;
     ip.rows = w->isl_rows.p;
     ip.row_cap = static_cast<uint32_t>(std::min<uint64_t>(row_cap, 0xffffffffu));
+    // islands a workgroup solves level by level (k_island_solve_big): the list of them, two words per body, four per point for the levels
+    const uint64_t int_cap = 2ull * row_cap + 8ull * n_bodies + 64;
+    HIP_TRY(w->isl_big_list.ensure(static_cast<size_t>(n_bodies) * 8));
+    HIP_TRY(w->isl_body_words.ensure(static_cast<size_t>(n_bodies) * 8));
+    HIP_TRY(w->isl_ints.ensure(static_cast<size_t>(int_cap) * 4));
+    ip.big_list = w->isl_big_list.as<uint32_t>();
+    ip.body_words = w->isl_body_words.as<uint32_t>();
+    ip.ints = w->isl_ints.as<uint32_t>();
+    ip.int_cap = static_cast<uint32_t>(std::min<uint64_t>(int_cap, 0xffffffffu));
+    ip.big_points = w->isl_big_points;
     ip.iterations = 10u;
     if (const char* e = std::getenv("BGE_ISLAND_ITERATIONS")) ip.iterations = static_cast<uint32_t>(std::strtoul(e, nullptr, 10)); // (measurements: what the set-up costs)
     HIP_TRY(bge::launch_island_solve(w->stream, w->view, gp, ip, bullet_basis));
@@ -2084,6 +2096,7 @@ try {
         HIP_TRY(hipMemsetAsync(w->bmanifold.p, 0xff, w->bmanifold.bytes, w->stream)); // every row free (bge::kBoxNone)
         w->rebuild_view();
     }
+    if (const char* e = std::getenv("BGE_ISLAND_BIG_POINTS")) w->isl_big_points = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
     w->dynamic_contacts = enabled != 0;
     w->isl_n_prev = 0; // (off and on again: the pair cache starts empty)
     w->isl_gen_stale = true;

@@ -1300,9 +1300,9 @@ def _compare_dynamic_world(w, ref, tick, dyn, plane, static):
     return st, hdr
 
 
-@pytest.mark.parametrize("basis,plane,static", [(False, True, False), (True, True, True), (False, False, True)],
-                         ids=["default-plane", "bullet_basis-plane-obstacles", "default-obstacles"])
-def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, static):
+@pytest.mark.parametrize("basis,plane,static,big", [(False, True, False, 256), (True, True, True, 256), (False, False, True, 256), (True, True, True, 16), (False, True, False, 0)],
+                         ids=["default-plane", "bullet_basis-plane-obstacles", "default-obstacles", "workgroup-solver-above-16-points", "workgroup-solver-for-all-but-the-smallest"])
+def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, static, big, monkeypatch):
     """Dynamic boxes collide with EACH OTHER (bge_world_set_dynamic_contacts; bge_contact.hip "islands" against oracle/island_ref.h and
     physics_ref.h CollideDynamicPairs / StepIsland).  Three towers of five, a loose heap of 120 boxes of mixed size, mass, friction and
     restitution raining on a 7 x 7 m patch (they pile up three deep), a far-away pair that only ever touches each other, a few
@@ -1310,6 +1310,9 @@ def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, sta
     first tower after everything fell asleep, a resting body is re-created, a tower's base is teleported away.  Every compared tick:
     the pair cache (which pairs, their points and impulses), pose, rotationEuler, quaternion, velocities, plane and obstacle
     manifolds, activation state and timers — bit for bit."""
+    # (islands of more than `big` contact points are solved by a workgroup, level by level — k_island_solve_big; the product's 256 leaves
+    #  this scene to the one-thread solvers, 16 sends the heap and the towers there, 0 everything that does not fit an LDS column)
+    monkeypatch.setenv("BGE_ISLAND_BIG_POINTS", str(big))
     rng = np.random.default_rng(99)
     n_stat = 5 if static else 0
     n_tower, n_heap, n_misc = 15, 120, 8
