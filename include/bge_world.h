@@ -310,7 +310,8 @@ BGE_API int bge_world_download_box_contacts(bge_world* world, uint64_t first, ui
  *       no gravity until the stepSimulation call ends) — and btSequentialImpulseConstraintSolver over all manifolds of an island
  *       (the bodies in ascending entity index, each body's plane manifold, its manifolds with Static / Kinematic boxes, its pairs
  *       with Dynamic boxes of higher index: oracle/island_ref.h states why this order and not Bullet's pool order).  One device
- *       thread solves one island; the sub-step reads two counters back (pairs, island bodies).  Capsules take no part (GJK / EPA).
+ *       thread solves a small island, a workgroup a big one (rows that share no body side by side, level by level: the sequence's
+ *       results exactly); the sub-step reads two counters back (pairs, island bodies).  Capsules take no part (GJK / EPA).
  *       Works with or without the plane and the static contacts.  The sub-step's pair search (all bodies, Static ones too) keeps
  *       pair_capacity pairs when bge_world_create was given one — more is BGE_ERR_INVALID, never a silent drop — and otherwise starts at
  *       8 per entity and doubles by itself whenever a sub-step finds more.
