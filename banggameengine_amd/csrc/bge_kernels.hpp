@@ -156,7 +156,7 @@ struct IslandParams {
     uint32_t* body_words;           // [n_bodies][2] per body of a big island: rows before it / the level of its last row
     uint32_t* ints;                 // [int_cap] per-row level, rows in level order, level starts (counts[6] handed out)
     uint32_t int_cap;
-    uint32_t big_points;            // islands with more contact points than this go to k_island_solve_big (256; BGE_ISLAND_BIG_POINTS for tests)
+    uint32_t big_points;            // islands with more contact points than this go to k_island_solve_big (128; BGE_ISLAND_BIG_POINTS for tests)
 };
 constexpr uint32_t kIslBodyBytes = 160, kIslRowBytes = 128;
 

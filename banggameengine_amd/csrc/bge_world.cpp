@@ -224,7 +224,7 @@ struct bge_world {
     uint64_t isl_identity_n = 0;
     bool isl_gen_stale = true;
     uint32_t isl_last_pairs = 0, isl_last_bodies = 0;
-    uint32_t isl_big_points = 256; // islands with more contact points go to the workgroup solver (BGE_ISLAND_BIG_POINTS: tests force it)
+    uint32_t isl_big_points = 128; // islands with more contact points go to the workgroup solver (BGE_ISLAND_BIG_POINTS: tests force it)
     uint64_t isl_pair_cap = 0; // pair capacity of island_bp (grows by itself unless bge_world_create fixed pair_capacity)
     bool pairs_from_slab = false;          // bge_world_pairs reads the slab search (global ids) instead of the local one
     std::vector<uint32_t> global_id_host;  // per entity index; empty = identity

@@ -37,8 +37,8 @@ _FIRST = int(os.environ.get("BGE_FUZZ_FIRST", "0"))
 def test_random_scene_and_edit_script_match_oracle_every_tick(seed, monkeypatch):
     if seed % 5 == 0:
         monkeypatch.setenv("BGE_TRIGGER_GRID_MIN", "0")    # the ghosts look their bodies up in the broadphase grid
-    # (islands of more than 256 contact points are solved by a workgroup, level by level; every other seed sends those of more than 8 there)
-    monkeypatch.setenv("BGE_ISLAND_BIG_POINTS", "8" if seed % 8 in (1, 2) else "256")
+    # (islands of more than 128 contact points are solved by a workgroup, level by level; every other seed sends those of more than 8 there)
+    monkeypatch.setenv("BGE_ISLAND_BIG_POINTS", "8" if seed % 8 in (1, 2) else "128")
     rng = np.random.default_rng(1000 + seed)
     # seeds 24..39 and 52..63: larger scenes with long parent chains (tiles that overflow into further passes), hundreds of collision
     # filter combinations (the palette's 32-class and 255-class boundaries), physics and transforms as separate calls (the

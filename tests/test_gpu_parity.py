@@ -1300,7 +1300,7 @@ def _compare_dynamic_world(w, ref, tick, dyn, plane, static):
     return st, hdr
 
 
-@pytest.mark.parametrize("basis,plane,static,big", [(False, True, False, 256), (True, True, True, 256), (False, False, True, 256), (True, True, True, 16), (False, True, False, 0)],
+@pytest.mark.parametrize("basis,plane,static,big", [(False, True, False, 128), (True, True, True, 128), (False, False, True, 128), (True, True, True, 16), (False, True, False, 0)],
                          ids=["default-plane", "bullet_basis-plane-obstacles", "default-obstacles", "workgroup-solver-above-16-points", "workgroup-solver-for-all-but-the-smallest"])
 def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, static, big, monkeypatch):
     """Dynamic boxes collide with EACH OTHER (bge_world_set_dynamic_contacts; bge_contact.hip "islands" against oracle/island_ref.h and
@@ -1310,7 +1310,7 @@ def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, sta
     first tower after everything fell asleep, a resting body is re-created, a tower's base is teleported away.  Every compared tick:
     the pair cache (which pairs, their points and impulses), pose, rotationEuler, quaternion, velocities, plane and obstacle
     manifolds, activation state and timers — bit for bit."""
-    # (islands of more than `big` contact points are solved by a workgroup, level by level — k_island_solve_big; the product's 256 leaves
+    # (islands of more than `big` contact points are solved by a workgroup, level by level — k_island_solve_big; the product's 128 leaves
     #  this scene to the one-thread solvers, 16 sends the heap and the towers there, 0 everything that does not fit an LDS column)
     monkeypatch.setenv("BGE_ISLAND_BIG_POINTS", str(big))
     rng = np.random.default_rng(99)

@@ -4,6 +4,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_islands
+rm -rf $OUT/stats
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/tools/measure_islands.py "$@" > $OUT/run.log 2> $OUT/run.err || echo "profiled run failed"
