@@ -2130,6 +2130,7 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
 //      What the iterations CHANGE — four vectors per body, three scalars per contact point — lives in a lane-private LDS column
 //      (word k of lane l at [64 k + l]: no bank conflicts); what they only read stays in the rows in global memory.
 constexpr uint32_t kIslLdsBodies = 4, kIslLdsPoints = 16, kIslLdsWords = kIslLdsBodies * 12u + kIslLdsPoints * 3u;
+constexpr uint32_t kIslMidBodies = 16; // k_island_solve<.., true>: that many bodies' delta velocities in a lane's LDS column (49 KB per workgroup)
 struct IslLocal {
     float* p;       // this lane's column
     uint32_t first; // the island's first body in the sorted list
@@ -2452,26 +2453,32 @@ __device__ void isl_finish_body(const WorldView& w, const GroundParams& g, IslBo
         w.cinfo[slot] = ci;
 }
 
-template <bool BASIS>
+// MID = false: the grid walks the sorted body list, an island's first body solves it — or hands it on: to the mid list (5 .. kIslMidBodies bodies:
+// k_island_solve<.., true>, launched next, keeps their bodies' delta velocities in LDS) or to the big list (k_island_solve_big).
+template <bool BASIS, bool MID>
 __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g, IslandParams ip)
 {
-    __shared__ float s_isl[kIslLdsWords * 64u];
-    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
-    if (first >= ip.n_bodies) return;
-    const uint32_t root = static_cast<uint32_t>(ip.body_keys[first] >> 32);
-    if (first > 0 && static_cast<uint32_t>(ip.body_keys[first - 1] >> 32) == root) return; // not the island's first body
-    if (!ip.active[root]) return; // "all sleeping": k_tick turns its WANTS_DEACTIVATION bodies to ISLAND_SLEEPING, the others sleep already
-    uint32_t end = first + 1;
-    while (end < ip.n_bodies && static_cast<uint32_t>(ip.body_keys[end] >> 32) == root) ++end;
-    // an island that does not fit one thread's LDS column goes to k_island_solve_big (a workgroup to each)
-    auto hand_over = [&]() {
-        const uint32_t at = atomicAdd(&ip.counts[4], 1u);
-        ip.big_list[2u * at] = first;
-        ip.big_list[2u * at + 1u] = end;
-    };
-    if (end - first > ip.big_points && end - first > kIslLdsBodies) { // (that many bodies: not worth counting)
-        hand_over();
-        return;
+    __shared__ float s_isl[(MID ? kIslMidBodies * 12u : kIslLdsWords) * 64u];
+    uint32_t first, end;
+    if (MID) {
+        const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= ip.counts[7]) return;
+        first = ip.mid_list[2u * t];
+        end = ip.mid_list[2u * t + 1u];
+    } else {
+        first = blockIdx.x * blockDim.x + threadIdx.x;
+        if (first >= ip.n_bodies) return;
+        const uint32_t root = static_cast<uint32_t>(ip.body_keys[first] >> 32);
+        if (first > 0 && static_cast<uint32_t>(ip.body_keys[first - 1] >> 32) == root) return; // not the island's first body
+        if (!ip.active[root]) return; // "all sleeping": k_tick turns its WANTS_DEACTIVATION bodies to ISLAND_SLEEPING, the others sleep already
+        end = first + 1;
+        while (end < ip.n_bodies && static_cast<uint32_t>(ip.body_keys[end] >> 32) == root) ++end;
+        if (end - first > ip.big_points && end - first > kIslLdsBodies) { // (that many bodies: not worth counting)
+            const uint32_t at = atomicAdd(&ip.counts[4], 1u);
+            ip.big_list[2u * at] = first;
+            ip.big_list[2u * at + 1u] = end;
+            return;
+        }
     }
     IslBody* sb = static_cast<IslBody*>(ip.solver_bodies);
     const int kIterations = static_cast<int>(ip.iterations);
@@ -2481,9 +2488,20 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     for (uint32_t i = first; i < end; ++i) n_points += isl_prepare_body<BASIS>(w, g, ip, sb, i);
     // the pairs owned by the island's bodies (keys ascend with the owner's entity, so they are one run per body)
     for (uint32_t i = first; i < end; ++i) n_points += isl_pair_points(ip, ip.body_slot[i]);
-    if (n_points > ip.big_points && n_points > kIslLdsPoints) {
-        hand_over(); // (its bodies are prepared again there: the same values)
-        return;
+    const bool small = end - first <= kIslLdsBodies && n_points <= kIslLdsPoints;
+    if (!MID && !small) { // (whoever takes it prepares its bodies again: the same values)
+        if (n_points > ip.big_points) {
+            const uint32_t at = atomicAdd(&ip.counts[4], 1u);
+            ip.big_list[2u * at] = first;
+            ip.big_list[2u * at + 1u] = end;
+            return;
+        }
+        if (end - first <= kIslMidBodies) {
+            const uint32_t at = atomicAdd(&ip.counts[7], 1u);
+            ip.mid_list[2u * at] = first;
+            ip.mid_list[2u * at + 1u] = end;
+            return;
+        }
     }
     IslRow* rows_base = nullptr;
     if (n_points) {
@@ -2501,7 +2519,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     uint32_t j = 0;
     for (uint32_t i = first; i < end; ++i) j = isl_build_body_rows<true>(w, g, ip, sb, i, invTimeStep, normalRow, frictionRow, j);
     // ---- solveGroupCacheFriendlySplitImpulseIterations, solveGroupCacheFriendlyIterations
-    if (end - first <= kIslLdsBodies && n_points <= kIslLdsPoints) {
+    if (!MID && small) {
         const IslLocal L{s_isl + (threadIdx.x & 63u), first};
         for (uint32_t i = first; i < end; ++i) {
             L.set(i, 0, sb[i].dLin); // (the warm start)
@@ -2556,9 +2574,60 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
             normalRow[r].applied = L.row(r, 0);
             frictionRow[r].applied = L.row(r, 2);
         }
-        } else {
-        // (a medium island — up to IslandParams::big_points contact points —: everything in global memory, still one thread; a row's constants are requested one row ahead here too, and a resolved row writes
-        //  back the one word that changed)
+    } else if (MID) {
+        // (5 .. kIslMidBodies bodies, up to IslandParams::big_points contact points — a tower, a small pile: the bodies' delta velocities
+        //  in LDS, a row's own scalars in the row; rows one ahead, a resolved row writes back the one word that changed)
+        const IslLocal L{s_isl + (threadIdx.x & 63u), first};
+        for (uint32_t i = first; i < end; ++i) {
+            L.set(i, 0, sb[i].dLin);
+            L.set(i, 1, sb[i].dAng);
+            L.set(i, 2, F3{0.0f, 0.0f, 0.0f});
+            L.set(i, 3, F3{0.0f, 0.0f, 0.0f});
+        }
+        for (int it = 0; it < kIterations; ++it) {
+            bool any = false;
+            for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
+            if (!any) break;
+            IslRow cur = normalRow[0];
+            for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
+                if (cur.rhsPenetration) {
+                    isl_resolve_split_lds(L, sb, cur, cur.appliedPush);
+                    normalRow[r].appliedPush = cur.appliedPush;
+                }
+                cur = nxt;
+            }
+        }
+        for (int it = 0; it < kIterations; ++it) {
+            if (n_points == 0) break;
+            IslRow cur = normalRow[0];
+            for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
+                isl_resolve_row_lds(L, sb, cur, cur.applied, cur.lower, cur.upper, false);
+                normalRow[r].applied = cur.applied;
+                cur = nxt;
+            }
+            cur = frictionRow[0];
+            for (uint32_t r = 0; r < n_points; ++r) {
+                const IslRow nxt = frictionRow[r + 1 < n_points ? r + 1 : r];
+                const float totalImpulse = normalRow[r].applied;
+                if (totalImpulse > 0.0f) {
+                    const float friction = cur.friction;
+                    isl_resolve_row_lds(L, sb, cur, cur.applied, -(friction * totalImpulse), friction * totalImpulse, true);
+                    frictionRow[r].applied = cur.applied;
+                }
+                cur = nxt;
+            }
+        }
+        for (uint32_t i = first; i < end; ++i) {
+            sb[i].dLin = L.get(i, 0);
+            sb[i].dAng = L.get(i, 1);
+            sb[i].push = L.get(i, 2);
+            sb[i].turn = L.get(i, 3);
+        }
+    } else {
+        // (more than kIslMidBodies bodies on at most IslandParams::big_points contact points — rare —: everything in global memory, still
+        //  one thread; rows one ahead, a resolved row writes back the one word that changed)
         for (int it = 0; it < kIterations; ++it) {
             bool any = false;
             for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
@@ -2865,13 +2934,16 @@ hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const Gro
     if (ip.n_bodies == 0) return hipSuccess;
     hipLaunchKernelGGL(k_island_flags, dim3((ip.n_bodies + 255u) / 256u), dim3(256), 0, stream, w, ip);
     const dim3 grid((ip.n_bodies + 63u) / 64u), block(64);
+    const dim3 mid_grid((ip.n_bodies / (kIslLdsBodies + 1u) + 64u) / 64u); // (an island on the mid list has more than kIslLdsBodies bodies)
     if (bullet_basis) {
         hipLaunchKernelGGL(k_island_own<true>, grid, block, 0, stream, w, g, ip);
-        hipLaunchKernelGGL(k_island_solve<true>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL((k_island_solve<true, false>), grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL((k_island_solve<true, true>), mid_grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL(k_island_solve_big<true>, dim3(512), dim3(256), 0, stream, w, g, ip);
     } else {
         hipLaunchKernelGGL(k_island_own<false>, grid, block, 0, stream, w, g, ip);
-        hipLaunchKernelGGL(k_island_solve<false>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL((k_island_solve<false, false>), grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL((k_island_solve<false, true>), mid_grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL(k_island_solve_big<false>, dim3(512), dim3(256), 0, stream, w, g, ip);
     }
     return hipGetLastError();

@@ -124,7 +124,7 @@ struct IslandParams {
     const uint32_t* slot_of_entity;
     const uint32_t* gen_of_entity;  // how often the entity's body was (re)created
     uint32_t* counts;               // [0] pairs of Dynamic boxes found, [1] bodies in islands, [2] rows handed out, [3] error bits,
-                                    // [4] big islands listed, [5] their ticket, [6] ints handed out
+                                    // [4] big islands listed, [5] their ticket, [6] ints handed out, [7] mid islands listed
     // pairs: key = lower entity << 32 | higher entity
     const uint2* bp_stage;          // the broadphase's pair list (slot, slot) in its shard slices (Broadphase::slices)
     const unsigned long long* bp_counts;
@@ -153,6 +153,7 @@ struct IslandParams {
     uint32_t iterations;            // 10 (btContactSolverInfo::m_numIterations); BGE_ISLAND_ITERATIONS overrides it for MEASUREMENTS only
     // islands too big for one thread's LDS column: k_island_solve lists them, k_island_solve_big takes a workgroup to each
     uint32_t* big_list;             // [n_bodies][2] first body, end (counts[4] of them; counts[5] is the workgroups' ticket)
+    uint32_t* mid_list;             // [n_bodies][2] likewise, islands of 5 .. 16 bodies (counts[7] of them): k_island_solve<.., true>
     uint32_t* body_words;           // [n_bodies][2] per body of a big island: rows before it / the level of its last row
     uint32_t* ints;                 // [int_cap] per-row level, rows in level order, level starts (counts[6] handed out)
     uint32_t int_cap;
