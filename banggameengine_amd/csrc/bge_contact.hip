@@ -16,6 +16,9 @@
 // which order — is oracle/contact_ref.h's (that header states what is pinned by the reference's exe and what is not);
 // tests/test_gpu_parity.py compares every body bit for bit.  Heavy per-thread state (four contact rows and four friction
 // rows) makes this a register-hungry kernel; it touches only bodies at the ground, so it is sized for correctness first.
+// Further down: Dynamic boxes on the Static / Kinematic box colliders of the scene (k_obstacles, k_contact_boxes: one island per body, the
+// rows in scratch memory) and Dynamic boxes against EACH OTHER ("islands": the pair cache with a manifold per pair, union-find over the
+// pairs, a solver thread — or, for a big island, a workgroup walking Bullet's row order level by level — per island).
 #include <hip/hip_runtime.h>
 
 #include <hipcub/hipcub.hpp>
@@ -1644,7 +1647,8 @@ __global__ void __launch_bounds__(64) k_contact_boxes(WorldView w, GroundParams 
 //   k_island_union / k_island_members   union-find over the pairs (findUnions unites every pair of the cache); the bodies that are
 //                       in a pair, keyed root slot << 32 | entity, and whether their island holds an ACTIVE_TAG body   (sorted by hipcub)
 //   k_island_flags      bodies of islands that stay awake get kCiIsland; k_island_own collides their own pairs (plane, obstacles)
-//   k_island_solve      one thread per island: solver bodies and rows in global memory, Bullet's iteration order
+//   k_island_solve      one thread per island (iteration state in LDS where it fits; islands of 5 .. 16 bodies in a second launch);
+//   k_island_solve_big  a workgroup per island of more than IslandParams::big_points contact points, Bullet's row order kept by levels
 // then k_ground_select / k_ground / k_contact_boxes for the one-body islands and k_tick for everybody, as always.
 struct IslBody {
     F3 dLin, dAng, push, turn, linVel, angVel, extForce, extTorque;

@@ -5,7 +5,7 @@
             the tick (with the switch off for comparison)
   stacks    n / 2 two-box stacks resting on the plane: n / 2 pairs, n / 2 islands of two
   towers    n / 10 towers of ten: 0.9 n pairs, islands of ten
-  heap      ONE pile of h boxes dropped into a pit: a single island that one thread solves — the path's known limit
+  heap      ONE pile of h boxes dropped into a pit: a single island — the workgroup solver that keeps Bullet's row order level by level
 
 Run on the GPU box:  python tools/measure_islands.py [n] [h]   (defaults 200000, 2000)
 """
