@@ -215,6 +215,7 @@ struct bge_world {
     // Dynamic boxes against each other (bge_contact.hip "islands"): a broadphase of its own over the sub-step's fed AABBs (the tick's
     // pair list and the trigger query keep theirs), the sorted pair cache with its manifolds in two generations, per-slot scratch
     bool dynamic_contacts = false;
+    bool static_contacts_ever = false; // bge_world_set_static_contacts(1) was called: bodies may hold manifolds with obstacles
     bge::Broadphase island_bp;
     DevBuf isl_slot_words, isl_counts, isl_identity, isl_gen, isl_keys_raw, isl_keys[2], isl_man[2], isl_body_keys_raw, isl_body_slot_raw,
         isl_body_keys, isl_body_slot, isl_solver_bodies, isl_rows, isl_sort_tmp, isl_big_list, isl_body_words, isl_ints;
@@ -1023,8 +1024,9 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     ip.body_keys = w->isl_body_keys.as<uint64_t>();
     ip.body_slot = w->isl_body_slot.as<uint32_t>();
     ip.n_bodies = n_bodies;
-    // every point the manifolds can hold: 4 on the plane + 4 x 4 on obstacles per body, 4 per pair; two rows a point
-    const uint64_t row_cap = 2ull * (20ull * n_bodies + 4ull * n_pairs);
+    // every point the manifolds can hold: 4 on the plane + 4 x 4 on obstacles per body (where those are on), 4 per pair; two rows a point
+    const uint64_t own_points = (w->ground_plane ? 4ull : 0ull) + (w->static_contacts_ever ? 4ull * bge::kBoxManifolds : 0ull); // (rows of obstacle manifolds outlive the switch)
+    const uint64_t row_cap = 2ull * (own_points * n_bodies + 4ull * n_pairs) + 2;
     HIP_TRY(w->isl_solver_bodies.ensure(static_cast<size_t>(n_bodies) * bge::kIslBodyBytes));
     HIP_TRY(w->isl_rows.ensure(static_cast<size_t>(row_cap) * bge::kIslRowBytes));
     ip.solver_bodies = w->isl_solver_bodies.p;
@@ -2078,6 +2080,7 @@ try {
         w->rebuild_view();
     }
     w->static_contacts = on;
+    w->static_contacts_ever = w->static_contacts_ever || on;
     w->obstacles_stale = true;
     w->drop_graph();
     return BGE_OK;
