@@ -1760,10 +1760,20 @@ __global__ void __launch_bounds__(256) k_island_pair_keys(WorldView w, IslandPar
     const uint32_t n = static_cast<uint32_t>(found < ip.bp_shard_cap ? found : ip.bp_shard_cap);
     const uint2* slice = ip.bp_stage + static_cast<uint64_t>(shard) * ip.bp_shard_cap;
     for (uint32_t i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
-        const uint2 pr = slice[i];
+        uint2 pr = slice[i];
+        uint32_t ea, eb;
+        if (ip.bp_ids_are_entities) {
+            ea = pr.x;
+            eb = pr.y;
+            pr.x = ip.slot_of_entity[ea];
+            pr.y = ip.slot_of_entity[eb];
+        }
         if (pr.x >= ip.n_slots || pr.y >= ip.n_slots) continue;
         if (!isl_dynamic_box(w, pr.x) || !isl_dynamic_box(w, pr.y)) continue;
-        const uint32_t ea = ip.entity_of_slot[pr.x], eb = ip.entity_of_slot[pr.y];
+        if (!ip.bp_ids_are_entities) {
+            ea = ip.entity_of_slot[pr.x];
+            eb = ip.entity_of_slot[pr.y];
+        }
         const uint64_t key = ea < eb ? (static_cast<uint64_t>(ea) << 32) | eb : (static_cast<uint64_t>(eb) << 32) | ea;
         const uint32_t at = atomicAdd(&ip.counts[0], 1u);
         if (at < ip.pair_cap) ip.keys_raw[at] = key;

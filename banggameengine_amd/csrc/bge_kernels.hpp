@@ -130,6 +130,7 @@ struct IslandParams {
     const unsigned long long* bp_counts;
     uint64_t bp_shard_cap;
     uint32_t bp_shards;
+    uint32_t bp_ids_are_entities;   // the list holds entity indices (the tick's own broadphase instance, shared) instead of slots
     uint64_t* keys_raw;             // [pair_cap] unsorted
     const uint64_t* keys;           // [n_pairs] ascending
     uint32_t pair_cap, n_pairs;

@@ -226,6 +226,7 @@ struct bge_world {
     bool isl_gen_stale = true;
     uint32_t isl_last_pairs = 0, isl_last_bodies = 0;
     uint32_t isl_big_points = 128; // islands with more contact points go to the workgroup solver (BGE_ISLAND_BIG_POINTS: tests force it)
+    bool bp_shared = false; // this sub-step's island phases ran `broadphase` on the boxes the tick would run it on: the tick skips its run
     uint64_t isl_pair_cap = 0; // pair capacity of island_bp (grows by itself unless bge_world_create fixed pair_capacity)
     bool pairs_from_slab = false;          // bge_world_pairs reads the slab search (global ids) instead of the local one
     std::vector<uint32_t> global_id_host;  // per entity index; empty = identity
@@ -893,7 +894,7 @@ int filter_palette_of(bge_world* w, bge::FilterPalette* out)
 // One sub-step's collision detection and constraint solving for the Dynamic boxes that touch each other (bge_contact.hip "islands";
 // oracle/physics_ref.h CollideDynamicPairs / StepIsland).  Runs before k_ground_select; two small read-backs (pairs, island bodies)
 // size the sorts between its phases.
-int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool bullet_basis, bool later_sub_step)
+int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool bullet_basis, bool later_sub_step, bool tick_wants_pairs)
 {
     const uint64_t n_entities = std::max<uint64_t>(w->flat.n_entities, 1);
     HIP_TRY(w->isl_slot_words.ensure(std::max<uint64_t>(n_slots, 1) * 16));
@@ -948,16 +949,23 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     gp.repose = 0u; // (done: k_ground_select must not derive the quaternions a second time from the angles k_island_begin wrote)
     bge::FilterPalette palette{};
     if (int prc = filter_palette_of(w, &palette)) return prc;
+    // The tick's own broadphase (BGE_TICK_BROADPHASE: pairs for the caller, the trigger query) sees exactly these boxes after k_tick — the
+    // fed AABBs of the sub-step's start — so when it is asked for, it runs HERE, once, and the tick skips its run (bp_shared).  Its
+    // capacity is the world's; should it drop pairs, the island path repeats the search with its own instance, which grows.
+    bool shared = tick_wants_pairs;
+    w->bp_shared = false;
     for (;;) {
-        const uint64_t cap = w->isl_pair_cap;
-        int rc = w->island_bp.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
-        if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->island_bp.error());
+        bge::Broadphase& bp = shared ? w->broadphase : w->island_bp;
+        const uint64_t cap = shared ? (w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * w->flat.n_entities, 4096)) : w->isl_pair_cap;
+        int rc = bp.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
+        if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", bp.error());
         HIP_TRY(w->isl_keys_raw.ensure(cap * 8));
         ip.keys_raw = w->isl_keys_raw.as<uint64_t>();
         ip.pair_cap = static_cast<uint32_t>(std::min<uint64_t>(cap, 0xffffffffu));
-        rc = w->island_bp.run(w->stream, w->view, n_slots, w->isl_identity.as<uint32_t>(), nullptr, &palette, nullptr);
-        if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->island_bp.error());
-        const bge::PairSlices sl = w->island_bp.slices();
+        ip.bp_ids_are_entities = shared ? 1u : 0u;
+        rc = bp.run(w->stream, w->view, n_slots, shared ? w->entity_of_slot.as<uint32_t>() : w->isl_identity.as<uint32_t>(), nullptr, &palette, nullptr);
+        if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", bp.error());
+        const bge::PairSlices sl = bp.slices();
         ip.bp_stage = sl.stage;
         ip.bp_counts = sl.counts;
         ip.bp_shard_cap = sl.shard_cap;
@@ -970,8 +978,15 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
             return fail(BGE_ERR_HIP, "internal error in the island solver of the previous sub-step (bits %#x): row pool exhausted or an obstacle record missing",
                         w->isl_counts_host[3]);
         }
-        if (!(w->isl_counts_host[3] & 2u) && w->isl_counts_host[0] <= ip.pair_cap) break;
+        if (!(w->isl_counts_host[3] & 2u) && w->isl_counts_host[0] <= ip.pair_cap) {
+            w->bp_shared = shared;
+            break;
+        }
         HIP_TRY(hipMemsetAsync(w->isl_counts.p, 0, 64, w->stream));
+        if (shared) { // (the tick's run will report what the world's capacity does to ITS pair list; the islands need every pair)
+            shared = false;
+            continue;
+        }
         if (w->pair_capacity_req || cap >= (1ull << 31)) {
             return fail(BGE_ERR_INVALID, "more overlapping body pairs than pair_capacity (%llu) holds: create the world with a larger pair_capacity",
                         (unsigned long long)cap);
@@ -1847,7 +1862,7 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
                 gp.box_count = w->box_count.as<uint32_t>();
             }
             if (w->dynamic_contacts) {
-                if (int rc = island_substep(w, gp, n_slots, (flags & BGE_TICK_BULLET_BASIS) != 0, sub.no_repose != 0)) return rc;
+                if (int rc = island_substep(w, gp, n_slots, (flags & BGE_TICK_BULLET_BASIS) != 0, sub.no_repose != 0, (flags & BGE_TICK_BROADPHASE) != 0)) return rc;
             }
             HIP_TRY(bge::launch_ground(w->stream, w->view, gp, (flags & BGE_TICK_BULLET_BASIS) != 0));
             p.no_repose = 1u;
@@ -1889,7 +1904,8 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
         if (flags & BGE_TICK_BROADPHASE) {
             // buffers are sized on first use: a world that never asks for pairs does not pay for them
             const uint64_t cap = w->pair_capacity_req ? w->pair_capacity_req : std::max<uint64_t>(8 * w->flat.n_entities, 4096);
-            int rc = w->broadphase.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
+            int rc = BGE_OK;
+            if (!(w->dynamic_contacts && w->bp_shared)) rc = w->broadphase.configure(std::max<uint64_t>(w->flat.n_slots, bge::kTile), cap);
             if (rc != BGE_OK) return fail(rc, "broadphase allocation failed: %s", w->broadphase.error());
             if (w->filter_table_stale && !w->filter_overflow) {
                 std::vector<uint32_t> tab(256 * 4, 0u);
@@ -1905,9 +1921,12 @@ int tick_impl(bge_world* w, uint32_t ticks, float dt, const float gravity[3], ui
             const bge::FilterPalette palette{w->filter_overflow ? nullptr : w->filter_class.as<uint32_t>(),
                                              w->filter_overflow ? nullptr : w->filter_table.as<uint4>(),
                                              static_cast<uint32_t>(w->filter_palette.size())};
-            rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
-                                   w->entity_of_slot.as<uint32_t>(), nullptr, &palette, w->bp_partials.as<float4>());
-            if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
+            if (!(w->dynamic_contacts && w->bp_shared)) { // (else: island_substep ran it on these very boxes)
+                rc = w->broadphase.run(w->stream, w->view, static_cast<uint64_t>(w->flat.n_tiles_ticked) * bge::kTile,
+                                       w->entity_of_slot.as<uint32_t>(), nullptr, &palette, w->bp_partials.as<float4>());
+                if (rc != BGE_OK) return fail(rc, "broadphase failed: %s", w->broadphase.error());
+            }
+            w->bp_shared = false;
             w->pairs_from_slab = false;
             if (with_triggers) {
                 // counters: [0] overlaps found, [1] ghosts left to the all-bodies pass, [2] ghosts walked through the grid
