@@ -2830,38 +2830,68 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         __syncthreads();
         for (uint32_t r = tid; r < P; r += 256u) order[atomicAdd(&cursor[level[r]], 1u)] = r;
         __syncthreads();
+        // One sweep over the rows of `arr` in level order: fn(row copy, row number) for every row, a barrier after every level.  A thread's
+        // first row of the NEXT level is requested before this level's barrier (the row's constants never change, and what does change in
+        // it — its applied impulse — is only ever written by this same thread, which has the same place in every sweep): after the barrier a
+        // row waits for its bodies only.
+        auto sweep = [&](IslRow* arr, auto&& fn) {
+            uint32_t kn = start[1] + tid, rn = 0;
+            bool hv = kn < start[2];
+            IslRow nx{};
+            if (hv) {
+                rn = order[kn];
+                nx = arr[rn];
+            }
+            for (uint32_t l = 1; l <= depth; ++l) {
+                IslRow cur = nx;
+                const uint32_t r = rn;
+                const bool have = hv;
+                hv = false;
+                if (l < depth) {
+                    kn = start[l + 1u] + tid;
+                    hv = kn < start[l + 2u];
+                    if (hv) {
+                        rn = order[kn];
+                        nx = arr[rn];
+                    }
+                }
+                if (have) fn(cur, r);
+                for (uint32_t k = start[l] + tid + 256u; k < start[l + 1u]; k += 256u) {
+                    const uint32_t r2 = order[k];
+                    IslRow c2 = arr[r2];
+                    fn(c2, r2);
+                }
+                __syncthreads();
+            }
+        };
         // the warm start, in the rows' order
-        for (uint32_t l = 1; l <= depth; ++l) {
-            for (uint32_t k = start[l] + tid; k < start[l + 1u]; k += 256u) isl_warm_start(sb, normalRow[order[k]]);
-            __syncthreads();
-        }
+        sweep(normalRow, [&](IslRow& c, uint32_t) { isl_warm_start(sb, c); });
         // solveGroupCacheFriendlySplitImpulseIterations
         if (s_any) {
             for (int it = 0; it < kIterations; ++it) {
-                for (uint32_t l = 1; l <= depth; ++l) {
-                    for (uint32_t k = start[l] + tid; k < start[l + 1u]; k += 256u) isl_resolve_split(sb, normalRow[order[k]]);
-                    __syncthreads();
-                }
+                sweep(normalRow, [&](IslRow& c, uint32_t r) {
+                    if (c.rhsPenetration) {
+                        isl_resolve_split(sb, c);
+                        normalRow[r].appliedPush = c.appliedPush;
+                    }
+                });
             }
         }
         // solveGroupCacheFriendlyIterations: all contact rows, then all friction rows
         for (int it = 0; it < kIterations; ++it) {
-            for (uint32_t l = 1; l <= depth; ++l) {
-                for (uint32_t k = start[l] + tid; k < start[l + 1u]; k += 256u) isl_resolve_row(sb, normalRow[order[k]], false);
-                __syncthreads();
-            }
-            for (uint32_t l = 1; l <= depth; ++l) {
-                for (uint32_t k = start[l] + tid; k < start[l + 1u]; k += 256u) {
-                    const uint32_t r = order[k];
-                    const float totalImpulse = normalRow[r].applied;
-                    if (totalImpulse > 0.0f) {
-                        frictionRow[r].lower = -(frictionRow[r].friction * totalImpulse);
-                        frictionRow[r].upper = frictionRow[r].friction * totalImpulse;
-                        isl_resolve_row(sb, frictionRow[r], true);
-                    }
+            sweep(normalRow, [&](IslRow& c, uint32_t r) {
+                isl_resolve_row(sb, c, false);
+                normalRow[r].applied = c.applied;
+            });
+            sweep(frictionRow, [&](IslRow& c, uint32_t r) {
+                const float totalImpulse = normalRow[r].applied;
+                if (totalImpulse > 0.0f) {
+                    c.lower = -(c.friction * totalImpulse);
+                    c.upper = c.friction * totalImpulse;
+                    isl_resolve_row(sb, c, true);
+                    frictionRow[r].applied = c.applied;
                 }
-                __syncthreads();
-            }
+            });
         }
         // solveGroupCacheFriendlyFinish
         for (uint32_t r = tid; r < P; r += 256u) {
