@@ -2145,27 +2145,30 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
 //      (word k of lane l at [64 k + l]: no bank conflicts); what they only read stays in the rows in global memory.
 constexpr uint32_t kIslLdsBodies = 4, kIslLdsPoints = 16, kIslLdsWords = kIslLdsBodies * 12u + kIslLdsPoints * 3u;
 constexpr uint32_t kIslMidBodies = 16; // k_island_solve<.., true>: that many bodies' delta velocities in a lane's LDS column (49 KB per workgroup)
-struct IslLocal {
-    float* p;       // this lane's column
+template <uint32_t STRIDE>
+struct IslLocalT {
+    float* p;       // this lane's column (STRIDE 64), or the workgroup's block (STRIDE 1: k_island_solve_big)
     uint32_t first; // the island's first body in the sorted list
     __device__ __forceinline__ F3 get(uint32_t body, uint32_t field) const
     {
-        const float* q = p + ((body - first) * 12u + field * 3u) * 64u;
-        return F3{q[0], q[64], q[128]};
+        const float* q = p + ((body - first) * 12u + field * 3u) * STRIDE;
+        return F3{q[0], q[STRIDE], q[2u * STRIDE]};
     }
     __device__ __forceinline__ void set(uint32_t body, uint32_t field, const F3& v) const
     {
-        float* q = p + ((body - first) * 12u + field * 3u) * 64u;
+        float* q = p + ((body - first) * 12u + field * 3u) * STRIDE;
         q[0] = v.x;
-        q[64] = v.y;
-        q[128] = v.z;
+        q[STRIDE] = v.y;
+        q[2u * STRIDE] = v.z;
     }
     // k: 0 the contact row's applied impulse, 1 its applied push impulse, 2 the friction row's applied impulse
-    __device__ __forceinline__ float& row(uint32_t r, uint32_t k) const { return p[(kIslLdsBodies * 12u + r * 3u + k) * 64u]; }
+    __device__ __forceinline__ float& row(uint32_t r, uint32_t k) const { return p[(kIslLdsBodies * 12u + r * 3u + k) * STRIDE]; }
 };
+using IslLocal = IslLocalT<64u>;
 
 // isl_resolve_row on that state (fields 0 dLin, 1 dAng)
-__device__ __forceinline__ void isl_resolve_row_lds(const IslLocal& L, const IslBody* sb, const IslRow& c, float& applied, float lower, float upper, bool withUpperLimit)
+template <class Local>
+__device__ __forceinline__ void isl_resolve_row_lds(const Local& L, const IslBody* sb, const IslRow& c, float& applied, float lower, float upper, bool withUpperLimit)
 {
     const bool two = c.b != kNone;
     const float invMassA = sb[c.a].invMass;
@@ -2207,7 +2210,8 @@ __device__ __forceinline__ void isl_resolve_row_lds(const IslLocal& L, const Isl
 }
 
 // isl_resolve_split on that state (fields 2 push, 3 turn)
-__device__ __forceinline__ void isl_resolve_split_lds(const IslLocal& L, const IslBody* sb, const IslRow& c, float& appliedPush)
+template <class Local>
+__device__ __forceinline__ void isl_resolve_split_lds(const Local& L, const IslBody* sb, const IslRow& c, float& appliedPush)
 {
     if (!c.rhsPenetration) return;
     const bool two = c.b != kNone;
@@ -2703,6 +2707,22 @@ __device__ __forceinline__ void isl_warm_start(IslBody* sb, const IslRow& c)
     }
 }
 
+template <class Local>
+__device__ __forceinline__ void isl_warm_start_lds(const Local& L, const IslBody* sb, const IslRow& c)
+{
+    const float invMassA = sb[c.a].invMass;
+    const F3 n = c.normal;
+    const F3 lin = F3{c.normal.x * invMassA, c.normal.y * invMassA, c.normal.z * invMassA};
+    L.set(c.a, 0, add3(L.get(c.a, 0), scale3(lin, c.applied)));
+    L.set(c.a, 1, add3(L.get(c.a, 1), scale3(c.angularComp, c.applied * 1.0f)));
+    if (c.b != kNone) {
+        const float invMassB = sb[c.b].invMass;
+        const F3 linB = F3{invMassB * n.x, invMassB * n.y, invMassB * n.z};
+        L.set(c.b, 0, sub3(L.get(c.b, 0), scale3(linB, c.applied)));
+        L.set(c.b, 1, add3(L.get(c.b, 1), scale3(c.angularCompB, c.applied * 1.0f)));
+    }
+}
+
 // Exclusive scan of a[0 .. n) in place by the workgroup (256 threads, contiguous chunks); returns the total.  Ends with a barrier.
 __device__ uint32_t isl_wg_scan(uint32_t* a, uint32_t n, uint32_t stride, uint32_t* s_part, uint32_t* s_total)
 {
@@ -2739,12 +2759,16 @@ __device__ uint32_t isl_wg_scan(uint32_t* a, uint32_t n, uint32_t stride, uint32
 //      between them and the rows of a level side by side: the same operations on the same operands as the one-thread walk, bit for bit.
 //      (A heap of 2,000 boxes: ~1,300 rows in ~30 levels.)  Bodies, rows and the level lists live in global memory; workgroups take
 //      islands off the list k_island_solve left (ticket).
-constexpr uint32_t kIslBigLastLds = 8192;
+constexpr uint32_t kIslBigLdsBytes = 144u * 1024u, kIslBigLastLds = kIslBigLdsBytes / 4u, kIslBigLdsBodies = kIslBigLdsBytes / 48u;
 template <bool BASIS>
 __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundParams g, IslandParams ip)
 {
     __shared__ uint32_t s_part[256];
-    __shared__ uint32_t s_last[kIslBigLastLds];
+    // kIslBigLdsBytes of LDS, twice: while the levels are computed it holds the level of every body's last row, during the sweeps the
+    // bodies' delta velocities (dLin, dAng, push, turn: 48 bytes a body) — after a level's barrier a row then waits for an LDS round trip,
+    // not for the stores of the level before to reach L2 and come back
+    extern __shared__ float s_dyn[];
+    uint32_t* s_last = reinterpret_cast<uint32_t*>(s_dyn);
     __shared__ uint32_t s_ticket, s_total, s_depth, s_rows_at, s_ints_at, s_fail, s_any;
     IslBody* sb = static_cast<IslBody*>(ip.solver_bodies);
     const uint32_t tid = threadIdx.x;
@@ -2788,38 +2812,74 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         for (uint32_t i = first + tid; i < end; i += 256u) {
             isl_build_body_rows<false>(w, g, ip, sb, i, invTimeStep, normalRow, frictionRow, ip.body_words[2u * i]);
         }
+        // the levels: one walk over the rows in their order (integers only).  Where it fits, the walk runs out of LDS: the two body
+        // numbers of every row are fetched by all threads first (a walk that waits for a global load per row took 2 of this kernel's
+        // 2.9 ms on a 2,000-box heap)
+        const bool walk_in_lds = 12ull * P + 4ull * nb <= kIslBigLdsBytes;
         const bool last_in_lds = nb <= kIslBigLastLds;
+        uint32_t* l_ab = s_last + nb;          // [P][2] (walk_in_lds)
+        uint32_t* l_level = l_ab + 2ull * P;   // [P]
+        if (tid == 0) s_any = 0u;
         for (uint32_t k = tid; k < nb; k += 256u) {
             if (last_in_lds) s_last[k] = 0u;
             else ip.body_words[2u * (first + k) + 1u] = 0u;
         }
         __syncthreads();
-        // the levels: one walk over the rows in their order (integers only)
-        if (tid == 0) {
-            uint32_t depth = 0, any = 0;
-            for (uint32_t r = 0; r < P; ++r) {
-                const uint32_t a = normalRow[r].a - first, b = normalRow[r].b;
-                uint32_t l = last_in_lds ? s_last[a] : ip.body_words[2u * (first + a) + 1u];
-                if (b != kNone) {
-                    const uint32_t lb = last_in_lds ? s_last[b - first] : ip.body_words[2u * b + 1u];
-                    l = lb > l ? lb : l;
-                }
-                l += 1u;
-                if (last_in_lds) {
-                    s_last[a] = l;
-                    if (b != kNone) s_last[b - first] = l;
-                } else {
-                    ip.body_words[2u * (first + a) + 1u] = l;
-                    if (b != kNone) ip.body_words[2u * b + 1u] = l;
-                }
-                level[r] = l;
-                depth = l > depth ? l : depth;
+        {
+            uint32_t any = 0u;
+            for (uint32_t r = tid; r < P; r += 256u) {
                 any |= normalRow[r].rhsPenetration != 0.0f ? 1u : 0u;
+                if (walk_in_lds) {
+                    const uint32_t b = normalRow[r].b;
+                    l_ab[2u * r] = normalRow[r].a - first;
+                    l_ab[2u * r + 1u] = b == kNone ? kNone : b - first;
+                }
             }
-            s_depth = depth;
-            s_any = any;
+            if (any) atomicOr(&s_any, 1u);
         }
         __syncthreads();
+        if (tid == 0) {
+            uint32_t depth = 0;
+            if (walk_in_lds) {
+                for (uint32_t r = 0; r < P; ++r) {
+                    const uint32_t a = l_ab[2u * r], b = l_ab[2u * r + 1u];
+                    uint32_t l = s_last[a];
+                    if (b != kNone) {
+                        const uint32_t lb = s_last[b];
+                        l = lb > l ? lb : l;
+                    }
+                    l += 1u;
+                    s_last[a] = l;
+                    if (b != kNone) s_last[b] = l;
+                    l_level[r] = l;
+                    depth = l > depth ? l : depth;
+                }
+            } else {
+                for (uint32_t r = 0; r < P; ++r) {
+                    const uint32_t a = normalRow[r].a - first, b = normalRow[r].b;
+                    uint32_t l = last_in_lds ? s_last[a] : ip.body_words[2u * (first + a) + 1u];
+                    if (b != kNone) {
+                        const uint32_t lb = last_in_lds ? s_last[b - first] : ip.body_words[2u * b + 1u];
+                        l = lb > l ? lb : l;
+                    }
+                    l += 1u;
+                    if (last_in_lds) {
+                        s_last[a] = l;
+                        if (b != kNone) s_last[b - first] = l;
+                    } else {
+                        ip.body_words[2u * (first + a) + 1u] = l;
+                        if (b != kNone) ip.body_words[2u * b + 1u] = l;
+                    }
+                    level[r] = l;
+                    depth = l > depth ? l : depth;
+                }
+            }
+            s_depth = depth;
+        }
+        __syncthreads();
+        if (walk_in_lds) {
+            for (uint32_t r = tid; r < P; r += 256u) level[r] = l_level[r];
+        }
         const uint32_t depth = s_depth;
         for (uint32_t k = tid; k < depth + 2u; k += 256u) start[k] = 0u;
         __syncthreads();
@@ -2864,14 +2924,22 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
                 __syncthreads();
             }
         };
+        const bool bodies_in_lds = nb <= kIslBigLdsBodies;
+        const IslLocalT<1u> L{s_dyn, first};
+        if (bodies_in_lds) { // (the levels are computed: their LDS now holds the bodies' delta velocities)
+            for (uint32_t k = tid; k < nb * 12u; k += 256u) s_dyn[k] = 0.0f;
+            __syncthreads();
+        }
         // the warm start, in the rows' order
-        sweep(normalRow, [&](IslRow& c, uint32_t) { isl_warm_start(sb, c); });
+        if (bodies_in_lds) sweep(normalRow, [&](IslRow& c, uint32_t) { isl_warm_start_lds(L, sb, c); });
+        else sweep(normalRow, [&](IslRow& c, uint32_t) { isl_warm_start(sb, c); });
         // solveGroupCacheFriendlySplitImpulseIterations
         if (s_any) {
             for (int it = 0; it < kIterations; ++it) {
                 sweep(normalRow, [&](IslRow& c, uint32_t r) {
                     if (c.rhsPenetration) {
-                        isl_resolve_split(sb, c);
+                        if (bodies_in_lds) isl_resolve_split_lds(L, sb, c, c.appliedPush);
+                        else isl_resolve_split(sb, c);
                         normalRow[r].appliedPush = c.appliedPush;
                     }
                 });
@@ -2880,7 +2948,8 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         // solveGroupCacheFriendlyIterations: all contact rows, then all friction rows
         for (int it = 0; it < kIterations; ++it) {
             sweep(normalRow, [&](IslRow& c, uint32_t r) {
-                isl_resolve_row(sb, c, false);
+                if (bodies_in_lds) isl_resolve_row_lds(L, sb, c, c.applied, c.lower, c.upper, false);
+                else isl_resolve_row(sb, c, false);
                 normalRow[r].applied = c.applied;
             });
             sweep(frictionRow, [&](IslRow& c, uint32_t r) {
@@ -2888,10 +2957,20 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
                 if (totalImpulse > 0.0f) {
                     c.lower = -(c.friction * totalImpulse);
                     c.upper = c.friction * totalImpulse;
-                    isl_resolve_row(sb, c, true);
+                    if (bodies_in_lds) isl_resolve_row_lds(L, sb, c, c.applied, c.lower, c.upper, true);
+                    else isl_resolve_row(sb, c, true);
                     frictionRow[r].applied = c.applied;
                 }
             });
+        }
+        if (bodies_in_lds) {
+            for (uint32_t i = first + tid; i < end; i += 256u) {
+                sb[i].dLin = L.get(i, 0);
+                sb[i].dAng = L.get(i, 1);
+                sb[i].push = L.get(i, 2);
+                sb[i].turn = L.get(i, 3);
+            }
+            // (each thread finishes the bodies it has just written: no barrier needed before isl_finish_body below — same i, same thread)
         }
         // solveGroupCacheFriendlyFinish
         for (uint32_t r = tid; r < P; r += 256u) {
@@ -2983,12 +3062,14 @@ hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const Gro
         hipLaunchKernelGGL(k_island_own<true>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, true>), mid_grid, block, 0, stream, w, g, ip);
-        hipLaunchKernelGGL(k_island_solve_big<true>, dim3(512), dim3(256), 0, stream, w, g, ip);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));
+        hipLaunchKernelGGL(k_island_solve_big<true>, dim3(256), dim3(256), kIslBigLdsBytes, stream, w, g, ip);
     } else {
         hipLaunchKernelGGL(k_island_own<false>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, true>), mid_grid, block, 0, stream, w, g, ip);
-        hipLaunchKernelGGL(k_island_solve_big<false>, dim3(512), dim3(256), 0, stream, w, g, ip);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));
+        hipLaunchKernelGGL(k_island_solve_big<false>, dim3(256), dim3(256), kIslBigLdsBytes, stream, w, g, ip);
     }
     return hipGetLastError();
 }
