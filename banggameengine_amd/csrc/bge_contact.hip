@@ -2489,8 +2489,17 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         const uint32_t root = static_cast<uint32_t>(ip.body_keys[first] >> 32);
         if (first > 0 && static_cast<uint32_t>(ip.body_keys[first - 1] >> 32) == root) return; // not the island's first body
         if (!ip.active[root]) return; // "all sleeping": k_tick turns its WANTS_DEACTIVATION bodies to ISLAND_SLEEPING, the others sleep already
-        end = first + 1;
-        while (end < ip.n_bodies && static_cast<uint32_t>(ip.body_keys[end] >> 32) == root) ++end;
+        {
+            // the island's bodies are the run of keys with this root: its end by bisection (a big island's head counted 1,828 keys one by
+            // one here — 0.46 ms)
+            uint32_t lo = first + 1, hi = ip.n_bodies;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (static_cast<uint32_t>(ip.body_keys[mid] >> 32) <= root) lo = mid + 1;
+                else hi = mid;
+            }
+            end = lo;
+        }
         if (end - first > ip.big_points && end - first > kIslLdsBodies) { // (that many bodies: not worth counting)
             const uint32_t at = atomicAdd(&ip.counts[4], 1u);
             ip.big_list[2u * at] = first;
