@@ -1664,7 +1664,9 @@ struct IslRow {
     uint32_t a, b;       // positions in the sorted body list; b = kNone: the fixed solver body
     float* out;          // the manifold point's appliedImpulse (contact rows only)
     uint32_t lateral_at; // ... and how many floats behind it appliedImpulseLateral1 is
-    uint32_t pad[3];
+    float invMassA, invMassB; // the two bodies' inverse masses (B's 0 without a second body): a resolve out of LDS state then needs no load
+                              // of its own — one issued behind the next row's would have to wait for that one first (loads return in order)
+    uint32_t pad;
 };
 static_assert(sizeof(IslRow) == kIslRowBytes, "IslandParams::rows");
 
@@ -2005,6 +2007,9 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
     c.lateral_at = lateral_at;
     fr.out = nullptr;
     fr.lateral_at = 0u;
+    c.invMassA = fr.invMassA = A.invMass;
+    c.invMassB = fr.invMassB = two ? sb[ib].invMass : 0.0f;
+    c.pad = fr.pad = 0u;
     const M3 invIA = isl_inv_i(A);
     const F3 rel_pos1 = sub3(worldA, A.origin);
     const F3 vel1 = add3(add3(A.linVel, A.extForce), cross3(add3(A.angVel, A.extTorque), rel_pos1));
@@ -2171,7 +2176,7 @@ template <class Local>
 __device__ __forceinline__ void isl_resolve_row_lds(const Local& L, const IslBody* sb, const IslRow& c, float& applied, float lower, float upper, bool withUpperLimit)
 {
     const bool two = c.b != kNone;
-    const float invMassA = sb[c.a].invMass;
+    const float invMassA = c.invMassA;
     F3 aLin = L.get(c.a, 0), aAng = L.get(c.a, 1);
     float deltaImpulse = c.rhs - applied * c.cfm;
     const float dv1 = isl_dpps(c.relposCrossN, aAng) + isl_dpps(c.normal, aLin);
@@ -2180,7 +2185,7 @@ __device__ __forceinline__ void isl_resolve_row_lds(const Local& L, const IslBod
     if (two) {
         bLin = L.get(c.b, 0);
         bAng = L.get(c.b, 1);
-        invMassB = sb[c.b].invMass;
+        invMassB = c.invMassB;
     }
     const float dv2 = two ? isl_dpps(neg3(c.normal), bLin) + isl_dpps(c.relpos2CrossN, bAng) : 0.0f + 0.0f;
     deltaImpulse = __builtin_fmaf(-dv1, c.jacDiagABInv, deltaImpulse);
@@ -2215,7 +2220,7 @@ __device__ __forceinline__ void isl_resolve_split_lds(const Local& L, const IslB
 {
     if (!c.rhsPenetration) return;
     const bool two = c.b != kNone;
-    const float invMassA = sb[c.a].invMass;
+    const float invMassA = c.invMassA;
     const F3 aPush = L.get(c.a, 2), aTurn = L.get(c.a, 3);
     float deltaImpulse = c.rhsPenetration - appliedPush * c.cfm;
     const float dv1 = isl_dot3s(c.normal, aPush) + isl_dot3s(c.relposCrossN, aTurn);
@@ -2224,7 +2229,7 @@ __device__ __forceinline__ void isl_resolve_split_lds(const Local& L, const IslB
     if (two) {
         bPush = L.get(c.b, 2);
         bTurn = L.get(c.b, 3);
-        invMassB = sb[c.b].invMass;
+        invMassB = c.invMassB;
     }
     const float dv2 = two ? isl_dot3s(neg3(c.normal), bPush) + isl_dot3s(c.relpos2CrossN, bTurn) : 0.0f + 0.0f;
     deltaImpulse = deltaImpulse - dv1 * c.jacDiagABInv;
@@ -2632,12 +2637,14 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
                 const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
                 isl_resolve_row_lds(L, sb, cur, cur.applied, cur.lower, cur.upper, false);
                 normalRow[r].applied = cur.applied;
+                frictionRow[r].appliedPush = cur.applied; // (a friction row has no push impulse: the word carries its contact row's impulse to
+                                                          //  the friction sweep inside the row — no load of its own behind the next row's)
                 cur = nxt;
             }
             cur = frictionRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = frictionRow[r + 1 < n_points ? r + 1 : r];
-                const float totalImpulse = normalRow[r].applied;
+                const float totalImpulse = cur.appliedPush;
                 if (totalImpulse > 0.0f) {
                     const float friction = cur.friction;
                     isl_resolve_row_lds(L, sb, cur, cur.applied, -(friction * totalImpulse), friction * totalImpulse, true);
@@ -2719,13 +2726,13 @@ __device__ __forceinline__ void isl_warm_start(IslBody* sb, const IslRow& c)
 template <class Local>
 __device__ __forceinline__ void isl_warm_start_lds(const Local& L, const IslBody* sb, const IslRow& c)
 {
-    const float invMassA = sb[c.a].invMass;
+    const float invMassA = c.invMassA;
     const F3 n = c.normal;
     const F3 lin = F3{c.normal.x * invMassA, c.normal.y * invMassA, c.normal.z * invMassA};
     L.set(c.a, 0, add3(L.get(c.a, 0), scale3(lin, c.applied)));
     L.set(c.a, 1, add3(L.get(c.a, 1), scale3(c.angularComp, c.applied * 1.0f)));
     if (c.b != kNone) {
-        const float invMassB = sb[c.b].invMass;
+        const float invMassB = c.invMassB;
         const F3 linB = F3{invMassB * n.x, invMassB * n.y, invMassB * n.z};
         L.set(c.b, 0, sub3(L.get(c.b, 0), scale3(linB, c.applied)));
         L.set(c.b, 1, add3(L.get(c.b, 1), scale3(c.angularCompB, c.applied * 1.0f)));
@@ -2960,9 +2967,10 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
                 if (bodies_in_lds) isl_resolve_row_lds(L, sb, c, c.applied, c.lower, c.upper, false);
                 else isl_resolve_row(sb, c, false);
                 normalRow[r].applied = c.applied;
+                frictionRow[r].appliedPush = c.applied; // (carries the contact row's impulse to the friction sweep inside the friction row)
             });
             sweep(frictionRow, [&](IslRow& c, uint32_t r) {
-                const float totalImpulse = normalRow[r].applied;
+                const float totalImpulse = c.appliedPush;
                 if (totalImpulse > 0.0f) {
                     c.lower = -(c.friction * totalImpulse);
                     c.upper = c.friction * totalImpulse;
