@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(kTile, NORMAL ? 4 : (AABB ? BGE_AABB_MIN_WAVES
                 const uint32_t dz0 = (kSleepEnabled && (f & kDrowsy)) ? (ground_early ? dz_early : w.deact[slot]) : 0u;
                 uint32_t dz = dz0;
                 // buildIslands: a free body is an island of its own; WANTS_DEACTIVATION -> ISLAND_SLEEPING
-                // (kCiIsland: an island of several bodies with an active body in it keeps this one awake — bge_contact.hip k_island_flags)
+                // (kCiIsland: an island of several bodies with an active body in it keeps this one awake — bge_island.hip k_island_flags)
                 if (dz == kDeactWants && !(ci & kCiIsland)) dz = kDeactSleeping;
                 if (inv_mass != 0.0f && dz == kDeactSleeping) {
                     // asleep: no gravity, not solved, not integrated; updateActivationState zeroes the velocities

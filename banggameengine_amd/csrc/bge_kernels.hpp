@@ -114,7 +114,7 @@ struct GroundParams {
     uint32_t* box_count;       // [0] entries of box_list, [1] workgroups of k_contact_boxes that are done (both zero between sub-steps)
     uint32_t obstacles_ready;  // the island phases of this sub-step ran k_obstacles (launch_obstacles) already
 };
-// Dynamic boxes against each other (round 3, bge_contact.hip "islands"): the pair cache of Dynamic boxes with a persistent manifold per
+// Dynamic boxes against each other (round 3, bge_island.hip): the pair cache of Dynamic boxes with a persistent manifold per
 // pair, simulation islands by union-find over the pairs, one solver thread per island.  All arrays are device memory of the world.
 struct IslandParams {
     float dt, gx, gy, gz;

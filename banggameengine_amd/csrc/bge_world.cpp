@@ -212,7 +212,7 @@ struct bge_world {
     // sharded broadphase (bge_route.hip): records routed to spatial slabs, pair search over what was received
     bge::ShardRouter router;
     bge::Broadphase slab_broadphase;
-    // Dynamic boxes against each other (bge_contact.hip "islands"): a broadphase of its own over the sub-step's fed AABBs (the tick's
+    // Dynamic boxes against each other (bge_island.hip): a broadphase of its own over the sub-step's fed AABBs (the tick's
     // pair list and the trigger query keep theirs), the sorted pair cache with its manifolds in two generations, per-slot scratch
     bool dynamic_contacts = false;
     bool static_contacts_ever = false; // bge_world_set_static_contacts(1) was called: bodies may hold manifolds with obstacles
@@ -891,7 +891,7 @@ int filter_palette_of(bge_world* w, bge::FilterPalette* out)
     return BGE_OK;
 }
 
-// One sub-step's collision detection and constraint solving for the Dynamic boxes that touch each other (bge_contact.hip "islands";
+// One sub-step's collision detection and constraint solving for the Dynamic boxes that touch each other (bge_island.hip;
 // oracle/physics_ref.h CollideDynamicPairs / StepIsland).  Runs before k_ground_select; two small read-backs (pairs, island bodies)
 // size the sorts between its phases.
 int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool bullet_basis, bool later_sub_step, bool tick_wants_pairs)

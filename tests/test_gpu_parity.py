@@ -1303,7 +1303,7 @@ def _compare_dynamic_world(w, ref, tick, dyn, plane, static):
 @pytest.mark.parametrize("basis,plane,static,big", [(False, True, False, 128), (True, True, True, 128), (False, False, True, 128), (True, True, True, 16), (False, True, False, 0)],
                          ids=["default-plane", "bullet_basis-plane-obstacles", "default-obstacles", "workgroup-solver-above-16-points", "workgroup-solver-for-all-but-the-smallest"])
 def test_dynamic_boxes_against_each_other_match_oracle_bitwise(basis, plane, static, big, monkeypatch):
-    """Dynamic boxes collide with EACH OTHER (bge_world_set_dynamic_contacts; bge_contact.hip "islands" against oracle/island_ref.h and
+    """Dynamic boxes collide with EACH OTHER (bge_world_set_dynamic_contacts; bge_island.hip against oracle/island_ref.h and
     physics_ref.h CollideDynamicPairs / StepIsland).  Three towers of five, a loose heap of 120 boxes of mixed size, mass, friction and
     restitution raining on a 7 x 7 m patch (they pile up three deep), a far-away pair that only ever touches each other, a few
     capsules and a filtered-out layer that take no part; the plane below and / or Static platforms.  A heavy box is thrown into the

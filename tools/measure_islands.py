@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Cost of the Dynamic-against-Dynamic contact path (bge_world_set_dynamic_contacts; bge_contact.hip "islands") at scale, per tick:
+"""Cost of the Dynamic-against-Dynamic contact path (bge_world_set_dynamic_contacts; bge_island.hip) at scale, per tick:
 
   free      n Dynamic boxes in free fall, nobody near anybody: what the sub-step's pair search and its two read-backs cost on top of
             the tick (with the switch off for comparison)
