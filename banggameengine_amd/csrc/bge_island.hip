@@ -271,12 +271,26 @@ __global__ void __launch_bounds__(256) k_island_orphans(WorldView w, IslandParam
     isl_list_body(w, ip, s);
 }
 
+// first pair of the sorted pair list whose lower entity is `entity`
+__device__ __forceinline__ uint32_t isl_first_pair_of(const IslandParams& ip, uint32_t entity)
+{
+    const uint64_t owner = static_cast<uint64_t>(entity) << 32;
+    uint32_t lo = 0, hi = ip.n_pairs;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ip.keys[mid] < owner) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(256) k_island_flags(WorldView w, IslandParams ip)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ip.n_bodies) return;
     const uint32_t s = ip.body_slot[i];
     ip.index_of_slot[s] = i;
+    ip.pair_first[i] = isl_first_pair_of(ip, ip.entity_of_slot[s]);
     if (ip.active[static_cast<uint32_t>(ip.body_keys[i] >> 32)]) w.cinfo[s] |= kCiIsland;
 }
 
@@ -720,25 +734,12 @@ __device__ uint32_t isl_prepare_body(const WorldView& w, const GroundParams& g, 
     return own;
 }
 
-// first pair of the sorted pair list whose lower entity is `entity`
-__device__ __forceinline__ uint32_t isl_first_pair_of(const IslandParams& ip, uint32_t entity)
+// contact points of the pairs body i of the sorted list owns (it is their lower entity)
+__device__ uint32_t isl_pair_points(const IslandParams& ip, uint32_t i)
 {
-    const uint64_t owner = static_cast<uint64_t>(entity) << 32;
-    uint32_t lo = 0, hi = ip.n_pairs;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (ip.keys[mid] < owner) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-
-// contact points of the pairs the body owns (it is their lower entity)
-__device__ uint32_t isl_pair_points(const IslandParams& ip, uint32_t slot)
-{
-    const uint32_t entity = ip.entity_of_slot[slot];
+    const uint32_t entity = ip.entity_of_slot[ip.body_slot[i]];
     uint32_t n = 0;
-    for (uint32_t k = isl_first_pair_of(ip, entity); k < ip.n_pairs && static_cast<uint32_t>(ip.keys[k] >> 32) == entity; ++k) {
+    for (uint32_t k = ip.pair_first[i]; k < ip.n_pairs && static_cast<uint32_t>(ip.keys[k] >> 32) == entity; ++k) {
         n += ip.man[static_cast<uint64_t>(k) * kBoxManifoldWords];
     }
     return n;
@@ -795,12 +796,7 @@ __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& 
             }
         }
         const uint64_t owner = static_cast<uint64_t>(ip.entity_of_slot[slot]) << 32;
-        uint32_t lo = 0, hi = ip.n_pairs;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (ip.keys[mid] < owner) lo = mid + 1;
-            else hi = mid;
-        }
+        const uint32_t lo = ip.pair_first[i]; // (k_island_flags looked it up: a bisection here is 17 loads that wait for each other)
         for (uint32_t k = lo; k < ip.n_pairs && (ip.keys[k] >> 32) == (owner >> 32); ++k) {
             uint32_t* m = ip.man + static_cast<uint64_t>(k) * kBoxManifoldWords;
             const uint32_t other_slot = ip.slot_of_entity[static_cast<uint32_t>(ip.keys[k])];
@@ -895,7 +891,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     uint32_t n_points = 0;
     for (uint32_t i = first; i < end; ++i) n_points += isl_prepare_body<BASIS>(w, g, ip, sb, i);
     // the pairs owned by the island's bodies (keys ascend with the owner's entity, so they are one run per body)
-    for (uint32_t i = first; i < end; ++i) n_points += isl_pair_points(ip, ip.body_slot[i]);
+    for (uint32_t i = first; i < end; ++i) n_points += isl_pair_points(ip, i);
     const bool small = end - first <= kIslLdsBodies && n_points <= kIslLdsPoints;
     if (!MID && !small) { // (whoever takes it prepares its bodies again: the same values)
         if (n_points > ip.big_points) {
@@ -1175,7 +1171,7 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         const uint32_t first = ip.big_list[2u * t], end = ip.big_list[2u * t + 1u], nb = end - first;
         // convertBodies; the rows of every body
         for (uint32_t i = first + tid; i < end; i += 256u) {
-            ip.body_words[2u * i] = isl_prepare_body<BASIS>(w, g, ip, sb, i) + isl_pair_points(ip, ip.body_slot[i]);
+            ip.body_words[2u * i] = isl_prepare_body<BASIS>(w, g, ip, sb, i) + isl_pair_points(ip, i);
         }
         __syncthreads();
         const uint32_t P = isl_wg_scan(ip.body_words + 2ull * first, nb, 2u, s_part, &s_total);

@@ -155,6 +155,7 @@ struct IslandParams {
     // islands too big for one thread's LDS column: k_island_solve lists them, k_island_solve_big takes a workgroup to each
     uint32_t* big_list;             // [n_bodies][2] first body, end (counts[4] of them; counts[5] is the workgroups' ticket)
     uint32_t* mid_list;             // [n_bodies][2] likewise, islands of 5 .. 16 bodies (counts[7] of them): k_island_solve<.., true>
+    uint32_t* pair_first;           // [n_bodies] first pair of the sorted list that body i owns (k_island_flags)
     uint32_t* body_words;           // [n_bodies][2] per body of a big island: rows before it / the level of its last row
     uint32_t* ints;                 // [int_cap] per-row level, rows in level order, level starts (counts[6] handed out)
     uint32_t int_cap;

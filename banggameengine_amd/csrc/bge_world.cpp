@@ -1050,11 +1050,12 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     // islands a workgroup solves level by level (k_island_solve_big): the list of them, two words per body, four per point for the levels
     const uint64_t int_cap = 2ull * row_cap + 8ull * n_bodies + 64;
     HIP_TRY(w->isl_big_list.ensure(static_cast<size_t>(n_bodies) * 16)); // (two lists: big islands, mid islands)
-    HIP_TRY(w->isl_body_words.ensure(static_cast<size_t>(n_bodies) * 8));
+    HIP_TRY(w->isl_body_words.ensure(static_cast<size_t>(n_bodies) * 12)); // (two words a body for the workgroup solver + pair_first)
     HIP_TRY(w->isl_ints.ensure(static_cast<size_t>(int_cap) * 4));
     ip.big_list = w->isl_big_list.as<uint32_t>();
     ip.mid_list = ip.big_list + 2ull * n_bodies;
     ip.body_words = w->isl_body_words.as<uint32_t>();
+    ip.pair_first = ip.body_words + 2ull * n_bodies;
     ip.ints = w->isl_ints.as<uint32_t>();
     ip.int_cap = static_cast<uint32_t>(std::min<uint64_t>(int_cap, 0xffffffffu));
     ip.big_points = w->isl_big_points;
