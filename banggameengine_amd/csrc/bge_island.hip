@@ -848,6 +848,17 @@ __device__ void isl_finish_body(const WorldView& w, const GroundParams& g, IslBo
         w.cinfo[slot] = ci;
 }
 
+// convertBodies for every body of an island that stays awake, one thread a body (the solver threads would do it one body after the
+// other), and the contact points the body brings into its island's row list: its own manifolds' and those of the pairs it owns
+template <bool BASIS>
+__global__ void __launch_bounds__(64) k_island_bodies(WorldView w, GroundParams g, IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_bodies) return;
+    if (!(w.cinfo[ip.body_slot[i]] & kCiIsland)) return;
+    ip.body_words[2u * i] = isl_prepare_body<BASIS>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), i) + isl_pair_points(ip, i);
+}
+
 // MID = false: the grid walks the sorted body list, an island's first body solves it — or hands it on: to the mid list (5 .. kIslMidBodies bodies:
 // k_island_solve<.., true>, launched next, keeps their bodies' delta velocities in LDS) or to the big list (k_island_solve_big).
 template <bool BASIS, bool MID>
@@ -887,13 +898,11 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     IslBody* sb = static_cast<IslBody*>(ip.solver_bodies);
     const int kIterations = static_cast<int>(ip.iterations);
     const float invTimeStep = 1.0f / g.dt;
-    // ---- convertBodies, and how many rows the island needs
+    // ---- how many rows the island needs
     uint32_t n_points = 0;
-    for (uint32_t i = first; i < end; ++i) n_points += isl_prepare_body<BASIS>(w, g, ip, sb, i);
-    // the pairs owned by the island's bodies (keys ascend with the owner's entity, so they are one run per body)
-    for (uint32_t i = first; i < end; ++i) n_points += isl_pair_points(ip, i);
+    for (uint32_t i = first; i < end; ++i) n_points += ip.body_words[2u * i]; // (k_island_bodies prepared the bodies and counted)
     const bool small = end - first <= kIslLdsBodies && n_points <= kIslLdsPoints;
-    if (!MID && !small) { // (whoever takes it prepares its bodies again: the same values)
+    if (!MID && !small) { // (its bodies are prepared: k_island_bodies)
         if (n_points > ip.big_points) {
             const uint32_t at = atomicAdd(&ip.counts[4], 1u);
             ip.big_list[2u * at] = first;
@@ -1169,11 +1178,7 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         const uint32_t t = s_ticket;
         if (t >= ip.counts[4]) return;
         const uint32_t first = ip.big_list[2u * t], end = ip.big_list[2u * t + 1u], nb = end - first;
-        // convertBodies; the rows of every body
-        for (uint32_t i = first + tid; i < end; i += 256u) {
-            ip.body_words[2u * i] = isl_prepare_body<BASIS>(w, g, ip, sb, i) + isl_pair_points(ip, i);
-        }
-        __syncthreads();
+        // (k_island_bodies prepared the bodies and left every body's number of rows in body_words)
         const uint32_t P = isl_wg_scan(ip.body_words + 2ull * first, nb, 2u, s_part, &s_total);
         if (P == 0) { // (bodies in each other's AABBs, nothing touches: gravity and the gyroscopic term only)
             for (uint32_t i = first + tid; i < end; i += 256u) isl_finish_body<BASIS>(w, g, sb, i);
@@ -1419,12 +1424,14 @@ hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const Gro
     const dim3 mid_grid((ip.n_bodies / (kIslLdsBodies + 1u) + 64u) / 64u); // (an island on the mid list has more than kIslLdsBodies bodies)
     if (bullet_basis) {
         hipLaunchKernelGGL(k_island_own<true>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL(k_island_bodies<true>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, true>), mid_grid, block, 0, stream, w, g, ip);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));
         hipLaunchKernelGGL(k_island_solve_big<true>, dim3(256), dim3(256), kIslBigLdsBytes, stream, w, g, ip);
     } else {
         hipLaunchKernelGGL(k_island_own<false>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL(k_island_bodies<false>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, true>), mid_grid, block, 0, stream, w, g, ip);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));
