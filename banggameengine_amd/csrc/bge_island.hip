@@ -848,6 +848,38 @@ __device__ void isl_finish_body(const WorldView& w, const GroundParams& g, IslBo
         w.cinfo[slot] = ci;
 }
 
+// the warm start of one contact row (the block isl_add_contact<true> runs in place)
+__device__ __forceinline__ void isl_warm_start(IslBody* sb, const IslRow& c)
+{
+    IslBody& A = sb[c.a];
+    const F3 n = c.normal;
+    const F3 lin = F3{c.normal.x * A.invMass, c.normal.y * A.invMass, c.normal.z * A.invMass};
+    A.dLin = add3(A.dLin, scale3(lin, c.applied));
+    A.dAng = add3(A.dAng, scale3(c.angularComp, c.applied * 1.0f));
+    if (c.b != kNone) {
+        IslBody& B = sb[c.b];
+        const F3 linB = F3{B.invMass * n.x, B.invMass * n.y, B.invMass * n.z};
+        B.dLin = sub3(B.dLin, scale3(linB, c.applied));
+        B.dAng = add3(B.dAng, scale3(c.angularCompB, c.applied * 1.0f));
+    }
+}
+
+template <class Local>
+__device__ __forceinline__ void isl_warm_start_lds(const Local& L, const IslBody* sb, const IslRow& c)
+{
+    const float invMassA = c.invMassA;
+    const F3 n = c.normal;
+    const F3 lin = F3{c.normal.x * invMassA, c.normal.y * invMassA, c.normal.z * invMassA};
+    L.set(c.a, 0, add3(L.get(c.a, 0), scale3(lin, c.applied)));
+    L.set(c.a, 1, add3(L.get(c.a, 1), scale3(c.angularComp, c.applied * 1.0f)));
+    if (c.b != kNone) {
+        const float invMassB = c.invMassB;
+        const F3 linB = F3{invMassB * n.x, invMassB * n.y, invMassB * n.z};
+        L.set(c.b, 0, sub3(L.get(c.b, 0), scale3(linB, c.applied)));
+        L.set(c.b, 1, add3(L.get(c.b, 1), scale3(c.angularCompB, c.applied * 1.0f)));
+    }
+}
+
 // convertBodies for every body of an island that stays awake, one thread a body (the solver threads would do it one body after the
 // other), and the contact points the body brings into its island's row list: its own manifolds' and those of the pairs it owns
 template <bool BASIS>
@@ -855,8 +887,26 @@ __global__ void __launch_bounds__(64) k_island_bodies(WorldView w, GroundParams 
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ip.n_bodies) return;
-    if (!(w.cinfo[ip.body_slot[i]] & kCiIsland)) return;
-    ip.body_words[2u * i] = isl_prepare_body<BASIS>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), i) + isl_pair_points(ip, i);
+    uint32_t n = 0;
+    if (w.cinfo[ip.body_slot[i]] & kCiIsland) n = isl_prepare_body<BASIS>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), i) + isl_pair_points(ip, i);
+    ip.row_count[i] = n;
+}
+
+// convertContacts, one thread a body: the body's rows at their place in the island's row list (row_first: the exclusive sum of the
+// counts over the sorted body list, so an island's rows are one run), without the warm start — that is order-dependent and the
+// solver's first sweep
+template <bool BASIS>
+__global__ void __launch_bounds__(64) k_island_rows(WorldView w, GroundParams g, IslandParams ip)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ip.n_bodies || ip.row_count[i] == 0u) return;
+    const uint32_t at = ip.row_first[i];
+    if (at + ip.row_count[i] > ip.row_cap / 2u) {
+        atomicOr(&ip.counts[3], 1u); // (cannot happen: the host sizes the arrays for every point the manifolds can hold)
+        return;
+    }
+    IslRow* normalRow = static_cast<IslRow*>(ip.rows);
+    isl_build_body_rows<false>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), i, 1.0f / g.dt, normalRow, normalRow + ip.row_cap / 2u, at);
 }
 
 // MID = false: the grid walks the sorted body list, an island's first body solves it — or hands it on: to the mid list (5 .. kIslMidBodies bodies:
@@ -897,12 +947,11 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     }
     IslBody* sb = static_cast<IslBody*>(ip.solver_bodies);
     const int kIterations = static_cast<int>(ip.iterations);
-    const float invTimeStep = 1.0f / g.dt;
-    // ---- how many rows the island needs
-    uint32_t n_points = 0;
-    for (uint32_t i = first; i < end; ++i) n_points += ip.body_words[2u * i]; // (k_island_bodies prepared the bodies and counted)
+    // ---- the island's rows: k_island_rows built them at rows row_first[first] .. of the two arrays
+    const uint32_t row0 = ip.row_first[first];
+    const uint32_t n_points = ip.row_first[end - 1u] + ip.row_count[end - 1u] - row0;
     const bool small = end - first <= kIslLdsBodies && n_points <= kIslLdsPoints;
-    if (!MID && !small) { // (its bodies are prepared: k_island_bodies)
+    if (!MID && !small) {
         if (n_points > ip.big_points) {
             const uint32_t at = atomicAdd(&ip.counts[4], 1u);
             ip.big_list[2u * at] = first;
@@ -916,32 +965,19 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
             return;
         }
     }
-    IslRow* rows_base = nullptr;
-    if (n_points) {
-        const uint32_t at = atomicAdd(&ip.counts[2], 2u * n_points);
-        if (at + 2u * n_points > ip.row_cap) {
-            atomicOr(&ip.counts[3], 1u); // (cannot happen: the host sizes the pool for every point the manifolds can hold)
-            return;
-        }
-        rows_base = static_cast<IslRow*>(ip.rows) + at;
-    }
-    IslRow* normalRow = rows_base;
-    IslRow* frictionRow = rows_base + n_points;
-    // ---- convertContacts: body by body (ascending entity) its plane manifold, its manifolds with obstacles (ascending entity), its pairs
-    //      with Dynamic boxes of higher entity (ascending)
-    uint32_t j = 0;
-    for (uint32_t i = first; i < end; ++i) j = isl_build_body_rows<true>(w, g, ip, sb, i, invTimeStep, normalRow, frictionRow, j);
+    if (row0 + n_points > ip.row_cap / 2u) return; // (reported by k_island_rows)
+    IslRow* normalRow = static_cast<IslRow*>(ip.rows) + row0;
+    IslRow* frictionRow = static_cast<IslRow*>(ip.rows) + ip.row_cap / 2u + row0;
     // ---- solveGroupCacheFriendlySplitImpulseIterations, solveGroupCacheFriendlyIterations
     if (!MID && small) {
         const IslLocal L{s_isl + (threadIdx.x & 63u), first};
         for (uint32_t i = first; i < end; ++i) {
-            L.set(i, 0, sb[i].dLin); // (the warm start)
-            L.set(i, 1, sb[i].dAng);
-            L.set(i, 2, F3{0.0f, 0.0f, 0.0f});
-            L.set(i, 3, F3{0.0f, 0.0f, 0.0f});
+            for (uint32_t f = 0; f < 4u; ++f) L.set(i, f, F3{0.0f, 0.0f, 0.0f});
         }
-        for (uint32_t r = 0; r < n_points; ++r) {
-            L.row(r, 0) = normalRow[r].applied;
+        for (uint32_t r = 0; r < n_points; ++r) { // (the warm start, in the rows' order)
+            const IslRow c = normalRow[r];
+            isl_warm_start_lds(L, sb, c);
+            L.row(r, 0) = c.applied;
             L.row(r, 1) = 0.0f;
             L.row(r, 2) = 0.0f;
         }
@@ -992,11 +1028,9 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         //  in LDS, a row's own scalars in the row; rows one ahead, a resolved row writes back the one word that changed)
         const IslLocal L{s_isl + (threadIdx.x & 63u), first};
         for (uint32_t i = first; i < end; ++i) {
-            L.set(i, 0, sb[i].dLin);
-            L.set(i, 1, sb[i].dAng);
-            L.set(i, 2, F3{0.0f, 0.0f, 0.0f});
-            L.set(i, 3, F3{0.0f, 0.0f, 0.0f});
+            for (uint32_t f = 0; f < 4u; ++f) L.set(i, f, F3{0.0f, 0.0f, 0.0f});
         }
+        for (uint32_t r = 0; r < n_points; ++r) isl_warm_start_lds(L, sb, normalRow[r]); // (the warm start, in the rows' order)
         for (int it = 0; it < kIterations; ++it) {
             bool any = false;
             for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
@@ -1043,6 +1077,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     } else {
         // (more than kIslMidBodies bodies on at most IslandParams::big_points contact points — rare —: everything in global memory, still
         //  one thread; rows one ahead, a resolved row writes back the one word that changed)
+        for (uint32_t r = 0; r < n_points; ++r) isl_warm_start(sb, normalRow[r]);
         for (int it = 0; it < kIterations; ++it) {
             bool any = false;
             for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
@@ -1086,38 +1121,6 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         normalRow[r].out[normalRow[r].lateral_at] = frictionRow[r].applied;
     }
     for (uint32_t i = first; i < end; ++i) isl_finish_body<BASIS>(w, g, sb, i);
-}
-
-// the warm start of one contact row (the block isl_add_contact<true> runs in place)
-__device__ __forceinline__ void isl_warm_start(IslBody* sb, const IslRow& c)
-{
-    IslBody& A = sb[c.a];
-    const F3 n = c.normal;
-    const F3 lin = F3{c.normal.x * A.invMass, c.normal.y * A.invMass, c.normal.z * A.invMass};
-    A.dLin = add3(A.dLin, scale3(lin, c.applied));
-    A.dAng = add3(A.dAng, scale3(c.angularComp, c.applied * 1.0f));
-    if (c.b != kNone) {
-        IslBody& B = sb[c.b];
-        const F3 linB = F3{B.invMass * n.x, B.invMass * n.y, B.invMass * n.z};
-        B.dLin = sub3(B.dLin, scale3(linB, c.applied));
-        B.dAng = add3(B.dAng, scale3(c.angularCompB, c.applied * 1.0f));
-    }
-}
-
-template <class Local>
-__device__ __forceinline__ void isl_warm_start_lds(const Local& L, const IslBody* sb, const IslRow& c)
-{
-    const float invMassA = c.invMassA;
-    const F3 n = c.normal;
-    const F3 lin = F3{c.normal.x * invMassA, c.normal.y * invMassA, c.normal.z * invMassA};
-    L.set(c.a, 0, add3(L.get(c.a, 0), scale3(lin, c.applied)));
-    L.set(c.a, 1, add3(L.get(c.a, 1), scale3(c.angularComp, c.applied * 1.0f)));
-    if (c.b != kNone) {
-        const float invMassB = c.invMassB;
-        const F3 linB = F3{invMassB * n.x, invMassB * n.y, invMassB * n.z};
-        L.set(c.b, 0, sub3(L.get(c.b, 0), scale3(linB, c.applied)));
-        L.set(c.b, 1, add3(L.get(c.b, 1), scale3(c.angularCompB, c.applied * 1.0f)));
-    }
 }
 
 // Exclusive scan of a[0 .. n) in place by the workgroup (256 threads, contiguous chunks); returns the total.  Ends with a barrier.
@@ -1166,11 +1169,10 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
     // not for the stores of the level before to reach L2 and come back
     extern __shared__ float s_dyn[];
     uint32_t* s_last = reinterpret_cast<uint32_t*>(s_dyn);
-    __shared__ uint32_t s_ticket, s_total, s_depth, s_rows_at, s_ints_at, s_fail, s_any;
+    __shared__ uint32_t s_ticket, s_total, s_depth, s_ints_at, s_fail, s_any;
     IslBody* sb = static_cast<IslBody*>(ip.solver_bodies);
     const uint32_t tid = threadIdx.x;
     const int kIterations = static_cast<int>(ip.iterations);
-    const float invTimeStep = 1.0f / g.dt;
     for (;;) {
         __syncthreads();
         if (tid == 0) s_ticket = atomicAdd(&ip.counts[5], 1u);
@@ -1178,33 +1180,29 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         const uint32_t t = s_ticket;
         if (t >= ip.counts[4]) return;
         const uint32_t first = ip.big_list[2u * t], end = ip.big_list[2u * t + 1u], nb = end - first;
-        // (k_island_bodies prepared the bodies and left every body's number of rows in body_words)
-        const uint32_t P = isl_wg_scan(ip.body_words + 2ull * first, nb, 2u, s_part, &s_total);
+        // (k_island_bodies prepared the bodies, k_island_rows built the rows: rows row_first[first] .. of the two arrays)
+        const uint32_t row0 = ip.row_first[first];
+        const uint32_t P = ip.row_first[end - 1u] + ip.row_count[end - 1u] - row0;
         if (P == 0) { // (bodies in each other's AABBs, nothing touches: gravity and the gyroscopic term only)
             for (uint32_t i = first + tid; i < end; i += 256u) isl_finish_body<BASIS>(w, g, sb, i);
             continue;
         }
         if (tid == 0) {
             s_fail = 0u;
-            s_rows_at = atomicAdd(&ip.counts[2], 2u * P);
             s_ints_at = atomicAdd(&ip.counts[6], 4u * P + 8u);
-            if (s_rows_at + 2u * P > ip.row_cap || s_ints_at + 4u * P + 8u > ip.int_cap) {
+            if (row0 + P > ip.row_cap / 2u || s_ints_at + 4u * P + 8u > ip.int_cap) {
                 atomicOr(&ip.counts[3], 1u); // (cannot happen: both pools hold every point the manifolds can hold)
                 s_fail = 1u;
             }
         }
         __syncthreads();
         if (s_fail) continue;
-        IslRow* normalRow = static_cast<IslRow*>(ip.rows) + s_rows_at;
-        IslRow* frictionRow = normalRow + P;
+        IslRow* normalRow = static_cast<IslRow*>(ip.rows) + row0;
+        IslRow* frictionRow = static_cast<IslRow*>(ip.rows) + ip.row_cap / 2u + row0;
         uint32_t* level = ip.ints + s_ints_at;  // [P] level of row r (1 ..)
         uint32_t* order = level + P;            // [P] rows in level order
         uint32_t* start = order + P;            // [depth + 2] first entry of level l in `order`
         uint32_t* cursor = start + P + 4u;      // [depth + 2]
-        // convertContacts without the warm start, body by body
-        for (uint32_t i = first + tid; i < end; i += 256u) {
-            isl_build_body_rows<false>(w, g, ip, sb, i, invTimeStep, normalRow, frictionRow, ip.body_words[2u * i]);
-        }
         // the levels: one walk over the rows in their order (integers only).  Where it fits, the walk runs out of LDS: the two body
         // numbers of every row are fetched by all threads first (a walk that waits for a global load per row took 2 of this kernel's
         // 2.9 ms on a 2,000-box heap)
@@ -1416,15 +1414,25 @@ hipError_t launch_island_build(hipStream_t stream, const WorldView& w, const Isl
     return hipGetLastError();
 }
 
+size_t island_scan_bytes(uint32_t n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<int>(n));
+    return bytes;
+}
+
 hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const GroundParams& g, const IslandParams& ip, bool bullet_basis)
 {
     if (ip.n_bodies == 0) return hipSuccess;
     hipLaunchKernelGGL(k_island_flags, dim3((ip.n_bodies + 255u) / 256u), dim3(256), 0, stream, w, ip);
     const dim3 grid((ip.n_bodies + 63u) / 64u), block(64);
+    size_t scan_bytes = ip.scan_tmp_bytes;
     const dim3 mid_grid((ip.n_bodies / (kIslLdsBodies + 1u) + 64u) / 64u); // (an island on the mid list has more than kIslLdsBodies bodies)
     if (bullet_basis) {
         hipLaunchKernelGGL(k_island_own<true>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL(k_island_bodies<true>, grid, block, 0, stream, w, g, ip);
+        (void)hipcub::DeviceScan::ExclusiveSum(ip.scan_tmp, scan_bytes, ip.row_count, ip.row_first, static_cast<int>(ip.n_bodies), stream);
+        hipLaunchKernelGGL(k_island_rows<true>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, true>), mid_grid, block, 0, stream, w, g, ip);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));
@@ -1432,6 +1440,8 @@ hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const Gro
     } else {
         hipLaunchKernelGGL(k_island_own<false>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL(k_island_bodies<false>, grid, block, 0, stream, w, g, ip);
+        (void)hipcub::DeviceScan::ExclusiveSum(ip.scan_tmp, scan_bytes, ip.row_count, ip.row_first, static_cast<int>(ip.n_bodies), stream);
+        hipLaunchKernelGGL(k_island_rows<false>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, true>), mid_grid, block, 0, stream, w, g, ip);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));

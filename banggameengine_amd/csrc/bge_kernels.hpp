@@ -149,12 +149,16 @@ struct IslandParams {
     const uint32_t* body_slot;
     uint32_t body_cap, n_bodies;
     void* solver_bodies;            // [n_bodies] IslBody
-    void* rows;                     // [row_cap] IslRow x 2 per contact point
+    void* rows;                     // [row_cap] IslRow: the contact rows in [0, row_cap / 2), the friction rows behind them
     uint32_t row_cap;
     uint32_t iterations;            // 10 (btContactSolverInfo::m_numIterations); BGE_ISLAND_ITERATIONS overrides it for MEASUREMENTS only
     // islands too big for one thread's LDS column: k_island_solve lists them, k_island_solve_big takes a workgroup to each
     uint32_t* big_list;             // [n_bodies][2] first body, end (counts[4] of them; counts[5] is the workgroups' ticket)
     uint32_t* mid_list;             // [n_bodies][2] likewise, islands of 5 .. 16 bodies (counts[7] of them): k_island_solve<.., true>
+    uint32_t* row_count;            // [n_bodies] contact points body i brings into its island's row list (k_island_bodies; 0 off the path)
+    uint32_t* row_first;            // [n_bodies] exclusive sum of row_count: the island's rows are rows row_first[first] .. of the two arrays
+    void* scan_tmp;                 // hipcub's temporary storage for that sum (island_scan_bytes)
+    uint64_t scan_tmp_bytes;
     uint32_t* pair_first;           // [n_bodies] first pair of the sorted list that body i owns (k_island_flags)
     uint32_t* body_words;           // [n_bodies][2] per body of a big island: rows before it / the level of its last row
     uint32_t* ints;                 // [int_cap] per-row level, rows in level order, level starts (counts[6] handed out)
@@ -211,6 +215,7 @@ hipError_t launch_island_pair_keys(hipStream_t stream, const WorldView& w, const
 hipError_t island_sort_keys(hipStream_t stream, void* tmp, size_t& tmp_bytes, const uint64_t* in, uint64_t* out, uint32_t n);
 hipError_t island_sort_pairs(hipStream_t stream, void* tmp, size_t& tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint32_t n);
 hipError_t launch_island_build(hipStream_t stream, const WorldView& w, const IslandParams& ip, bool orphans);
+size_t island_scan_bytes(uint32_t n);
 hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const GroundParams& g, const IslandParams& ip, bool bullet_basis);
 hipError_t launch_ground(hipStream_t stream, const WorldView& w, const GroundParams& g, bool bullet_basis);
 

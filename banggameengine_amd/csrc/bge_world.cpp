@@ -1050,12 +1050,18 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     // islands a workgroup solves level by level (k_island_solve_big): the list of them, two words per body, four per point for the levels
     const uint64_t int_cap = 2ull * row_cap + 8ull * n_bodies + 64;
     HIP_TRY(w->isl_big_list.ensure(static_cast<size_t>(n_bodies) * 16)); // (two lists: big islands, mid islands)
-    HIP_TRY(w->isl_body_words.ensure(static_cast<size_t>(n_bodies) * 12)); // (two words a body for the workgroup solver + pair_first)
+    HIP_TRY(w->isl_body_words.ensure(static_cast<size_t>(n_bodies) * 20 + 16)); // (two words a body for the workgroup solver, pair_first, row_count, row_first)
+    const size_t scan_bytes = bge::island_scan_bytes(n_bodies);
+    HIP_TRY(w->isl_sort_tmp.ensure(std::max<size_t>(scan_bytes, 16)));
     HIP_TRY(w->isl_ints.ensure(static_cast<size_t>(int_cap) * 4));
     ip.big_list = w->isl_big_list.as<uint32_t>();
     ip.mid_list = ip.big_list + 2ull * n_bodies;
     ip.body_words = w->isl_body_words.as<uint32_t>();
     ip.pair_first = ip.body_words + 2ull * n_bodies;
+    ip.row_count = ip.pair_first + n_bodies;
+    ip.row_first = ip.row_count + n_bodies;
+    ip.scan_tmp = w->isl_sort_tmp.p;
+    ip.scan_tmp_bytes = scan_bytes;
     ip.ints = w->isl_ints.as<uint32_t>();
     ip.int_cap = static_cast<uint32_t>(std::min<uint64_t>(int_cap, 0xffffffffu));
     ip.big_points = w->isl_big_points;
