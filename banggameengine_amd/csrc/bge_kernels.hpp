@@ -123,7 +123,7 @@ struct IslandParams {
     const uint32_t* entity_of_slot;
     const uint32_t* slot_of_entity;
     const uint32_t* gen_of_entity;  // how often the entity's body was (re)created
-    uint32_t* counts;               // [0] pairs of Dynamic boxes found, [1] bodies in islands, [2] rows handed out, [3] error bits,
+    uint32_t* counts;               // [0] pairs of Dynamic boxes found, [1] bodies in islands, [2] unused, [3] error bits,
                                     // [4] big islands listed, [5] their ticket, [6] ints handed out, [7] mid islands listed
     // pairs: key = lower entity << 32 | higher entity
     const uint2* bp_stage;          // the broadphase's pair list (slot, slot) in its shard slices (Broadphase::slices)
