@@ -749,8 +749,9 @@ __device__ uint32_t isl_pair_points(const IslandParams& ip, uint32_t i)
 // entity (ascending) — rows j, j + 1, ... of the island; returns the row after its last
 template <bool WARM>
 __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& g, const IslandParams& ip, IslBody* sb, uint32_t i, float invTimeStep,
-                                        IslRow* normalRow, IslRow* frictionRow, uint32_t j)
+                                        IslRow* normalRow, IslRow* frictionRow, uint32_t j, uint32_t only = kNone)
 {
+    // (only != kNone: just that row of the island's list — k_island_rows has a thread for every row)
         const uint32_t slot = sb[i].slot;
         const uint32_t ci = w.cinfo[slot];
         const M3 basis = bt_mat_from_quat(ld4(w.quat, slot));
@@ -761,6 +762,10 @@ __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& 
             const float combinedFriction = fmaxf(-10.0f, fminf(10.0f, bodyFriction * 1.0f));
             float* mp = w.manifold + 32ull * slot;
             for (uint32_t k = 0; k < n; ++k) {
+                if (only != kNone && j != only) {
+                    j++;
+                    continue;
+                }
                 const F3 worldA = xform_point(basis, pos, F3{mp[8 * k], mp[8 * k + 1], mp[8 * k + 2]});
                 isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, F3{0.0f, 1.0f, 0.0f}, mp[8 * k + 5],
                                 combinedFriction, 0.0f, mp + 8 * k + 3, 4u);
@@ -788,6 +793,10 @@ __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& 
                 float* pts = reinterpret_cast<float*>(hdr + 4);
                 for (uint32_t k = 0; k < hdr[1]; ++k) {
                     float* c = pts + 12 * k;
+                    if (only != kNone && j != only) {
+                        j++;
+                        continue;
+                    }
                     const F3 worldA = xform_point(basis, pos, bp_get3(c, 0));
                     isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, bp_get3(c, 6), c[9], combinedFriction,
                                     combinedRestitution, c + 10, 1u);
@@ -807,6 +816,10 @@ __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& 
             float* pts = reinterpret_cast<float*>(m + 4);
             for (uint32_t q = 0; q < m[0]; ++q) {
                 float* c = pts + 12 * q;
+                if (only != kNone && j != only) {
+                    j++;
+                    continue;
+                }
                 const F3 worldA = xform_point(basis, pos, bp_get3(c, 0));
                 const F3 worldB = xform_point_b(basis_b, sb[ib].origin, bp_get3(c, 3));
                 isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], i, ib, invTimeStep, worldA, worldB, bp_get3(c, 6), c[9], combinedFriction, combinedRestitution,
@@ -892,21 +905,27 @@ __global__ void __launch_bounds__(64) k_island_bodies(WorldView w, GroundParams 
     ip.row_count[i] = n;
 }
 
-// convertContacts, one thread a body: the body's rows at their place in the island's row list (row_first: the exclusive sum of the
-// counts over the sorted body list, so an island's rows are one run), without the warm start — that is order-dependent and the
-// solver's first sweep
+// convertContacts, one thread a ROW: rows row_first[i] .. of body i (row_first: the exclusive sum of the counts over the sorted body
+// list, so an island's rows are one run of the two arrays), without the warm start — that is order-dependent and the solvers' first sweep
 template <bool BASIS>
 __global__ void __launch_bounds__(64) k_island_rows(WorldView w, GroundParams g, IslandParams ip)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ip.n_bodies || ip.row_count[i] == 0u) return;
-    const uint32_t at = ip.row_first[i];
-    if (at + ip.row_count[i] > ip.row_cap / 2u) {
-        atomicOr(&ip.counts[3], 1u); // (cannot happen: the host sizes the arrays for every point the manifolds can hold)
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t last = ip.n_bodies - 1u;
+    if (j >= ip.row_first[last] + ip.row_count[last]) return;
+    if (j >= ip.row_cap / 2u) {
+        if (j == ip.row_cap / 2u) atomicOr(&ip.counts[3], 1u); // (cannot happen: the host sizes the arrays for every point the manifolds can hold)
         return;
     }
+    // the body whose run holds row j: the last one that starts at or before it (bodies without rows share their successor's start)
+    uint32_t lo = 0, hi = ip.n_bodies;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ip.row_first[mid] <= j) lo = mid;
+        else hi = mid;
+    }
     IslRow* normalRow = static_cast<IslRow*>(ip.rows);
-    isl_build_body_rows<false>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), i, 1.0f / g.dt, normalRow, normalRow + ip.row_cap / 2u, at);
+    isl_build_body_rows<false>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), lo, 1.0f / g.dt, normalRow, normalRow + ip.row_cap / 2u, ip.row_first[lo], j);
 }
 
 // MID = false: the grid walks the sorted body list, an island's first body solves it — or hands it on: to the mid list (5 .. kIslMidBodies bodies:
@@ -1427,12 +1446,13 @@ hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const Gro
     hipLaunchKernelGGL(k_island_flags, dim3((ip.n_bodies + 255u) / 256u), dim3(256), 0, stream, w, ip);
     const dim3 grid((ip.n_bodies + 63u) / 64u), block(64);
     size_t scan_bytes = ip.scan_tmp_bytes;
+    const dim3 row_grid((ip.row_cap / 2u + 64u) / 64u); // (a thread for every row the arrays can hold; those past the last row leave at once)
     const dim3 mid_grid((ip.n_bodies / (kIslLdsBodies + 1u) + 64u) / 64u); // (an island on the mid list has more than kIslLdsBodies bodies)
     if (bullet_basis) {
         hipLaunchKernelGGL(k_island_own<true>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL(k_island_bodies<true>, grid, block, 0, stream, w, g, ip);
         (void)hipcub::DeviceScan::ExclusiveSum(ip.scan_tmp, scan_bytes, ip.row_count, ip.row_first, static_cast<int>(ip.n_bodies), stream);
-        hipLaunchKernelGGL(k_island_rows<true>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL(k_island_rows<true>, row_grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<true, true>), mid_grid, block, 0, stream, w, g, ip);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));
@@ -1441,7 +1461,7 @@ hipError_t launch_island_solve(hipStream_t stream, const WorldView& w, const Gro
         hipLaunchKernelGGL(k_island_own<false>, grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL(k_island_bodies<false>, grid, block, 0, stream, w, g, ip);
         (void)hipcub::DeviceScan::ExclusiveSum(ip.scan_tmp, scan_bytes, ip.row_count, ip.row_first, static_cast<int>(ip.n_bodies), stream);
-        hipLaunchKernelGGL(k_island_rows<false>, grid, block, 0, stream, w, g, ip);
+        hipLaunchKernelGGL(k_island_rows<false>, row_grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, false>), grid, block, 0, stream, w, g, ip);
         hipLaunchKernelGGL((k_island_solve<false, true>), mid_grid, block, 0, stream, w, g, ip);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_island_solve_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kIslBigLdsBytes));
