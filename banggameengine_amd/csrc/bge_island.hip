@@ -34,17 +34,25 @@ struct IslBody {
     uint32_t slot, woken, pad;
 };
 static_assert(sizeof(IslBody) == kIslBodyBytes, "IslandParams::solver_bodies");
+// What every sweep reads of a row, and nothing else: 96 bytes.  The sweeps are bound by these bytes — the rows of 100 k two-box stacks were
+// 205 MB of 128-byte records read ten times a tick, 2.18 GB per launch by FETCH_SIZE, 0.65 of the HBM peak (profiles/r03/pmc_islands.md).
+// A contact row's limits are constants (0 and 1e10), a friction row's follow from its contact row's impulse at every visit.
 struct IslRow {
     F3 normal, relposCrossN, angularComp, relpos2CrossN, angularCompB;
-    float jacDiagABInv, rhs, rhsPenetration, cfm, lower, upper, friction, applied, appliedPush;
-    uint32_t a, b;       // positions in the sorted body list; b = kNone: the fixed solver body
-    float* out;          // the manifold point's appliedImpulse (contact rows only)
-    uint32_t lateral_at; // ... and how many floats behind it appliedImpulseLateral1 is
+    float jacDiagABInv, rhs, cfm, friction, applied;
+    uint32_t a, b;            // positions in the sorted body list; b = kNone: the fixed solver body
     float invMassA, invMassB; // the two bodies' inverse masses (B's 0 without a second body): a resolve out of LDS state then needs no load
                               // of its own — one issued behind the next row's would have to wait for that one first (loads return in order)
-    uint32_t pad;
 };
 static_assert(sizeof(IslRow) == kIslRowBytes, "IslandParams::rows");
+// ... and what only the split-impulse sweeps and the write-back need of a CONTACT row: 32 bytes in an array of their own
+struct IslRowCold {
+    float* out;          // the manifold point's appliedImpulse
+    uint32_t lateral_at; // ... and how many floats behind it appliedImpulseLateral1 is
+    float rhsPenetration, appliedPush;
+    uint32_t pad[3];
+};
+static_assert(sizeof(IslRowCold) == kIslRowColdBytes, "IslandParams::rows_cold");
 
 __device__ __forceinline__ uint32_t isl_find(uint32_t* parent, uint32_t s)
 {
@@ -308,7 +316,7 @@ __device__ __forceinline__ float isl_dot3s(const F3& u, const F3& v) { return u.
 __device__ __forceinline__ F3 neg3(const F3& a) { return F3{-a.x, -a.y, -a.z}; }
 
 // oracle/island_ref.h isl::ResolveRow2
-__device__ void isl_resolve_row(IslBody* sb, IslRow& c, bool withUpperLimit)
+__device__ void isl_resolve_row(IslBody* sb, IslRow& c, float lower, float upper, bool withUpperLimit)
 {
     IslBody& a = sb[c.a];
     const bool two = c.b != kNone;
@@ -318,16 +326,16 @@ __device__ void isl_resolve_row(IslBody* sb, IslRow& c, bool withUpperLimit)
     deltaImpulse = __builtin_fmaf(-dv1, c.jacDiagABInv, deltaImpulse);
     deltaImpulse = __builtin_fmaf(-dv2, c.jacDiagABInv, deltaImpulse);
     const float sum = c.applied + deltaImpulse;
-    if (c.lower < sum) {
-        if (withUpperLimit && !(sum < c.upper)) {
-            deltaImpulse = c.upper - c.applied;
-            c.applied = c.upper;
+    if (lower < sum) {
+        if (withUpperLimit && !(sum < upper)) {
+            deltaImpulse = upper - c.applied;
+            c.applied = upper;
         } else {
             c.applied = sum;
         }
     } else {
-        deltaImpulse = c.lower - c.applied;
-        c.applied = c.lower;
+        deltaImpulse = lower - c.applied;
+        c.applied = lower;
     }
     a.dLin = F3{__builtin_fmaf(c.normal.x * a.invMass, deltaImpulse, a.dLin.x), __builtin_fmaf(c.normal.y * a.invMass, deltaImpulse, a.dLin.y),
                 __builtin_fmaf(c.normal.z * a.invMass, deltaImpulse, a.dLin.z)};
@@ -343,22 +351,22 @@ __device__ void isl_resolve_row(IslBody* sb, IslRow& c, bool withUpperLimit)
 }
 
 // oracle/island_ref.h isl::ResolveSplitPenetration2
-__device__ void isl_resolve_split(IslBody* sb, IslRow& c)
+__device__ void isl_resolve_split(IslBody* sb, const IslRow& c, float rhsPenetration, float& appliedPush)
 {
-    if (!c.rhsPenetration) return;
+    if (!rhsPenetration) return;
     IslBody& a = sb[c.a];
     const bool two = c.b != kNone;
-    float deltaImpulse = c.rhsPenetration - c.appliedPush * c.cfm;
+    float deltaImpulse = rhsPenetration - appliedPush * c.cfm;
     const float dv1 = isl_dot3s(c.normal, a.push) + isl_dot3s(c.relposCrossN, a.turn);
     const float dv2 = two ? isl_dot3s(neg3(c.normal), sb[c.b].push) + isl_dot3s(c.relpos2CrossN, sb[c.b].turn) : 0.0f + 0.0f;
     deltaImpulse = deltaImpulse - dv1 * c.jacDiagABInv;
     deltaImpulse = deltaImpulse - dv2 * c.jacDiagABInv;
-    const float sum = c.appliedPush + deltaImpulse;
-    if (sum < c.lower) {
-        deltaImpulse = c.lower - c.appliedPush;
-        c.appliedPush = c.lower;
+    const float sum = appliedPush + deltaImpulse;
+    if (sum < 0.0f) {
+        deltaImpulse = 0.0f - appliedPush;
+        appliedPush = 0.0f;
     } else {
-        c.appliedPush = sum;
+        appliedPush = sum;
     }
     const F3 lin = F3{c.normal.x * a.invMass, c.normal.y * a.invMass, c.normal.z * a.invMass};
     a.push = add3(a.push, scale3(lin, deltaImpulse));
@@ -384,7 +392,7 @@ __device__ __forceinline__ M3 isl_inv_i(const IslBody& b)
 
 // One contact's two rows, warm started: oracle/island_ref.h SolveIsland's loop body (ct_add_contact with a second body)
 template <bool WARM = true>
-__device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia, uint32_t ib, float invTimeStep, const F3& worldA, const F3& worldB,
+__device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, IslRowCold& cc, uint32_t ia, uint32_t ib, float invTimeStep, const F3& worldA, const F3& worldB,
                                 const F3& n, float distance, float friction, float combinedRestitution, float* out, uint32_t lateral_at)
 {
     constexpr float kErp2 = 0.2f, kSplitThreshold = -0.04f, kWarmstart = 0.85f, kSor = 1.0f, kRestitutionVelocityThreshold = 0.2f;
@@ -393,13 +401,11 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
     const F3 zero{0.0f, 0.0f, 0.0f};
     c.a = fr.a = ia;
     c.b = fr.b = ib;
-    c.out = out;
-    c.lateral_at = lateral_at;
-    fr.out = nullptr;
-    fr.lateral_at = 0u;
+    cc.out = out;
+    cc.lateral_at = lateral_at;
+    cc.pad[0] = cc.pad[1] = cc.pad[2] = 0u;
     c.invMassA = fr.invMassA = A.invMass;
     c.invMassB = fr.invMassB = two ? sb[ib].invMass : 0.0f;
-    c.pad = fr.pad = 0u;
     const M3 invIA = isl_inv_i(A);
     const F3 rel_pos1 = sub3(worldA, A.origin);
     const F3 vel1 = add3(add3(A.linVel, A.extForce), cross3(add3(A.angVel, A.extTorque), rel_pos1));
@@ -455,7 +461,7 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
             B.dAng = add3(B.dAng, scale3(c.angularCompB, c.applied * 1.0f));
         }
     }
-    c.appliedPush = 0.0f;
+    cc.appliedPush = 0.0f;
     {
         const float vel1Dotn = dot_xzy(c.normal, add3(A.linVel, A.extForce)) + dot_xzy(c.relposCrossN, add3(A.angVel, A.extTorque));
         float vel2Dotn = 0.0f + 0.0f;
@@ -477,14 +483,12 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
         const float velocityImpulse = velocityError * c.jacDiagABInv;
         if (penetration > kSplitThreshold) {
             c.rhs = penetrationImpulse + velocityImpulse;
-            c.rhsPenetration = 0.0f;
+            cc.rhsPenetration = 0.0f;
         } else {
             c.rhs = velocityImpulse;
-            c.rhsPenetration = penetrationImpulse;
+            cc.rhsPenetration = penetrationImpulse;
         }
         c.cfm = 0.0f * c.jacDiagABInv;
-        c.lower = 0.0f;
-        c.upper = 1e10f;
     }
     F3 dir = sub3(vel, scale3(n, rel_vel));
     const float lat_rel_vel = dot3(dir, dir);
@@ -525,13 +529,9 @@ __device__ void isl_add_contact(IslBody* sb, IslRow& c, IslRow& fr, uint32_t ia,
         const float velocityError = 0.0f - rv;
         const float velocityImpulse = velocityError * fr.jacDiagABInv;
         fr.rhs = 0.0f + velocityImpulse;
-        fr.rhsPenetration = 0.0f;
         fr.cfm = 0.0f;
-        fr.lower = -fr.friction;
-        fr.upper = fr.friction;
     }
     fr.applied = 0.0f;
-    fr.appliedPush = 0.0f;
 }
 
 // ---- the iterations of a small island out of LDS.  In global memory every row update is a store that the next row's load has to wait
@@ -606,13 +606,13 @@ __device__ __forceinline__ void isl_resolve_row_lds(const Local& L, const IslBod
 
 // isl_resolve_split on that state (fields 2 push, 3 turn)
 template <class Local>
-__device__ __forceinline__ void isl_resolve_split_lds(const Local& L, const IslBody* sb, const IslRow& c, float& appliedPush)
+__device__ __forceinline__ void isl_resolve_split_lds(const Local& L, const IslBody* sb, const IslRow& c, float rhsPenetration, float& appliedPush)
 {
-    if (!c.rhsPenetration) return;
+    if (!rhsPenetration) return;
     const bool two = c.b != kNone;
     const float invMassA = c.invMassA;
     const F3 aPush = L.get(c.a, 2), aTurn = L.get(c.a, 3);
-    float deltaImpulse = c.rhsPenetration - appliedPush * c.cfm;
+    float deltaImpulse = rhsPenetration - appliedPush * c.cfm;
     const float dv1 = isl_dot3s(c.normal, aPush) + isl_dot3s(c.relposCrossN, aTurn);
     F3 bPush{0.0f, 0.0f, 0.0f}, bTurn{0.0f, 0.0f, 0.0f};
     float invMassB = 0.0f;
@@ -625,9 +625,9 @@ __device__ __forceinline__ void isl_resolve_split_lds(const Local& L, const IslB
     deltaImpulse = deltaImpulse - dv1 * c.jacDiagABInv;
     deltaImpulse = deltaImpulse - dv2 * c.jacDiagABInv;
     const float sum = appliedPush + deltaImpulse;
-    if (sum < c.lower) {
-        deltaImpulse = c.lower - appliedPush;
-        appliedPush = c.lower;
+    if (sum < 0.0f) {
+        deltaImpulse = 0.0f - appliedPush;
+        appliedPush = 0.0f;
     } else {
         appliedPush = sum;
     }
@@ -749,7 +749,7 @@ __device__ uint32_t isl_pair_points(const IslandParams& ip, uint32_t i)
 // entity (ascending) — rows j, j + 1, ... of the island; returns the row after its last
 template <bool WARM>
 __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& g, const IslandParams& ip, IslBody* sb, uint32_t i, float invTimeStep,
-                                        IslRow* normalRow, IslRow* frictionRow, uint32_t j, uint32_t only = kNone)
+                                        IslRow* normalRow, IslRow* frictionRow, IslRowCold* coldRow, uint32_t j, uint32_t only = kNone)
 {
     // (only != kNone: just that row of the island's list — k_island_rows has a thread for every row)
         const uint32_t slot = sb[i].slot;
@@ -767,7 +767,7 @@ __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& 
                     continue;
                 }
                 const F3 worldA = xform_point(basis, pos, F3{mp[8 * k], mp[8 * k + 1], mp[8 * k + 2]});
-                isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, F3{0.0f, 1.0f, 0.0f}, mp[8 * k + 5],
+                isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], coldRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, F3{0.0f, 1.0f, 0.0f}, mp[8 * k + 5],
                                 combinedFriction, 0.0f, mp + 8 * k + 3, 4u);
                 j++;
             }
@@ -798,7 +798,7 @@ __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& 
                         continue;
                     }
                     const F3 worldA = xform_point(basis, pos, bp_get3(c, 0));
-                    isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, bp_get3(c, 6), c[9], combinedFriction,
+                    isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], coldRow[j], i, kNone, invTimeStep, worldA, F3{0.0f, 0.0f, 0.0f}, bp_get3(c, 6), c[9], combinedFriction,
                                     combinedRestitution, c + 10, 1u);
                     j++;
                 }
@@ -822,7 +822,7 @@ __device__ uint32_t isl_build_body_rows(const WorldView& w, const GroundParams& 
                 }
                 const F3 worldA = xform_point(basis, pos, bp_get3(c, 0));
                 const F3 worldB = xform_point_b(basis_b, sb[ib].origin, bp_get3(c, 3));
-                isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], i, ib, invTimeStep, worldA, worldB, bp_get3(c, 6), c[9], combinedFriction, combinedRestitution,
+                isl_add_contact<WARM>(sb, normalRow[j], frictionRow[j], coldRow[j], i, ib, invTimeStep, worldA, worldB, bp_get3(c, 6), c[9], combinedFriction, combinedRestitution,
                                 c + 10, 1u);
                 j++;
             }
@@ -925,7 +925,8 @@ __global__ void __launch_bounds__(64) k_island_rows(WorldView w, GroundParams g,
         else hi = mid;
     }
     IslRow* normalRow = static_cast<IslRow*>(ip.rows);
-    isl_build_body_rows<false>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), lo, 1.0f / g.dt, normalRow, normalRow + ip.row_cap / 2u, ip.row_first[lo], j);
+    isl_build_body_rows<false>(w, g, ip, static_cast<IslBody*>(ip.solver_bodies), lo, 1.0f / g.dt, normalRow, normalRow + ip.row_cap / 2u,
+                               static_cast<IslRowCold*>(ip.rows_cold), ip.row_first[lo], j);
 }
 
 // MID = false: the grid walks the sorted body list, an island's first body solves it — or hands it on: to the mid list (5 .. kIslMidBodies bodies:
@@ -987,6 +988,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     if (row0 + n_points > ip.row_cap / 2u) return; // (reported by k_island_rows)
     IslRow* normalRow = static_cast<IslRow*>(ip.rows) + row0;
     IslRow* frictionRow = static_cast<IslRow*>(ip.rows) + ip.row_cap / 2u + row0;
+    IslRowCold* coldRow = static_cast<IslRowCold*>(ip.rows_cold) + row0;
     // ---- solveGroupCacheFriendlySplitImpulseIterations, solveGroupCacheFriendlyIterations
     if (!MID && small) {
         const IslLocal L{s_isl + (threadIdx.x & 63u), first};
@@ -1004,12 +1006,12 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         //  waits for is then the LDS round trip of the bodies it shares with the row before, not a global load per row)
         for (int it = 0; it < kIterations; ++it) {
             bool any = false;
-            for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
+            for (uint32_t r = 0; r < n_points; ++r) any = any || coldRow[r].rhsPenetration != 0.0f;
             if (!any) break; // (no row takes the split impulse: every sweep would return at its first test)
             IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
-                isl_resolve_split_lds(L, sb, cur, L.row(r, 1));
+                isl_resolve_split_lds(L, sb, cur, coldRow[r].rhsPenetration, L.row(r, 1));
                 cur = nxt;
             }
         }
@@ -1018,7 +1020,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
             IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
-                isl_resolve_row_lds(L, sb, cur, L.row(r, 0), cur.lower, cur.upper, false);
+                isl_resolve_row_lds(L, sb, cur, L.row(r, 0), 0.0f, 1e10f, false);
                 cur = nxt;
             }
             cur = frictionRow[0];
@@ -1052,14 +1054,16 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         for (uint32_t r = 0; r < n_points; ++r) isl_warm_start_lds(L, sb, normalRow[r]); // (the warm start, in the rows' order)
         for (int it = 0; it < kIterations; ++it) {
             bool any = false;
-            for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
+            for (uint32_t r = 0; r < n_points; ++r) any = any || coldRow[r].rhsPenetration != 0.0f;
             if (!any) break;
             IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
-                if (cur.rhsPenetration) {
-                    isl_resolve_split_lds(L, sb, cur, cur.appliedPush);
-                    normalRow[r].appliedPush = cur.appliedPush;
+                const float rhsPenetration = coldRow[r].rhsPenetration;
+                if (rhsPenetration) {
+                    float appliedPush = coldRow[r].appliedPush;
+                    isl_resolve_split_lds(L, sb, cur, rhsPenetration, appliedPush);
+                    coldRow[r].appliedPush = appliedPush;
                 }
                 cur = nxt;
             }
@@ -1069,16 +1073,14 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
             IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
-                isl_resolve_row_lds(L, sb, cur, cur.applied, cur.lower, cur.upper, false);
+                isl_resolve_row_lds(L, sb, cur, cur.applied, 0.0f, 1e10f, false);
                 normalRow[r].applied = cur.applied;
-                frictionRow[r].appliedPush = cur.applied; // (a friction row has no push impulse: the word carries its contact row's impulse to
-                                                          //  the friction sweep inside the row — no load of its own behind the next row's)
                 cur = nxt;
             }
             cur = frictionRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = frictionRow[r + 1 < n_points ? r + 1 : r];
-                const float totalImpulse = cur.appliedPush;
+                const float totalImpulse = normalRow[r].applied;
                 if (totalImpulse > 0.0f) {
                     const float friction = cur.friction;
                     isl_resolve_row_lds(L, sb, cur, cur.applied, -(friction * totalImpulse), friction * totalImpulse, true);
@@ -1099,14 +1101,16 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
         for (uint32_t r = 0; r < n_points; ++r) isl_warm_start(sb, normalRow[r]);
         for (int it = 0; it < kIterations; ++it) {
             bool any = false;
-            for (uint32_t r = 0; r < n_points; ++r) any = any || normalRow[r].rhsPenetration != 0.0f;
+            for (uint32_t r = 0; r < n_points; ++r) any = any || coldRow[r].rhsPenetration != 0.0f;
             if (!any) break;
             IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
-                if (cur.rhsPenetration) {
-                    isl_resolve_split(sb, cur);
-                    normalRow[r].appliedPush = cur.appliedPush;
+                const float rhsPenetration = coldRow[r].rhsPenetration;
+                if (rhsPenetration) {
+                    float appliedPush = coldRow[r].appliedPush;
+                    isl_resolve_split(sb, cur, rhsPenetration, appliedPush);
+                    coldRow[r].appliedPush = appliedPush;
                 }
                 cur = nxt;
             }
@@ -1116,7 +1120,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
             IslRow cur = normalRow[0];
             for (uint32_t r = 0; r < n_points; ++r) {
                 const IslRow nxt = normalRow[r + 1 < n_points ? r + 1 : r];
-                isl_resolve_row(sb, cur, false);
+                isl_resolve_row(sb, cur, 0.0f, 1e10f, false);
                 normalRow[r].applied = cur.applied;
                 cur = nxt;
             }
@@ -1125,9 +1129,7 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
                 const IslRow nxt = frictionRow[r + 1 < n_points ? r + 1 : r];
                 const float totalImpulse = normalRow[r].applied;
                 if (totalImpulse > 0.0f) {
-                    cur.lower = -(cur.friction * totalImpulse);
-                    cur.upper = cur.friction * totalImpulse;
-                    isl_resolve_row(sb, cur, true);
+                    isl_resolve_row(sb, cur, -(cur.friction * totalImpulse), cur.friction * totalImpulse, true);
                     frictionRow[r].applied = cur.applied;
                 }
                 cur = nxt;
@@ -1136,8 +1138,8 @@ __global__ void __launch_bounds__(64) k_island_solve(WorldView w, GroundParams g
     }
     // ---- solveGroupCacheFriendlyFinish
     for (uint32_t r = 0; r < n_points; ++r) {
-        normalRow[r].out[0] = normalRow[r].applied;
-        normalRow[r].out[normalRow[r].lateral_at] = frictionRow[r].applied;
+        coldRow[r].out[0] = normalRow[r].applied;
+        coldRow[r].out[coldRow[r].lateral_at] = frictionRow[r].applied;
     }
     for (uint32_t i = first; i < end; ++i) isl_finish_body<BASIS>(w, g, sb, i);
 }
@@ -1218,6 +1220,7 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         if (s_fail) continue;
         IslRow* normalRow = static_cast<IslRow*>(ip.rows) + row0;
         IslRow* frictionRow = static_cast<IslRow*>(ip.rows) + ip.row_cap / 2u + row0;
+        IslRowCold* coldRow = static_cast<IslRowCold*>(ip.rows_cold) + row0;
         uint32_t* level = ip.ints + s_ints_at;  // [P] level of row r (1 ..)
         uint32_t* order = level + P;            // [P] rows in level order
         uint32_t* start = order + P;            // [depth + 2] first entry of level l in `order`
@@ -1238,7 +1241,7 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         {
             uint32_t any = 0u;
             for (uint32_t r = tid; r < P; r += 256u) {
-                any |= normalRow[r].rhsPenetration != 0.0f ? 1u : 0u;
+                any |= coldRow[r].rhsPenetration != 0.0f ? 1u : 0u;
                 if (walk_in_lds) {
                     const uint32_t b = normalRow[r].b;
                     l_ab[2u * r] = normalRow[r].a - first;
@@ -1347,10 +1350,12 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         if (s_any) {
             for (int it = 0; it < kIterations; ++it) {
                 sweep(normalRow, [&](IslRow& c, uint32_t r) {
-                    if (c.rhsPenetration) {
-                        if (bodies_in_lds) isl_resolve_split_lds(L, sb, c, c.appliedPush);
-                        else isl_resolve_split(sb, c);
-                        normalRow[r].appliedPush = c.appliedPush;
+                    const float rhsPenetration = coldRow[r].rhsPenetration;
+                    if (rhsPenetration) {
+                        float appliedPush = coldRow[r].appliedPush;
+                        if (bodies_in_lds) isl_resolve_split_lds(L, sb, c, rhsPenetration, appliedPush);
+                        else isl_resolve_split(sb, c, rhsPenetration, appliedPush);
+                        coldRow[r].appliedPush = appliedPush;
                     }
                 });
             }
@@ -1358,18 +1363,16 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         // solveGroupCacheFriendlyIterations: all contact rows, then all friction rows
         for (int it = 0; it < kIterations; ++it) {
             sweep(normalRow, [&](IslRow& c, uint32_t r) {
-                if (bodies_in_lds) isl_resolve_row_lds(L, sb, c, c.applied, c.lower, c.upper, false);
-                else isl_resolve_row(sb, c, false);
+                if (bodies_in_lds) isl_resolve_row_lds(L, sb, c, c.applied, 0.0f, 1e10f, false);
+                else isl_resolve_row(sb, c, 0.0f, 1e10f, false);
                 normalRow[r].applied = c.applied;
-                frictionRow[r].appliedPush = c.applied; // (carries the contact row's impulse to the friction sweep inside the friction row)
             });
             sweep(frictionRow, [&](IslRow& c, uint32_t r) {
-                const float totalImpulse = c.appliedPush;
+                const float totalImpulse = normalRow[r].applied;
                 if (totalImpulse > 0.0f) {
-                    c.lower = -(c.friction * totalImpulse);
-                    c.upper = c.friction * totalImpulse;
-                    if (bodies_in_lds) isl_resolve_row_lds(L, sb, c, c.applied, c.lower, c.upper, true);
-                    else isl_resolve_row(sb, c, true);
+                    const float lower = -(c.friction * totalImpulse), upper = c.friction * totalImpulse;
+                    if (bodies_in_lds) isl_resolve_row_lds(L, sb, c, c.applied, lower, upper, true);
+                    else isl_resolve_row(sb, c, lower, upper, true);
                     frictionRow[r].applied = c.applied;
                 }
             });
@@ -1385,8 +1388,8 @@ __global__ void __launch_bounds__(256) k_island_solve_big(WorldView w, GroundPar
         }
         // solveGroupCacheFriendlyFinish
         for (uint32_t r = tid; r < P; r += 256u) {
-            normalRow[r].out[0] = normalRow[r].applied;
-            normalRow[r].out[normalRow[r].lateral_at] = frictionRow[r].applied;
+            coldRow[r].out[0] = normalRow[r].applied;
+            coldRow[r].out[coldRow[r].lateral_at] = frictionRow[r].applied;
         }
         for (uint32_t i = first + tid; i < end; i += 256u) isl_finish_body<BASIS>(w, g, sb, i);
     }

@@ -150,6 +150,7 @@ struct IslandParams {
     uint32_t body_cap, n_bodies;
     void* solver_bodies;            // [n_bodies] IslBody
     void* rows;                     // [row_cap] IslRow: the contact rows in [0, row_cap / 2), the friction rows behind them
+    void* rows_cold;                // [row_cap / 2] IslRowCold: what only the split-impulse sweeps and the write-back need of a contact row
     uint32_t row_cap;
     uint32_t iterations;            // 10 (btContactSolverInfo::m_numIterations); BGE_ISLAND_ITERATIONS overrides it for MEASUREMENTS only
     // islands too big for one thread's LDS column: k_island_solve lists them, k_island_solve_big takes a workgroup to each
@@ -165,7 +166,7 @@ struct IslandParams {
     uint32_t int_cap;
     uint32_t big_points;            // islands with more contact points than this go to k_island_solve_big (128; BGE_ISLAND_BIG_POINTS for tests)
 };
-constexpr uint32_t kIslBodyBytes = 160, kIslRowBytes = 128;
+constexpr uint32_t kIslBodyBytes = 160, kIslRowBytes = 96, kIslRowColdBytes = 32;
 
 constexpr uint32_t kGroundShards = 64;
 constexpr uint32_t kObstacleGridMin = 64, kObstacleGridAxis = 64, kObstacleGridWide = 32, kObstacleGridStart = 40,

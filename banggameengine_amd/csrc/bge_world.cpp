@@ -1043,9 +1043,10 @@ int island_substep(bge_world* w, bge::GroundParams& gp, uint64_t n_slots, bool b
     const uint64_t own_points = (w->ground_plane ? 4ull : 0ull) + (w->static_contacts_ever ? 4ull * bge::kBoxManifolds : 0ull); // (rows of obstacle manifolds outlive the switch)
     const uint64_t row_cap = 2ull * (own_points * n_bodies + 4ull * n_pairs) + 2;
     HIP_TRY(w->isl_solver_bodies.ensure(static_cast<size_t>(n_bodies) * bge::kIslBodyBytes));
-    HIP_TRY(w->isl_rows.ensure(static_cast<size_t>(row_cap) * bge::kIslRowBytes));
+    HIP_TRY(w->isl_rows.ensure(static_cast<size_t>(row_cap) * bge::kIslRowBytes + static_cast<size_t>(row_cap / 2 + 1) * bge::kIslRowColdBytes));
     ip.solver_bodies = w->isl_solver_bodies.p;
     ip.rows = w->isl_rows.p;
+    ip.rows_cold = static_cast<char*>(w->isl_rows.p) + static_cast<size_t>(row_cap) * bge::kIslRowBytes;
     ip.row_cap = static_cast<uint32_t>(std::min<uint64_t>(row_cap, 0xffffffffu));
     // islands a workgroup solves level by level (k_island_solve_big): the list of them, two words per body, four per point for the levels
     const uint64_t int_cap = 2ull * row_cap + 8ull * n_bodies + 64;
